@@ -1,0 +1,177 @@
+"""ctypes front-end for the CPU checker libraries -- TEST INFRASTRUCTURE ONLY.
+
+Two libraries export the same entry points under different prefixes:
+
+* ``oracle/liboracle.so``        (prefix ``x265o_``): our plain-C restatement, travels to the GPU box.
+* ``oracle/_ref/libx265ref.so``  (prefix ``x265r_``): the real reference C path built from
+  /root/reference by ``oracle/Makefile`` (present only where it was built).
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+MAX_MVC = 12
+
+ME_JOB = np.dtype([
+    ("fenc_plane", "<i4"), ("ref_plane", "<i4"),
+    ("pu_x", "<i2"), ("pu_y", "<i2"),
+    ("pu_w", "u1"), ("pu_h", "u1"), ("method", "u1"), ("subme", "u1"),
+    ("mvmin_x", "<i2"), ("mvmin_y", "<i2"), ("mvmax_x", "<i2"), ("mvmax_y", "<i2"),
+    ("qmvp_x", "<i2"), ("qmvp_y", "<i2"),
+    ("merange", "<i2"), ("qp", "u1"), ("num_mvc", "u1"),
+    ("mvc", "<i2", (2 * MAX_MVC,)),
+], align=False)
+assert ME_JOB.itemsize == 80
+
+ME_RESULT = np.dtype([("cost", "<i4"), ("mvx", "<i2"), ("mvy", "<i2")])
+assert ME_RESULT.itemsize == 8
+
+COST_REQ = np.dtype([
+    ("fenc_plane", "<i4"), ("ref_plane", "<i4"),
+    ("pu_x", "<i2"), ("pu_y", "<i2"),
+    ("pu_w", "u1"), ("pu_h", "u1"), ("metric", "u1"), ("pad", "u1"),
+    ("qmv_x", "<i2"), ("qmv_y", "<i2"),
+])
+assert COST_REQ.itemsize == 20
+
+
+class _Plane(C.Structure):
+    _fields_ = [("origin", C.c_void_p), ("stride", C.c_ssize_t)]
+
+
+PARTS = [(4, 4), (8, 8), (8, 4), (4, 8), (16, 16), (16, 8), (8, 16), (16, 12), (12, 16), (16, 4), (4, 16),
+         (32, 32), (32, 16), (16, 32), (32, 24), (24, 32), (32, 8), (8, 32), (64, 64), (64, 32), (32, 64),
+         (64, 48), (48, 64), (64, 16), (16, 64)]
+
+
+def _ptr(a, off=0):
+    return C.c_void_p(a.ctypes.data + off)
+
+
+class Checker:
+    """One loaded checker library (oracle restatement or reference build)."""
+
+    def __init__(self, path, prefix, kind):
+        self.lib = C.CDLL(path)
+        self.prefix = prefix
+        self.kind = kind
+        self._tabs = {}
+
+    def _f(self, name, restype=None):
+        fn = getattr(self.lib, self.prefix + name)
+        fn.restype = restype
+        return fn
+
+    # ---- primitives on raw numpy buffers (offsets in elements) -------------------------
+    def sad(self, part, fenc, foff, fstride, fref, roff, rstride):
+        return self._f("sad", C.c_int)(C.c_int(part), _ptr(fenc, foff), C.c_ssize_t(fstride), _ptr(fref, roff),
+                                       C.c_ssize_t(rstride))
+
+    def satd(self, part, fenc, foff, fstride, fref, roff, rstride):
+        return self._f("satd", C.c_int)(C.c_int(part), _ptr(fenc, foff), C.c_ssize_t(fstride), _ptr(fref, roff),
+                                        C.c_ssize_t(rstride))
+
+    def sad_x3(self, part, fenc, foff, fref, roffs, rstride):
+        res = np.zeros(3, np.int32)
+        self._f("sad_x3")(C.c_int(part), _ptr(fenc, foff), _ptr(fref, roffs[0]), _ptr(fref, roffs[1]),
+                          _ptr(fref, roffs[2]), C.c_ssize_t(rstride), _ptr(res))
+        return res
+
+    def sad_x4(self, part, fenc, foff, fref, roffs, rstride):
+        res = np.zeros(4, np.int32)
+        self._f("sad_x4")(C.c_int(part), _ptr(fenc, foff), _ptr(fref, roffs[0]), _ptr(fref, roffs[1]),
+                          _ptr(fref, roffs[2]), _ptr(fref, roffs[3]), C.c_ssize_t(rstride), _ptr(res))
+        return res
+
+    def luma_hpp(self, part, src, soff, sstride, dst, doff, dstride, coeff):
+        self._f("luma_hpp")(C.c_int(part), _ptr(src, soff), C.c_ssize_t(sstride), _ptr(dst, doff),
+                            C.c_ssize_t(dstride), C.c_int(coeff))
+
+    def luma_vpp(self, part, src, soff, sstride, dst, doff, dstride, coeff):
+        self._f("luma_vpp")(C.c_int(part), _ptr(src, soff), C.c_ssize_t(sstride), _ptr(dst, doff),
+                            C.c_ssize_t(dstride), C.c_int(coeff))
+
+    def luma_hps(self, part, src, soff, sstride, dst16, doff, dstride, coeff, row_ext):
+        self._f("luma_hps")(C.c_int(part), _ptr(src, soff), C.c_ssize_t(sstride), _ptr(dst16, 2 * doff),
+                            C.c_ssize_t(dstride), C.c_int(coeff), C.c_int(row_ext))
+
+    def luma_vsp(self, part, src16, soff, sstride, dst, doff, dstride, coeff):
+        self._f("luma_vsp")(C.c_int(part), _ptr(src16, 2 * soff), C.c_ssize_t(sstride), _ptr(dst, doff),
+                            C.c_ssize_t(dstride), C.c_int(coeff))
+
+    def luma_copy_pp(self, part, dst, doff, dstride, src, soff, sstride):
+        self._f("luma_copy_pp")(C.c_int(part), _ptr(dst, doff), C.c_ssize_t(dstride), _ptr(src, soff),
+                                C.c_ssize_t(sstride))
+
+    def partition_from_sizes(self, w, h):
+        return self._f("partition_from_sizes", C.c_int)(C.c_int(w), C.c_int(h))
+
+    def bitcost_table(self, qp):
+        if qp not in self._tabs:
+            out = np.zeros(65536, np.uint16)
+            self._f("bitcost_table")(C.c_int(qp), _ptr(out))
+            self._tabs[qp] = out
+        return self._tabs[qp]
+
+    # ---- batched front-ends ------------------------------------------------------------
+    @staticmethod
+    def _planes(planes):
+        """planes: list of (buffer ndarray uint8, origin_offset, stride)."""
+        arr = (_Plane * len(planes))()
+        for i, (buf, off, stride) in enumerate(planes):
+            arr[i].origin = buf.ctypes.data + off
+            arr[i].stride = stride
+        return arr
+
+    def me_batch(self, planes, costtabs, jobs, nthreads=1):
+        """costtabs: dict qp -> uint16[65536] (centre +32768)."""
+        jobs = np.ascontiguousarray(jobs, dtype=ME_JOB)
+        out = np.zeros(len(jobs), ME_RESULT)
+        tabs = (C.c_void_p * 256)()
+        keep = []
+        for qp, t in costtabs.items():
+            t = np.ascontiguousarray(t, np.uint16)
+            keep.append(t)
+            tabs[qp] = t.ctypes.data
+        self._f("me_batch")(self._planes(planes), tabs, _ptr(jobs), C.c_int(len(jobs)), _ptr(out), C.c_int(nthreads))
+        return out
+
+    def cost_batch(self, planes, reqs, nthreads=1):
+        reqs = np.ascontiguousarray(reqs, dtype=COST_REQ)
+        out = np.zeros(len(reqs), np.int32)
+        self._f("cost_batch")(self._planes(planes), _ptr(reqs), C.c_int(len(reqs)), _ptr(out), C.c_int(nthreads))
+        return out
+
+    def ctu_fullsearch(self, fenc, ref, costtab, ctu_x, ctu_y, mvmin, mvmax, qmvp):
+        out = np.zeros(85, ME_RESULT)
+        pl = self._planes([fenc, ref])
+        costtab = np.ascontiguousarray(costtab, np.uint16)
+        self._f("ctu_fullsearch")(C.byref(pl[0]), C.byref(pl[1]), _ptr(costtab), C.c_int(ctu_x), C.c_int(ctu_y),
+                                  C.c_int(mvmin[0]), C.c_int(mvmin[1]), C.c_int(mvmax[0]), C.c_int(mvmax[1]),
+                                  C.c_int(qmvp[0]), C.c_int(qmvp[1]), _ptr(out))
+        return out
+
+
+def oracle_path():
+    return os.path.join(HERE, "liboracle.so")
+
+
+def ref_path():
+    return os.path.join(HERE, "_ref", "libx265ref.so")
+
+
+def load_oracle():
+    return Checker(oracle_path(), "x265o_", "port")
+
+
+def have_ref():
+    return os.path.exists(ref_path())
+
+
+def load_ref():
+    return Checker(ref_path(), "x265r_", "reference")

@@ -1,0 +1,262 @@
+/* ref_shim.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Thin extern "C" wrapper around the REAL reference implementation (the C primitives filled by
+ * Setup_C_Primitives and the MotionEstimate class), compiled by oracle/Makefile together with
+ * the reference's own sources where they lie under /root/reference.  It contains no arithmetic
+ * of its own: every function forwards to the reference.  Same signatures as x265_oracle.h with
+ * the x265r_ prefix so tests can swap the two libraries.
+ *
+ * Built only when /root/reference exists (this container); output goes to oracle/_ref/.
+ */
+#include "TLibCommon/TComRom.h"
+#include "primitives.h"
+#include "common.h"
+#include "lowres.h"
+#include "motion.h"
+#include "bitcost.h"
+#include "x265.h"
+
+#include <pthread.h>
+#include <string.h>
+
+#include "x265_oracle.h" /* job / result / plane structs only */
+
+using namespace x265;
+
+namespace {
+EncoderPrimitives g_c;
+pthread_once_t g_once = PTHREAD_ONCE_INIT;
+
+void init_once()
+{
+    memset(&g_c, 0, sizeof(g_c));
+    Setup_C_Primitives(g_c);
+    /* MotionEstimate reads the global table; give it the C primitives as well */
+    Setup_C_Primitives(primitives);
+    initROM();
+}
+
+inline void init() { pthread_once(&g_once, init_once); }
+
+/* exposes the protected cost-table pointer of BitCost */
+struct CostPeek : public BitCost
+{
+    const uint16_t *centre(int qp)
+    {
+        setQP(qp);
+        return m_cost;
+    }
+};
+}
+
+extern "C" {
+int x265r_partition_from_sizes(int w, int h)
+{
+    return partitionFromSizes(w, h);
+}
+
+int x265r_sad(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *fref, intptr_t rstride)
+{
+    init();
+    return g_c.sad[part]((pixel *)fenc, fstride, (pixel *)fref, rstride);
+}
+
+void x265r_sad_x3(int part, const uint8_t *fenc, const uint8_t *r0, const uint8_t *r1, const uint8_t *r2,
+                  intptr_t rstride, int32_t *res)
+{
+    init();
+    g_c.sad_x3[part]((pixel *)fenc, (pixel *)r0, (pixel *)r1, (pixel *)r2, rstride, res);
+}
+
+void x265r_sad_x4(int part, const uint8_t *fenc, const uint8_t *r0, const uint8_t *r1, const uint8_t *r2,
+                  const uint8_t *r3, intptr_t rstride, int32_t *res)
+{
+    init();
+    g_c.sad_x4[part]((pixel *)fenc, (pixel *)r0, (pixel *)r1, (pixel *)r2, (pixel *)r3, rstride, res);
+}
+
+int x265r_satd(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *fref, intptr_t rstride)
+{
+    init();
+    return g_c.satd[part]((pixel *)fenc, fstride, (pixel *)fref, rstride);
+}
+
+void x265r_luma_hpp(int part, const uint8_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int coeffIdx)
+{
+    init();
+    g_c.luma_hpp[part]((pixel *)src, sstride, dst, dstride, coeffIdx);
+}
+
+void x265r_luma_vpp(int part, const uint8_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int coeffIdx)
+{
+    init();
+    g_c.luma_vpp[part]((pixel *)src, sstride, dst, dstride, coeffIdx);
+}
+
+void x265r_luma_hps(int part, const uint8_t *src, intptr_t sstride, int16_t *dst, intptr_t dstride, int coeffIdx,
+                    int isRowExt)
+{
+    init();
+    g_c.luma_hps[part]((pixel *)src, sstride, dst, dstride, coeffIdx, isRowExt);
+}
+
+void x265r_luma_vsp(int part, const int16_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int coeffIdx)
+{
+    init();
+    g_c.luma_vsp[part]((int16_t *)src, sstride, dst, dstride, coeffIdx);
+}
+
+void x265r_luma_copy_pp(int part, uint8_t *dst, intptr_t dstride, const uint8_t *src, intptr_t sstride)
+{
+    init();
+    g_c.luma_copy_pp[part](dst, dstride, (pixel *)src, sstride);
+}
+
+void x265r_bitcost_table(int qp, uint16_t *out)
+{
+    init();
+    CostPeek p;
+    const uint16_t *c = p.centre(qp);
+    /* the reference never writes entry -32768 (bitcost.cpp:48); mirror x265o's convention */
+    memcpy(out + 1, c - 32767, 65535 * sizeof(uint16_t));
+    out[0] = out[1];
+}
+
+static void run_me(MotionEstimate &me, const x265o_plane *planes, const x265o_me_job *j, x265o_me_result *r)
+{
+    const x265o_plane &f = planes[j->fenc_plane];
+    const x265o_plane &p = planes[j->ref_plane];
+    ReferencePlanes ref;
+    ref.fpelPlane = (pixel *)p.origin;
+    ref.lumaStride = (int)p.stride;
+    ref.isLowres = false;
+    ref.isWeighted = false;
+    me.setSourcePlane((pixel *)f.origin, f.stride);
+    me.setSearchMethod(j->method);
+    me.setSubpelRefine(j->subme);
+    me.setQP(j->qp);
+    me.setSourcePU(j->pu_x + j->pu_y * (int)f.stride, j->pu_w, j->pu_h);
+    /* blockOffset is shared between fenc and ref planes in the reference (motion.cpp:537);
+     * both planes therefore must have the same stride */
+    MV mvmin(j->mvmin_x, j->mvmin_y), mvmax(j->mvmax_x, j->mvmax_y), mvp(j->qmvp_x, j->qmvp_y), outmv;
+    MV mvc[X265O_MAX_MVC];
+    for (int i = 0; i < j->num_mvc; i++)
+        mvc[i] = MV(j->mvc[2 * i], j->mvc[2 * i + 1]);
+    r->cost = me.motionEstimate(&ref, mvmin, mvmax, mvp, j->num_mvc, mvc, j->merange, outmv);
+    r->mvx = outmv.x;
+    r->mvy = outmv.y;
+}
+
+struct MeSlice
+{
+    const x265o_plane *planes;
+    const x265o_me_job *jobs;
+    x265o_me_result *out;
+    int lo, hi;
+};
+
+static void *me_slice(void *p)
+{
+    MeSlice *s = (MeSlice *)p;
+    MotionEstimate me; /* one per worker, as cturow.h:59 does */
+    for (int i = s->lo; i < s->hi; i++)
+        run_me(me, s->planes, &s->jobs[i], &s->out[i]);
+    return 0;
+}
+
+/* costtabs is ignored: the reference builds its own tables from job->qp */
+void x265r_me_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_me_job *jobs, int n,
+                    x265o_me_result *out, int nthreads)
+{
+    (void)costtabs;
+    init();
+    {
+        /* build every needed cost table up front, single-threaded */
+        CostPeek p;
+        for (int i = 0; i < n; i++)
+            p.centre(jobs[i].qp);
+    }
+    if (nthreads <= 1 || n < 2 * nthreads)
+    {
+        MeSlice s = { planes, jobs, out, 0, n };
+        me_slice(&s);
+        return;
+    }
+    pthread_t *th = new pthread_t[nthreads];
+    MeSlice *sl = new MeSlice[nthreads];
+    for (int t = 0; t < nthreads; t++)
+    {
+        MeSlice s = { planes, jobs, out, (int)((int64_t)n * t / nthreads), (int)((int64_t)n * (t + 1) / nthreads) };
+        sl[t] = s;
+        pthread_create(&th[t], 0, me_slice, &sl[t]);
+    }
+    for (int t = 0; t < nthreads; t++)
+        pthread_join(th[t], 0);
+    delete[] sl;
+    delete[] th;
+}
+
+int x265r_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, int y, int w, int h, int qmvx,
+                      int qmvy, int metric)
+{
+    init();
+    MotionEstimate me;
+    ReferencePlanes rp;
+    rp.fpelPlane = (pixel *)ref->origin;
+    rp.lumaStride = (int)ref->stride;
+    me.setSourcePlane((pixel *)fenc->origin, fenc->stride);
+    me.setSourcePU(x + y * (int)fenc->stride, w, h);
+    int part = partitionFromSizes(w, h);
+    return me.subpelCompare(&rp, MV(qmvx, qmvy), metric ? primitives.satd[part] : primitives.sad[part]);
+}
+
+void x265r_cost_batch(const x265o_plane *planes, const x265o_cost_req *reqs, int n, int32_t *out, int nthreads)
+{
+    (void)nthreads;
+    for (int i = 0; i < n; i++)
+    {
+        const x265o_cost_req *r = &reqs[i];
+        out[i] = x265r_subpel_cost(&planes[r->fenc_plane], &planes[r->ref_plane], r->pu_x, r->pu_y, r->pu_w, r->pu_h,
+                                   r->qmv_x, r->qmv_y, r->metric);
+    }
+}
+
+/* config-2 building block via the reference: motionEstimate's FULL raster is not separable from
+ * its pre-tests, so this drives the reference sad primitive in the same raster order instead. */
+void x265r_ctu_fullsearch(const x265o_plane *fenc, const x265o_plane *ref, const uint16_t *costtab, int ctu_x,
+                          int ctu_y, int mvmin_x, int mvmin_y, int mvmax_x, int mvmax_y, int qmvp_x, int qmvp_y,
+                          x265o_me_result *out)
+{
+    init();
+    int idx = 0;
+    for (int lvl = 0; lvl < 4; lvl++)
+    {
+        int size = 64 >> lvl, n = 1 << lvl;
+        int part = partitionFromSizes(size, size);
+        for (int by = 0; by < n; by++)
+            for (int bx = 0; bx < n; bx++, idx++)
+            {
+                pixel *f = (pixel *)fenc->origin + (ctu_x + bx * size) + (intptr_t)(ctu_y + by * size) * fenc->stride;
+                pixel *r = (pixel *)ref->origin + (ctu_x + bx * size) + (intptr_t)(ctu_y + by * size) * ref->stride;
+                int best = 0x7fffffff, bmx = 0, bmy = 0;
+                for (int my = mvmin_y; my <= mvmax_y; my++)
+                    for (int mx = mvmin_x; mx <= mvmax_x; mx++)
+                    {
+                        MV q = MV(mx, my) << 2;
+                        uint16_t mvc = (uint16_t)(costtab[(uint16_t)(q.x - qmvp_x + 32768)] +
+                                                  costtab[(uint16_t)(q.y - qmvp_y + 32768)]);
+                        int cost = g_c.sad[part](f, fenc->stride, r + mx + my * ref->stride, ref->stride) + mvc;
+                        if (cost < best)
+                        {
+                            best = cost;
+                            bmx = mx;
+                            bmy = my;
+                        }
+                    }
+                out[idx].cost = best;
+                out[idx].mvx = (int16_t)(bmx << 2);
+                out[idx].mvy = (int16_t)(bmy << 2);
+            }
+    }
+}
+}

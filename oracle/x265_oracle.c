@@ -1,0 +1,1077 @@
+/* x265_oracle.c -- TEST INFRASTRUCTURE ONLY (see x265_oracle.h).
+ *
+ * CPU restatement of the x265 ME cost path.  Written from the algorithm, not
+ * from the reference text: straightforward integer loops, no SWAR, no
+ * templates.  "ref:" comments cite /root/reference/source/<file>:<lines>.
+ */
+#include "x265_oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* partitions                                         ref: common/primitives.h:38-46,103-112;
+ *                                                         common/primitives.cpp:32-51        */
+
+static const uint8_t k_part_w[X265O_NUM_PARTS] = { 4, 8, 8, 4, 16, 16, 8, 16, 12, 16, 4, 32, 32, 16, 32,
+                                                    24, 32, 8, 64, 64, 32, 64, 48, 64, 16 };
+static const uint8_t k_part_h[X265O_NUM_PARTS] = { 4, 8, 4, 8, 16, 8, 16, 12, 16, 4, 16, 32, 16, 32, 24,
+                                                    32, 8, 32, 64, 32, 64, 48, 64, 16, 64 };
+
+int x265o_partition_from_sizes(int w, int h)
+{
+    for (int p = 0; p < X265O_NUM_PARTS; p++)
+        if (k_part_w[p] == w && k_part_h[p] == h)
+            return p;
+    return -1;
+}
+
+void x265o_partition_size(int part, int *w, int *h)
+{
+    *w = k_part_w[part];
+    *h = k_part_h[part];
+}
+
+/* ------------------------------------------------------------------------- */
+/* SAD                                                 ref: common/pixel.cpp:92-156 */
+
+static int sad_wh(int w, int h, const uint8_t *a, intptr_t as, const uint8_t *b, intptr_t bs)
+{
+    int acc = 0;
+    for (int y = 0; y < h; y++, a += as, b += bs)
+        for (int x = 0; x < w; x++)
+        {
+            int d = (int)a[x] - (int)b[x];
+            acc += d < 0 ? -d : d;
+        }
+    return acc;
+}
+
+int x265o_sad(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *fref, intptr_t rstride)
+{
+    return sad_wh(k_part_w[part], k_part_h[part], fenc, fstride, fref, rstride);
+}
+
+/* fenc stride is the fixed FENC_STRIDE = 64 (ref: common/common.h:45, pixel.cpp:126,150) */
+void x265o_sad_x3(int part, const uint8_t *fenc, const uint8_t *r0, const uint8_t *r1, const uint8_t *r2,
+                  intptr_t rstride, int32_t *res)
+{
+    int w = k_part_w[part], h = k_part_h[part];
+    res[0] = sad_wh(w, h, fenc, 64, r0, rstride);
+    res[1] = sad_wh(w, h, fenc, 64, r1, rstride);
+    res[2] = sad_wh(w, h, fenc, 64, r2, rstride);
+}
+
+void x265o_sad_x4(int part, const uint8_t *fenc, const uint8_t *r0, const uint8_t *r1, const uint8_t *r2,
+                  const uint8_t *r3, intptr_t rstride, int32_t *res)
+{
+    int w = k_part_w[part], h = k_part_h[part];
+    res[0] = sad_wh(w, h, fenc, 64, r0, rstride);
+    res[1] = sad_wh(w, h, fenc, 64, r1, rstride);
+    res[2] = sad_wh(w, h, fenc, 64, r2, rstride);
+    res[3] = sad_wh(w, h, fenc, 64, r3, rstride);
+}
+
+/* ------------------------------------------------------------------------- */
+/* SATD                                                ref: common/pixel.cpp:181-288, 922-946
+ *
+ * The reference computes 4x4 (satd_4x4) or paired 8x4 (satd_8x4) Hadamard sums with
+ * two 16-bit lanes packed in a uint32 and halves the sum of absolute coefficients once per
+ * 4x4 / 8x4 call.  All 16 coefficients of a 4x4 Hadamard share the parity of the block's
+ * difference sum, so every per-4x4 sum is even and the halving distributes: the result is
+ * sum over 4x4 tiles of (sum|coef| / 2), whatever the grouping.  That is what is coded here. */
+
+static int satd_4x4_tile(const uint8_t *a, intptr_t as, const uint8_t *b, intptr_t bs)
+{
+    int m[4][4];
+    for (int y = 0; y < 4; y++)
+    {
+        int d0 = (int)a[y * as + 0] - (int)b[y * bs + 0];
+        int d1 = (int)a[y * as + 1] - (int)b[y * bs + 1];
+        int d2 = (int)a[y * as + 2] - (int)b[y * bs + 2];
+        int d3 = (int)a[y * as + 3] - (int)b[y * bs + 3];
+        int s01 = d0 + d1, t01 = d0 - d1, s23 = d2 + d3, t23 = d2 - d3;
+        m[y][0] = s01 + s23;
+        m[y][1] = t01 + t23;
+        m[y][2] = s01 - s23;
+        m[y][3] = t01 - t23;
+    }
+    int acc = 0;
+    for (int x = 0; x < 4; x++)
+    {
+        int s01 = m[0][x] + m[1][x], t01 = m[0][x] - m[1][x];
+        int s23 = m[2][x] + m[3][x], t23 = m[2][x] - m[3][x];
+        acc += abs(s01 + s23) + abs(s01 - s23) + abs(t01 + t23) + abs(t01 - t23);
+    }
+    return acc >> 1;
+}
+
+int x265o_satd(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *fref, intptr_t rstride)
+{
+    int w = k_part_w[part], h = k_part_h[part], acc = 0;
+    for (int y = 0; y < h; y += 4)
+        for (int x = 0; x < w; x += 4)
+            acc += satd_4x4_tile(fenc + y * fstride + x, fstride, fref + y * rstride + x, rstride);
+    return acc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* 8-tap luma interpolation         ref: common/ipfilter.cpp:76-160,162-201,241-282,399-406;
+ *                                       Lib/TLibCommon/TComRom.cpp:335-341; TComRom.h:117-121 */
+
+static const int16_t k_luma_taps[4][8] = {
+    { 0, 0, 0, 64, 0, 0, 0, 0 },
+    { -1, 4, -10, 58, 17, -5, 1, 0 },
+    { -1, 4, -11, 40, 40, -11, 4, -1 },
+    { 0, 1, -5, 17, 58, -10, 4, -1 },
+};
+
+static inline uint8_t clip_u8_from_i16(int v)
+{
+    /* the reference narrows to int16_t before clamping (ipfilter.cpp:105-109) */
+    int16_t s = (int16_t)v;
+    return (uint8_t)(s < 0 ? 0 : (s > 255 ? 255 : s));
+}
+
+void x265o_luma_hpp(int part, const uint8_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int coeffIdx)
+{
+    const int16_t *c = k_luma_taps[coeffIdx];
+    int w = k_part_w[part], h = k_part_h[part];
+    for (int y = 0; y < h; y++, src += sstride, dst += dstride)
+        for (int x = 0; x < w; x++)
+        {
+            int s = 0;
+            for (int k = 0; k < 8; k++)
+                s += src[x - 3 + k] * c[k];
+            dst[x] = clip_u8_from_i16((s + 32) >> 6);
+        }
+}
+
+void x265o_luma_vpp(int part, const uint8_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int coeffIdx)
+{
+    const int16_t *c = k_luma_taps[coeffIdx];
+    int w = k_part_w[part], h = k_part_h[part];
+    for (int y = 0; y < h; y++, src += sstride, dst += dstride)
+        for (int x = 0; x < w; x++)
+        {
+            int s = 0;
+            for (int k = 0; k < 8; k++)
+                s += src[x + (k - 3) * sstride] * c[k];
+            dst[x] = clip_u8_from_i16((s + 32) >> 6);
+        }
+}
+
+/* 8-bit build: headRoom = 14-8 = 6, shift = 6-6 = 0, offset = -8192 (ipfilter.cpp:121-123) */
+void x265o_luma_hps(int part, const uint8_t *src, intptr_t sstride, int16_t *dst, intptr_t dstride, int coeffIdx,
+                    int isRowExt)
+{
+    const int16_t *c = k_luma_taps[coeffIdx];
+    int w = k_part_w[part], h = k_part_h[part];
+    if (isRowExt)
+    {
+        src -= 3 * sstride;
+        h += 7;
+    }
+    for (int y = 0; y < h; y++, src += sstride, dst += dstride)
+        for (int x = 0; x < w; x++)
+        {
+            int s = 0;
+            for (int k = 0; k < 8; k++)
+                s += src[x - 3 + k] * c[k];
+            dst[x] = (int16_t)(s - 8192);
+        }
+}
+
+/* 8-bit build: shift = 6+6 = 12, offset = (1<<11) + (8192<<6) (ipfilter.cpp:244-247) */
+void x265o_luma_vsp(int part, const int16_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int coeffIdx)
+{
+    const int16_t *c = k_luma_taps[coeffIdx];
+    int w = k_part_w[part], h = k_part_h[part];
+    for (int y = 0; y < h; y++, src += sstride, dst += dstride)
+        for (int x = 0; x < w; x++)
+        {
+            int s = 0;
+            for (int k = 0; k < 8; k++)
+                s += src[x + (k - 3) * sstride] * c[k];
+            dst[x] = clip_u8_from_i16((s + 2048 + (8192 << 6)) >> 12);
+        }
+}
+
+/* ref: common/pixel.cpp:726-739 (blockcopy_pp_c<bx,by>) */
+void x265o_luma_copy_pp(int part, uint8_t *dst, intptr_t dstride, const uint8_t *src, intptr_t sstride)
+{
+    int w = k_part_w[part], h = k_part_h[part];
+    for (int y = 0; y < h; y++)
+        memcpy(dst + y * dstride, src + y * sstride, (size_t)w);
+}
+
+/* ------------------------------------------------------------------------- */
+/* MV bit-cost table           ref: encoder/bitcost.cpp:31-80; Lib/TLibCommon/TComRom.cpp:127-143 */
+
+static const double k_lambda[70] = {
+    0.2500, 0.2806, 0.3150, 0.3536, 0.3969, 0.4454, 0.5000, 0.5612, 0.6300, 0.7071,
+    0.7937, 0.8909, 1.0000, 1.1225, 1.2599, 1.4142, 1.5874, 1.7818, 2.0000, 2.2449,
+    2.5198, 2.8284, 3.1748, 3.5636, 4.0000, 4.4898, 5.0397, 5.6569, 6.3496, 7.1272,
+    8.0000, 8.9797, 10.0794, 11.3137, 12.6992, 14.2544, 16.0000, 17.9594, 20.1587, 22.6274,
+    25.3984, 28.5088, 32.0000, 35.9188, 40.3175, 45.2548, 50.7968, 57.0175, 64.0000, 71.8376,
+    80.6349, 90.5097, 101.5937, 114.0350, 128.0000, 143.6751, 161.2699, 181.0193, 203.1873, 228.0701,
+    256.0000, 287.3503, 322.5398, 362.0387, 406.3747, 456.1401, 512.0000, 574.7006, 645.0796, 724.0773
+};
+
+void x265o_bitcost_table(int qp, uint16_t *out)
+{
+    /* bits[0] = 0.718, bits[i] = log(i+1) * (2/ln 2) + 1.718, stored as float; the reference's
+     * unqualified log() calls resolve to the double overload, so the logarithm and the
+     * multiply-add are evaluated in double and only the stored results are single precision.
+     * cost[+-i] = (uint16) min(bits[i] * lambda + 0.5, 65535) with lambda in double. */
+    const float two_over_ln2 = (float)(2.0f / log((double)2.0f));
+    const double lambda = k_lambda[qp];
+    for (int i = 0; i < 32768; i++)
+    {
+        float bits = i ? (float)(log((double)(float)(i + 1)) * two_over_ln2 + 1.718f) : 0.718f;
+        double v = bits * lambda + 0.5f;
+        uint16_t c = (uint16_t)(v < 65535.0 ? v : 65535.0);
+        out[32768 + i] = c;
+        out[32768 - i] = c;
+    }
+    /* entry -32768 is never written by the reference loop (i < BC_MAX_MV); index 0 of our
+     * array corresponds to it.  Give it the value of its neighbour so the array is defined. */
+    out[0] = out[1];
+}
+
+/* ------------------------------------------------------------------------- */
+/* search context                                                            */
+
+typedef struct
+{
+    uint8_t fenc[64 * 64]; /* PU copied at stride 64   ref: encoder/motion.cpp:110-126 */
+    int w, h, part;
+    const uint8_t *fref;   /* ref plane at the PU origin   ref: motion.cpp:537 */
+    intptr_t stride;
+    const uint16_t *tab;   /* 65536 entries, centre at +32768 */
+    int mvpx, mvpy;        /* setMVP bias                  ref: encoder/bitcost.h:42 */
+} me_ctx;
+
+/* mvcost() sums two uint16 entries and truncates to uint16 (bitcost.h:45).  Indices are
+ * wrapped to the table so that the reference's out-of-table reads (undefined there) are at
+ * least defined here; in-range inputs never wrap. */
+static inline int tab_at(const uint16_t *tab, int mvp, int v)
+{
+    return tab[(uint16_t)(v - mvp + 32768)];
+}
+
+static inline int mvcost_q(const me_ctx *c, int qx, int qy)
+{
+    return (uint16_t)(tab_at(c->tab, c->mvpx, qx) + tab_at(c->tab, c->mvpy, qy));
+}
+
+static inline int16_t s16(int v) { return (int16_t)v; }
+
+/* cost of a full-pel position given in full-pel units: SAD + mvcost(mv << 2)
+ * (ref: COST_MV, motion.cpp:179-185).  MV << 2 is an int16 operation (mv.h:63). */
+static inline int sad_at(const me_ctx *c, int mx, int my)
+{
+    return sad_wh(c->w, c->h, c->fenc, 64, c->fref + mx + my * c->stride, c->stride);
+}
+
+static inline int cost_fpel(const me_ctx *c, int mx, int my)
+{
+    return sad_at(c, mx, my) + mvcost_q(c, s16(mx << 2), s16(my << 2));
+}
+
+/* ref: MotionEstimate::subpelCompare, motion.cpp:1126-1164 */
+static int subpel_cost(const me_ctx *c, int qx, int qy, int use_satd)
+{
+    int xf = qx & 3, yf = qy & 3;
+    const uint8_t *p = c->fref + (qx >> 2) + (qy >> 2) * c->stride;
+    uint8_t buf[64 * 64];
+    const uint8_t *cmp = buf;
+    intptr_t cmpstride = 64;
+    if (!(xf | yf))
+    {
+        cmp = p;
+        cmpstride = c->stride;
+    }
+    else if (!yf)
+        x265o_luma_hpp(c->part, p, c->stride, buf, 64, xf);
+    else if (!xf)
+        x265o_luma_vpp(c->part, p, c->stride, buf, 64, yf);
+    else
+    {
+        int16_t immed[64 * (64 + 8)];
+        x265o_luma_hps(c->part, p, c->stride, immed, c->w, xf, 1);
+        x265o_luma_vsp(c->part, immed + 3 * c->w, c->w, buf, 64, yf);
+    }
+    return use_satd ? x265o_satd(c->part, c->fenc, 64, cmp, cmpstride)
+                    : sad_wh(c->w, c->h, c->fenc, 64, cmp, cmpstride);
+}
+
+typedef struct
+{
+    int16_t x, y;
+} mv_t;
+
+static inline int in_range(int x, int y, mv_t lo, mv_t hi)
+{
+    return x >= lo.x && x <= hi.x && y >= lo.y && y <= hi.y;
+}
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+/* tables                                                ref: motion.cpp:129-149 */
+static const int8_t k_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
+static const uint8_t k_mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+static const int8_t k_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+static const int8_t k_hex4[16][2] = { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 },
+                                      { -4, 0 }, { 4, 0 }, { -4, 1 }, { 4, 1 }, { -4, 2 }, { 4, 2 }, { -2, 3 }, { 2, 3 } };
+static const int8_t k_twopoint[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
+                                          { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
+/* ref: motion.cpp:47-57 */
+static const struct { int hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd; } k_workload[8] = {
+    { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
+    { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 },
+};
+
+/* search state shared by the pattern helpers */
+typedef struct
+{
+    const me_ctx *c;
+    mv_t lo, hi;   /* full-pel range */
+    int bcost;
+    mv_t bmv;      /* full-pel during the integer stage */
+    int point, dist; /* STAR bookkeeping */
+} srch;
+
+/* one scalar candidate, strict less (COPY2_IF_LT, common.h:123-128) */
+static inline void try_mv(srch *s, int mx, int my)
+{
+    int cost = cost_fpel(s->c, mx, my);
+    if (cost < s->bcost)
+    {
+        s->bcost = cost;
+        s->bmv.x = s16(mx);
+        s->bmv.y = s16(my);
+    }
+}
+
+static inline void try_mv_pd(srch *s, int mx, int my, int point, int dist)
+{
+    int cost = cost_fpel(s->c, mx, my);
+    if (cost < s->bcost)
+    {
+        s->bcost = cost;
+        s->bmv.x = s16(mx);
+        s->bmv.y = s16(my);
+        s->point = point;
+        s->dist = dist;
+    }
+}
+
+/* four candidates around origin o, in the listed order (COST_MV_X4, motion.cpp:218-235) */
+static void try_x4(srch *s, mv_t o, const int d[4][2])
+{
+    for (int k = 0; k < 4; k++)
+        try_mv(s, s16(o.x + d[k][0]), s16(o.y + d[k][1]));
+}
+
+/* ref: StarPatternSearch, motion.cpp:284-524.  Coordinates are int16 in the reference.
+ * The reference has a sad_x4 fast path when the whole ring is inside [lo,hi] and a guarded scalar
+ * path otherwise; both visit the same points in the same order, so only the guarded form is
+ * written here (inside-ness of the outer points implies it for the inner ones). */
+static void star_pattern(srch *s, int early_exit_iters, int merange)
+{
+    const mv_t o = s->bmv;
+    const mv_t lo = s->lo, hi = s->hi;
+    int saved = s->bcost;
+    int rounds = 0;
+
+    for (int dist = 1; dist <= 8; dist <<= 1)
+    {
+        const int half = dist >> 1;
+        const int16_t top = s16(o.y - dist), bottom = s16(o.y + dist), left = s16(o.x - dist), right = s16(o.x + dist);
+        const int16_t top2 = s16(o.y - half), bottom2 = s16(o.y + half), left2 = s16(o.x - half), right2 = s16(o.x + half);
+        saved = s->bcost;
+        /* visiting order 2,1,3,4,5,6,8,7; points 1,3,6,8 exist only for dist >= 2 (:317-419) */
+        if (top >= lo.y)
+            try_mv_pd(s, o.x, top, 2, dist);
+        if (dist > 1 && top2 >= lo.y)
+        {
+            if (left2 >= lo.x)
+                try_mv_pd(s, left2, top2, 1, half);
+            if (right2 <= hi.x)
+                try_mv_pd(s, right2, top2, 3, half);
+        }
+        if (left >= lo.x)
+            try_mv_pd(s, left, o.y, 4, dist);
+        if (right <= hi.x)
+            try_mv_pd(s, right, o.y, 5, dist);
+        if (dist > 1 && bottom2 <= hi.y)
+        {
+            if (left2 >= lo.x)
+                try_mv_pd(s, left2, bottom2, 6, half);
+            if (right2 <= hi.x)
+                try_mv_pd(s, right2, bottom2, 8, half);
+        }
+        if (bottom <= hi.y)
+            try_mv_pd(s, o.x, bottom, 7, dist);
+        if (s->bcost < saved)
+            rounds = 0;
+        else if (++rounds >= early_exit_iters)
+            return;
+    }
+
+    for (int dist = 16; dist <= (int16_t)merange; dist <<= 1)
+    {
+        const int q = dist >> 2;
+        const int16_t top = s16(o.y - dist), bottom = s16(o.y + dist), left = s16(o.x - dist), right = s16(o.x + dist);
+        saved = s->bcost;
+        if (top >= lo.y)
+            try_mv_pd(s, o.x, top, 0, dist);
+        if (left >= lo.x)
+            try_mv_pd(s, left, o.y, 0, dist);
+        if (right <= hi.x)
+            try_mv_pd(s, right, o.y, 0, dist);
+        if (bottom <= hi.y)
+            try_mv_pd(s, o.x, bottom, 0, dist);
+        for (int idx = 1; idx < 4; idx++)
+        {
+            const int16_t yt = s16(top + q * idx), yb = s16(bottom - q * idx);
+            const int16_t xl = s16(o.x - q * idx), xr = s16(o.x + q * idx);
+            if (yt >= lo.y)
+            {
+                if (xl >= lo.x)
+                    try_mv_pd(s, xl, yt, 0, dist);
+                if (xr <= hi.x)
+                    try_mv_pd(s, xr, yt, 0, dist);
+            }
+            if (yb <= hi.y)
+            {
+                if (xl >= lo.x)
+                    try_mv_pd(s, xl, yb, 0, dist);
+                if (xr <= hi.x)
+                    try_mv_pd(s, xr, yb, 0, dist);
+            }
+        }
+        if (s->bcost < saved)
+            rounds = 0;
+        else if (++rounds >= early_exit_iters)
+            return;
+    }
+}
+
+/* UMH cross (CROSS macro, motion.cpp:258-282) around origin o */
+static void umh_cross(srch *s, mv_t o, int start, int x_max, int y_max)
+{
+    const mv_t lo = s->lo, hi = s->hi;
+    int16_t i = s16(start);
+    if (x_max <= imin(hi.x - o.x, o.x - lo.x))
+        for (; i < x_max - 2; i = s16(i + 4))
+        {
+            const int d[4][2] = { { i, 0 }, { -i, 0 }, { i + 2, 0 }, { -i - 2, 0 } };
+            try_x4(s, o, d);
+        }
+    for (; i < x_max; i = s16(i + 2))
+    {
+        if (o.x + i <= hi.x)
+            try_mv(s, o.x + i, o.y);
+        if (o.x - i >= lo.x)
+            try_mv(s, o.x - i, o.y);
+    }
+    i = s16(start);
+    if (y_max <= imin(hi.y - o.y, o.y - lo.y))
+        for (; i < y_max - 2; i = s16(i + 4))
+        {
+            const int d[4][2] = { { 0, i }, { 0, -i }, { 0, i + 2 }, { 0, -i - 2 } };
+            try_x4(s, o, d);
+        }
+    for (; i < y_max; i = s16(i + 2))
+    {
+        if (o.y + i <= hi.y)
+            try_mv(s, o.x, o.y + i);
+        if (o.y - i >= lo.y)
+            try_mv(s, o.x, o.y - i);
+    }
+}
+
+/* ref: MotionEstimate::motionEstimate, motion.cpp:526-1124 (non-lowres branch) */
+static int motion_estimate(const x265o_plane *fencpl, const x265o_plane *refpl, const uint16_t *costtab,
+                           const x265o_me_job *j, mv_t *out)
+{
+    me_ctx c;
+    c.w = j->pu_w;
+    c.h = j->pu_h;
+    c.part = x265o_partition_from_sizes(c.w, c.h);
+    c.stride = refpl->stride;
+    c.fref = refpl->origin + j->pu_x + (intptr_t)j->pu_y * refpl->stride;
+    c.tab = costtab;
+    c.mvpx = j->qmvp_x; /* setMVP, bitcost.h:42 */
+    c.mvpy = j->qmvp_y;
+    /* setSourcePU: copy the PU into the 64-stride cache (motion.cpp:125) */
+    x265o_luma_copy_pp(c.part, c.fenc, 64, fencpl->origin + j->pu_x + (intptr_t)j->pu_y * fencpl->stride,
+                       fencpl->stride);
+
+    const mv_t lo = { j->mvmin_x, j->mvmin_y }, hi = { j->mvmax_x, j->mvmax_y };
+    const int qlox = s16(lo.x << 2), qloy = s16(lo.y << 2), qhix = s16(hi.x << 2), qhiy = s16(hi.y << 2);
+    int merange = j->merange;
+
+    /* clipped quarter-pel predictor, measured with SAD and no mvcost (motion.cpp:552-559).
+     * MV::clipped = min with max first, then max with min (mv.h:89-94). */
+    mv_t pmv;
+    pmv.x = s16(j->qmvp_x > qhix ? qhix : j->qmvp_x);
+    pmv.x = s16(pmv.x < qlox ? qlox : pmv.x);
+    pmv.y = s16(j->qmvp_y > qhiy ? qhiy : j->qmvp_y);
+    pmv.y = s16(pmv.y < qloy ? qloy : pmv.y);
+    mv_t bestpre = pmv;
+    int bprecost = subpel_cost(&c, pmv.x, pmv.y, 0);
+
+    srch s;
+    s.c = &c;
+    s.lo = lo;
+    s.hi = hi;
+    s.point = 0;
+    s.dist = 0;
+    /* full-pel start = (pmv + 2) >> 2, re-measured with mvcost if pmv was fractional (:562-567) */
+    s.bmv.x = s16(s16(pmv.x + 2) >> 2);
+    s.bmv.y = s16(s16(pmv.y + 2) >> 2);
+    s.bcost = bprecost;
+    if ((pmv.x | pmv.y) & 3)
+        s.bcost = cost_fpel(&c, s.bmv.x, s.bmv.y);
+
+    /* zero MV (:570-578) */
+    if (pmv.x | pmv.y)
+    {
+        int cost = sad_at(&c, 0, 0) + mvcost_q(&c, 0, 0);
+        if (cost < s.bcost)
+        {
+            s.bcost = cost;
+            s.bmv.x = s.bmv.y = 0;
+        }
+    }
+
+    /* candidate predictors at quarter-pel, SAD + mvcost, compete with bprecost only (:581-598) */
+    for (int i = 0; i < j->num_mvc; i++)
+    {
+        int mx = j->mvc[2 * i], my = j->mvc[2 * i + 1];
+        mx = mx > qhix ? qhix : mx;
+        mx = mx < qlox ? qlox : mx;
+        my = my > qhiy ? qhiy : my;
+        my = my < qloy ? qloy : my;
+        if ((mx | my) && !(mx == pmv.x && my == pmv.y) && !(mx == bestpre.x && my == bestpre.y))
+        {
+            int cost = subpel_cost(&c, mx, my, 0) + mvcost_q(&c, mx, my);
+            if (cost < bprecost)
+            {
+                bprecost = cost;
+                bestpre.x = s16(mx);
+                bestpre.y = s16(my);
+            }
+        }
+    }
+
+    pmv.x = s16(s16(pmv.x + 2) >> 2);
+    pmv.y = s16(s16(pmv.y + 2) >> 2);
+    mv_t omv = s.bmv;
+
+    switch (j->method)
+    {
+    case 0: /* DIA, motion.cpp:605-626: packed (cost<<4)+code, centre wins ties, lowest code next */
+    {
+        int i = merange;
+        do
+        {
+            int best = s.bcost << 4;
+            static const int dx[4] = { 0, 0, -1, 1 }, dy[4] = { -1, 1, 0, 0 }, code[4] = { 1, 3, 4, 12 };
+            int k, sel = -1;
+            for (k = 0; k < 4; k++)
+            {
+                int v = (cost_fpel(&c, s16(s.bmv.x + dx[k]), s16(s.bmv.y + dy[k])) << 4) + code[k];
+                if (v < best)
+                {
+                    best = v;
+                    sel = k;
+                }
+            }
+            if (sel < 0)
+                break;
+            s.bmv.x = s16(s.bmv.x + dx[sel]);
+            s.bmv.y = s16(s.bmv.y + dy[sel]);
+            s.bcost = best >> 4;
+        }
+        while (--i && in_range(s.bmv.x, s.bmv.y, lo, hi));
+        break;
+    }
+
+    case 2: /* UMH, motion.cpp:702-885; falls into the hexagon stage when bmv is in range */
+    {
+        int ucost1, ucost2;
+        int cross_start = 1;
+        int leave = 0;
+        static const int dia[4][2] = { { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 } };
+        const int sscale = (c.h * c.h) >> 4; /* size_scale, motion.cpp:60-66 */
+#define THRESH(v) (s.bcost < (((v) >> 4) * sscale))
+
+        omv = s.bmv;
+        ucost1 = s.bcost;
+        try_x4(&s, pmv, dia);
+        if (pmv.x | pmv.y)
+        {
+            mv_t z = { 0, 0 };
+            try_x4(&s, z, dia);
+        }
+        ucost2 = s.bcost;
+        if ((s.bmv.x | s.bmv.y) && !(s.bmv.x == pmv.x && s.bmv.y == pmv.y))
+            try_x4(&s, s.bmv, dia);
+        if (s.bcost == ucost2)
+            cross_start = 3;
+
+        omv = s.bmv;
+        if (s.bcost == ucost2 && THRESH(2000))
+        {
+            static const int o1[4][2] = { { 0, -2 }, { -1, -1 }, { 1, -1 }, { -2, 0 } };
+            static const int o2[4][2] = { { 2, 0 }, { -1, 1 }, { 1, 1 }, { 0, 2 } };
+            try_x4(&s, omv, o1);
+            try_x4(&s, omv, o2);
+            if (s.bcost == ucost1 && THRESH(500))
+                leave = 1;
+            else if (s.bcost == ucost2)
+            {
+                int16_t range = s16((merange >> 1) | 1);
+                static const int o3[4][2] = { { -1, -2 }, { 1, -2 }, { -2, -1 }, { 2, -1 } };
+                static const int o4[4][2] = { { -2, 1 }, { 2, 1 }, { -1, 2 }, { 1, 2 } };
+                umh_cross(&s, omv, 3, range, range);
+                try_x4(&s, omv, o3);
+                try_x4(&s, omv, o4);
+                if (s.bcost == ucost2)
+                    leave = 1;
+                else
+                    cross_start = range + 2;
+            }
+        }
+        if (leave)
+            break;
+
+        if (j->num_mvc)
+        {
+            static const uint8_t range_mul[4][4] = { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } };
+            int mvd, denom = 1;
+            const int is64 = (c.w == 64 && c.h == 64);
+            if (j->num_mvc == 1)
+                mvd = is64 ? 25 : abs(j->qmvp_x - j->mvc[0]) + abs(j->qmvp_y - j->mvc[1]);
+            else
+            {
+                denom = j->num_mvc - 1;
+                mvd = 0;
+                if (!is64)
+                {
+                    mvd = abs(j->qmvp_x - j->mvc[0]) + abs(j->qmvp_y - j->mvc[1]);
+                    denom++;
+                }
+                for (int i = 0; i < j->num_mvc - 1; i++)
+                    mvd += abs(j->mvc[2 * i] - j->mvc[2 * i + 2]) + abs(j->mvc[2 * i + 1] - j->mvc[2 * i + 3]);
+            }
+            int sad_ctx = THRESH(1000) ? 0 : THRESH(2000) ? 1 : THRESH(4000) ? 2 : 3;
+            int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
+            merange = (merange * range_mul[mvd_ctx][sad_ctx]) >> 2;
+        }
+#undef THRESH
+
+        {
+            static const int o5[4][2] = { { -2, -2 }, { -2, 2 }, { 2, -2 }, { 2, 2 } };
+            umh_cross(&s, omv, cross_start, merange, merange >> 1);
+            try_x4(&s, omv, o5);
+        }
+
+        /* hexagon grid, rings i = 1 .. merange/4 around the new centre (:802-881).  The in-range
+         * branch adds the two table entries as ints (no uint16 truncation of their sum). */
+        omv = s.bmv;
+        {
+            uint16_t i = 1;
+            do
+            {
+                int room = imin(imin(hi.x - omv.x, omv.x - lo.x), imin(hi.y - omv.y, omv.y - lo.y));
+                if (4 * i > room)
+                {
+                    for (int k = 0; k < 16; k++)
+                    {
+                        int16_t mx = s16(omv.x + s16(k_hex4[k][0] * (int16_t)i));
+                        int16_t my = s16(omv.y + s16(k_hex4[k][1] * (int16_t)i));
+                        if (in_range(mx, my, lo, hi))
+                            try_mv(&s, mx, my);
+                    }
+                }
+                else
+                {
+                    int dirx = 0, diry = 0, moved = 0;
+                    for (int k = 0; k < 16; k++)
+                    {
+                        int ox = k_hex4[k][0] * i, oy = k_hex4[k][1] * i;
+                        int cost = sad_at(&c, omv.x + ox, omv.y + oy)
+                                   + tab_at(c.tab, c.mvpx, omv.x * 4 + ox * 4) + tab_at(c.tab, c.mvpy, omv.y * 4 + oy * 4);
+                        if (cost < s.bcost)
+                        {
+                            s.bcost = cost;
+                            dirx = k_hex4[k][0];
+                            diry = k_hex4[k][1];
+                            moved = 1;
+                        }
+                    }
+                    if (moved)
+                    {
+                        s.bmv.x = s16(omv.x + i * dirx);
+                        s.bmv.y = s16(omv.y + i * diry);
+                    }
+                }
+            }
+            while (++i <= merange >> 2);
+        }
+        if (!in_range(s.bmv.x, s.bmv.y, lo, hi))
+            break;
+    }
+    /* fall through */
+    case 1: /* HEX, motion.cpp:628-700 */
+    {
+        /* first full hexagon: codes 2..7 in the order (-2,0)(-1,2)(1,2)(2,0)(1,-2)(-1,-2) */
+        static const int first[6][2] = { { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 } };
+        int best = s.bcost << 3;
+        for (int k = 0; k < 6; k++)
+        {
+            int v = (cost_fpel(&c, s16(s.bmv.x + first[k][0]), s16(s.bmv.y + first[k][1])) << 3) + (k + 2);
+            if (v < best)
+                best = v;
+        }
+        if (best & 7)
+        {
+            int dir = (best & 7) - 2;
+            s.bmv.x = s16(s.bmv.x + k_hex2[dir + 1][0]);
+            s.bmv.y = s16(s.bmv.y + k_hex2[dir + 1][1]);
+            for (int i = (merange >> 1) - 1; i > 0 && in_range(s.bmv.x, s.bmv.y, lo, hi); i--)
+            {
+                best &= ~7;
+                for (int k = 0; k < 3; k++)
+                {
+                    int v = (cost_fpel(&c, s16(s.bmv.x + k_hex2[dir + k][0]), s16(s.bmv.y + k_hex2[dir + k][1])) << 3) + (k + 1);
+                    if (v < best)
+                        best = v;
+                }
+                if (!(best & 7))
+                    break;
+                dir += (best & 7) - 2;
+                dir = k_mod6m1[dir + 1];
+                s.bmv.x = s16(s.bmv.x + k_hex2[dir + 1][0]);
+                s.bmv.y = s16(s.bmv.y + k_hex2[dir + 1][1]);
+            }
+        }
+        s.bcost = best >> 3;
+
+        /* square refine, 8 neighbours, fixed centre, lowest index wins ties (:686-698) */
+        int dir = 0;
+        for (int k = 1; k <= 8; k++)
+        {
+            int cost = cost_fpel(&c, s16(s.bmv.x + k_square1[k][0]), s16(s.bmv.y + k_square1[k][1]));
+            if (cost < s.bcost)
+            {
+                s.bcost = cost;
+                dir = k;
+            }
+        }
+        s.bmv.x = s16(s.bmv.x + k_square1[dir][0]);
+        s.bmv.y = s16(s.bmv.y + k_square1[dir][1]);
+        break;
+    }
+
+    case 3: /* STAR, motion.cpp:887-995 */
+    {
+        s.point = 0;
+        s.dist = 0;
+        star_pattern(&s, 3, merange);
+        int done = 0;
+        if (s.dist == 1)
+        {
+            if (s.point)
+            {
+                int saved = s.bcost;
+                int x1 = s16(s.bmv.x + k_twopoint[(s.point - 1) * 2][0]), y1 = s16(s.bmv.y + k_twopoint[(s.point - 1) * 2][1]);
+                int x2 = s16(s.bmv.x + k_twopoint[(s.point - 1) * 2 + 1][0]), y2 = s16(s.bmv.y + k_twopoint[(s.point - 1) * 2 + 1][1]);
+                if (in_range(x1, y1, lo, hi))
+                    try_mv(&s, x1, y1);
+                if (in_range(x2, y2, lo, hi))
+                    try_mv(&s, x2, y2);
+                if (s.bcost == saved)
+                    done = 1;
+            }
+            else
+                done = 1;
+        }
+        if (done)
+            break;
+
+        if (s.dist > 5)
+        {
+            /* raster at step 5; groups of four when three more steps fit, and the 4th point of a
+             * group is charged mvcost(tmv << 3) -- a reference quirk kept on purpose (:951) */
+            for (int ty = lo.y; ty <= hi.y; ty += 5)
+            {
+                int16_t tx = lo.x;
+                for (; tx <= hi.x; tx = s16(tx + 5))
+                {
+                    if (tx + 15 <= hi.x)
+                    {
+                        for (int k = 0; k < 4; k++)
+                        {
+                            int16_t px = s16(tx + 5 * k);
+                            int sh = k == 3 ? 3 : 2;
+                            int cost = sad_at(&c, px, ty) + mvcost_q(&c, s16(px << sh), s16(ty << sh));
+                            if (cost < s.bcost)
+                            {
+                                s.bcost = cost;
+                                s.bmv.x = px;
+                                s.bmv.y = s16(ty);
+                            }
+                        }
+                        tx = s16(tx + 15);
+                    }
+                    else
+                        try_mv(&s, tx, ty);
+                }
+            }
+        }
+
+        while (s.dist > 0)
+        {
+            s.dist = 0;
+            s.point = 0;
+            star_pattern(&s, 32, merange);
+            if (s.dist == 1)
+            {
+                if (!s.point)
+                    break;
+                int x1 = s16(s.bmv.x + k_twopoint[(s.point - 1) * 2][0]), y1 = s16(s.bmv.y + k_twopoint[(s.point - 1) * 2][1]);
+                int x2 = s16(s.bmv.x + k_twopoint[(s.point - 1) * 2 + 1][0]), y2 = s16(s.bmv.y + k_twopoint[(s.point - 1) * 2 + 1][1]);
+                if (in_range(x1, y1, lo, hi))
+                    try_mv(&s, x1, y1);
+                if (in_range(x2, y2, lo, hi))
+                    try_mv(&s, x2, y2);
+                break;
+            }
+        }
+        break;
+    }
+
+    case 4: /* FULL, motion.cpp:997-1032: raster order, first minimum wins */
+        for (int ty = lo.y; ty <= hi.y; ty++)
+            for (int tx = lo.x; tx <= hi.x; tx++)
+                try_mv(&s, tx, ty);
+        break;
+
+    default:
+        break;
+    }
+
+    /* pre-test winner bypasses the integer result (:1039-1045) */
+    int bcost = s.bcost;
+    int bx, by;
+    if (bprecost < bcost)
+    {
+        bx = bestpre.x;
+        by = bestpre.y;
+        bcost = bprecost;
+    }
+    else
+    {
+        bx = s16(s.bmv.x << 2);
+        by = s16(s.bmv.y << 2);
+    }
+
+    if (!bcost)
+    {
+        bcost = mvcost_q(&c, bx, by); /* :1049-1054 */
+    }
+    else
+    {
+        const int hsatd = k_workload[j->subme].hpel_satd;
+        if (hsatd)
+            bcost = subpel_cost(&c, bx, by, 1) + mvcost_q(&c, bx, by);
+        for (int it = 0; it < k_workload[j->subme].hpel_iters; it++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= k_workload[j->subme].hpel_dirs; i++)
+            {
+                int qx = s16(bx + k_square1[i][0] * 2), qy = s16(by + k_square1[i][1] * 2);
+                int cost = subpel_cost(&c, qx, qy, hsatd) + mvcost_q(&c, qx, qy);
+                if (cost < bcost)
+                {
+                    bcost = cost;
+                    bdir = i;
+                }
+            }
+            bx = s16(bx + k_square1[bdir][0] * 2);
+            by = s16(by + k_square1[bdir][1] * 2);
+        }
+        if (!hsatd)
+            bcost = subpel_cost(&c, bx, by, 1) + mvcost_q(&c, bx, by);
+        for (int it = 0; it < k_workload[j->subme].qpel_iters; it++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= k_workload[j->subme].qpel_dirs; i++)
+            {
+                int qx = s16(bx + k_square1[i][0]), qy = s16(by + k_square1[i][1]);
+                int cost = subpel_cost(&c, qx, qy, 1) + mvcost_q(&c, qx, qy);
+                if (cost < bcost)
+                {
+                    bcost = cost;
+                    bdir = i;
+                }
+            }
+            bx = s16(bx + k_square1[bdir][0]);
+            by = s16(by + k_square1[bdir][1]);
+        }
+    }
+    out->x = s16(bx);
+    out->y = s16(by);
+    return bcost;
+}
+
+/* ------------------------------------------------------------------------- */
+/* public single-call helpers                                                */
+
+int x265o_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, int y, int w, int h, int qmvx,
+                      int qmvy, int metric)
+{
+    me_ctx c;
+    c.w = w;
+    c.h = h;
+    c.part = x265o_partition_from_sizes(w, h);
+    c.stride = ref->stride;
+    c.fref = ref->origin + x + (intptr_t)y * ref->stride;
+    c.tab = 0;
+    c.mvpx = c.mvpy = 0;
+    x265o_luma_copy_pp(c.part, c.fenc, 64, fenc->origin + x + (intptr_t)y * fenc->stride, fenc->stride);
+    return subpel_cost(&c, qmvx, qmvy, metric);
+}
+
+/* ------------------------------------------------------------------------- */
+/* batched drivers (pthread fan-out over contiguous slices)                  */
+
+typedef struct
+{
+    const x265o_plane *planes;
+    const uint16_t *const *tabs;
+    const x265o_me_job *jobs;
+    x265o_me_result *mres;
+    const x265o_cost_req *reqs;
+    int32_t *cres;
+    int lo, hi;
+} slice_arg;
+
+static void *me_slice(void *p)
+{
+    slice_arg *a = (slice_arg *)p;
+    for (int i = a->lo; i < a->hi; i++)
+    {
+        const x265o_me_job *j = &a->jobs[i];
+        mv_t mv;
+        a->mres[i].cost = motion_estimate(&a->planes[j->fenc_plane], &a->planes[j->ref_plane], a->tabs[j->qp], j, &mv);
+        a->mres[i].mvx = mv.x;
+        a->mres[i].mvy = mv.y;
+    }
+    return 0;
+}
+
+static void *cost_slice(void *p)
+{
+    slice_arg *a = (slice_arg *)p;
+    for (int i = a->lo; i < a->hi; i++)
+    {
+        const x265o_cost_req *r = &a->reqs[i];
+        a->cres[i] = x265o_subpel_cost(&a->planes[r->fenc_plane], &a->planes[r->ref_plane], r->pu_x, r->pu_y, r->pu_w,
+                                       r->pu_h, r->qmv_x, r->qmv_y, r->metric);
+    }
+    return 0;
+}
+
+static void fan_out(void *(*fn)(void *), slice_arg *proto, int n, int nthreads)
+{
+    if (nthreads <= 1 || n < 2 * nthreads)
+    {
+        proto->lo = 0;
+        proto->hi = n;
+        fn(proto);
+        return;
+    }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    slice_arg *args = (slice_arg *)malloc(sizeof(slice_arg) * nthreads);
+    for (int t = 0; t < nthreads; t++)
+    {
+        args[t] = *proto;
+        args[t].lo = (int)((int64_t)n * t / nthreads);
+        args[t].hi = (int)((int64_t)n * (t + 1) / nthreads);
+        pthread_create(&th[t], 0, fn, &args[t]);
+    }
+    for (int t = 0; t < nthreads; t++)
+        pthread_join(th[t], 0);
+    free(args);
+    free(th);
+}
+
+void x265o_me_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_me_job *jobs, int n,
+                    x265o_me_result *out, int nthreads)
+{
+    slice_arg a;
+    memset(&a, 0, sizeof(a));
+    a.planes = planes;
+    a.tabs = costtabs;
+    a.jobs = jobs;
+    a.mres = out;
+    fan_out(me_slice, &a, n, nthreads);
+}
+
+void x265o_cost_batch(const x265o_plane *planes, const x265o_cost_req *reqs, int n, int32_t *out, int nthreads)
+{
+    slice_arg a;
+    memset(&a, 0, sizeof(a));
+    a.planes = planes;
+    a.reqs = reqs;
+    a.cres = out;
+    fan_out(cost_slice, &a, n, nthreads);
+}
+
+/* ------------------------------------------------------------------------- */
+/* config-2 hierarchical full search, one CTU                                 */
+
+void x265o_ctu_fullsearch(const x265o_plane *fenc, const x265o_plane *ref, const uint16_t *costtab, int ctu_x,
+                          int ctu_y, int mvmin_x, int mvmin_y, int mvmax_x, int mvmax_y, int qmvp_x, int qmvp_y,
+                          x265o_me_result *out)
+{
+    /* PU order: level 0 = 64x64 (1), level 1 = 32x32 (4), level 2 = 16x16 (16), level 3 = 8x8 (64);
+     * inside a level PUs are in raster order of their position in the CTU. */
+    int idx = 0;
+    for (int lvl = 0; lvl < 4; lvl++)
+    {
+        int size = 64 >> lvl, n = 1 << lvl;
+        for (int by = 0; by < n; by++)
+            for (int bx = 0; bx < n; bx++, idx++)
+            {
+                const uint8_t *f = fenc->origin + (ctu_x + bx * size) + (intptr_t)(ctu_y + by * size) * fenc->stride;
+                const uint8_t *r = ref->origin + (ctu_x + bx * size) + (intptr_t)(ctu_y + by * size) * ref->stride;
+                int best = INT_MAX, bmx = 0, bmy = 0;
+                for (int my = mvmin_y; my <= mvmax_y; my++)
+                    for (int mx = mvmin_x; mx <= mvmax_x; mx++)
+                    {
+                        int cost = sad_wh(size, size, f, fenc->stride, r + mx + my * ref->stride, ref->stride)
+                                   + (uint16_t)(tab_at(costtab, qmvp_x, s16(mx << 2)) + tab_at(costtab, qmvp_y, s16(my << 2)));
+                        if (cost < best)
+                        {
+                            best = cost;
+                            bmx = mx;
+                            bmy = my;
+                        }
+                    }
+                out[idx].cost = best;
+                out[idx].mvx = s16(bmx << 2);
+                out[idx].mvy = s16(bmy << 2);
+            }
+    }
+}

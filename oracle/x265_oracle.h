@@ -1,0 +1,115 @@
+/* x265_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, single-thread-per-job CPU restatement of the x265 motion-estimation
+ * cost path (SAD / SATD / 8-tap luma interpolation / MV bit cost / the
+ * MotionEstimate search state machine).  It exists so that the HIP path can be
+ * checked bit-for-bit on a machine that has no copy of the reference.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  Nothing under x265_amd/ links, imports or calls it.
+ *
+ * Parity status: PINNED.  Every function here is compared against the real
+ * reference C primitives / MotionEstimate (built from /root/reference by
+ * oracle/Makefile into oracle/_ref/libx265ref.so) by tests/test_oracle_vs_ref.py
+ * when that library is present, and against tests/golden/ fixtures (generated
+ * from that same library by oracle/gen_golden.py) everywhere else.
+ *
+ * Each function cites the reference file:line it restates (paths relative to
+ * /root/reference/source).
+ */
+#ifndef X265_ORACLE_H
+#define X265_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X265O_NUM_PARTS 25
+#define X265O_MAX_MVC   12
+
+/* Same byte layout as x265_hip_me_job in include/x265_hip.h (declared again
+ * here on purpose: the oracle shares no header with the product). */
+typedef struct x265o_me_job
+{
+    int32_t fenc_plane;
+    int32_t ref_plane;
+    int16_t pu_x, pu_y;
+    uint8_t pu_w, pu_h;
+    uint8_t method;     /* 0 DIA 1 HEX 2 UMH 3 STAR 4 FULL  (x265.h:143-147) */
+    uint8_t subme;      /* 0..7                              (x265.h:192)     */
+    int16_t mvmin_x, mvmin_y, mvmax_x, mvmax_y; /* full-pel, inclusive */
+    int16_t qmvp_x, qmvp_y;                     /* quarter-pel         */
+    int16_t merange;
+    uint8_t qp;
+    uint8_t num_mvc;
+    int16_t mvc[2 * X265O_MAX_MVC];             /* quarter-pel x,y pairs */
+} x265o_me_job;
+
+typedef struct x265o_me_result
+{
+    int32_t cost;
+    int16_t mvx, mvy; /* quarter-pel */
+} x265o_me_result;
+
+typedef struct x265o_plane
+{
+    const uint8_t *origin; /* pointer to picture sample (0,0) inside a padded buffer */
+    intptr_t stride;
+} x265o_plane;
+
+/* one batched cost request: block (x,y,w,h) of fenc vs ref displaced by qmv */
+typedef struct x265o_cost_req
+{
+    int32_t fenc_plane;
+    int32_t ref_plane;
+    int16_t pu_x, pu_y;
+    uint8_t pu_w, pu_h;
+    uint8_t metric; /* 0 SAD 1 SATD */
+    uint8_t pad;
+    int16_t qmv_x, qmv_y;
+} x265o_cost_req;
+
+int  x265o_partition_from_sizes(int w, int h);
+void x265o_partition_size(int part, int *w, int *h);
+
+int  x265o_sad(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *fref, intptr_t rstride);
+void x265o_sad_x3(int part, const uint8_t *fenc, const uint8_t *r0, const uint8_t *r1, const uint8_t *r2,
+                  intptr_t rstride, int32_t *res);
+void x265o_sad_x4(int part, const uint8_t *fenc, const uint8_t *r0, const uint8_t *r1, const uint8_t *r2,
+                  const uint8_t *r3, intptr_t rstride, int32_t *res);
+int  x265o_satd(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *fref, intptr_t rstride);
+
+void x265o_luma_hpp(int part, const uint8_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int coeffIdx);
+void x265o_luma_vpp(int part, const uint8_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int coeffIdx);
+void x265o_luma_hps(int part, const uint8_t *src, intptr_t sstride, int16_t *dst, intptr_t dstride, int coeffIdx,
+                    int isRowExt);
+void x265o_luma_vsp(int part, const int16_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int coeffIdx);
+void x265o_luma_copy_pp(int part, uint8_t *dst, intptr_t dstride, const uint8_t *src, intptr_t sstride);
+
+/* fills out[65536]; out[32768 + d] is the lambda-scaled cost of MVD component d */
+void x265o_bitcost_table(int qp, uint16_t *out);
+
+/* MotionEstimate::subpelCompare restated: cost of the block at qmv, metric 0 SAD / 1 SATD */
+int  x265o_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, int y, int w, int h,
+                       int qmvx, int qmvy, int metric);
+
+/* Batched front-ends.  costtabs[qp] points at 65536 entries (centre at +32768).
+ * nthreads <= 1 runs inline. */
+void x265o_cost_batch(const x265o_plane *planes, const x265o_cost_req *reqs, int n, int32_t *out, int nthreads);
+void x265o_me_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_me_job *jobs, int n,
+                    x265o_me_result *out, int nthreads);
+
+/* Hierarchical full search used by config 2: for one 64x64 CTU at (ctu_x,ctu_y), every square PU of
+ * sizes 64/32/16/8 (85 PUs, z-order within each level, levels 64,32,16,8) is searched over
+ * [mvmin,mvmax] in raster order with SAD + mvcost; equivalent to motionEstimate(FULL) restricted to
+ * its integer stage with bcost initialised to INT_MAX.  out: 85 results (cost, full-pel mv<<2). */
+void x265o_ctu_fullsearch(const x265o_plane *fenc, const x265o_plane *ref, const uint16_t *costtab,
+                          int ctu_x, int ctu_y, int mvmin_x, int mvmin_y, int mvmax_x, int mvmax_y,
+                          int qmvp_x, int qmvp_y, x265o_me_result *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,35 @@
+"""numpy views of the structs declared in include/x265_hip.h (keep the two in step)."""
+import numpy as np
+
+MAX_MVC = 12
+NUM_PARTS = 25
+
+# LumaPartitions order, source/common/primitives.h:38-46 of the reference (index order is ABI)
+PARTS = [(4, 4), (8, 8), (8, 4), (4, 8), (16, 16), (16, 8), (8, 16), (16, 12), (12, 16), (16, 4), (4, 16),
+         (32, 32), (32, 16), (16, 32), (32, 24), (24, 32), (32, 8), (8, 32), (64, 64), (64, 32), (32, 64),
+         (64, 48), (48, 64), (64, 16), (16, 64)]
+
+DIA, HEX, UMH, STAR, FULL = range(5)
+SAD, SATD = 0, 1
+
+ME_JOB = np.dtype([
+    ("fenc_plane", "<i4"), ("ref_plane", "<i4"),
+    ("pu_x", "<i2"), ("pu_y", "<i2"),
+    ("pu_w", "u1"), ("pu_h", "u1"), ("method", "u1"), ("subme", "u1"),
+    ("mvmin_x", "<i2"), ("mvmin_y", "<i2"), ("mvmax_x", "<i2"), ("mvmax_y", "<i2"),
+    ("qmvp_x", "<i2"), ("qmvp_y", "<i2"),
+    ("merange", "<i2"), ("qp", "u1"), ("num_mvc", "u1"),
+    ("mvc", "<i2", (2 * MAX_MVC,)),
+], align=False)
+assert ME_JOB.itemsize == 80
+
+ME_RESULT = np.dtype([("cost", "<i4"), ("mvx", "<i2"), ("mvy", "<i2")])
+assert ME_RESULT.itemsize == 8
+
+COST_REQ = np.dtype([
+    ("fenc_plane", "<i4"), ("ref_plane", "<i4"),
+    ("pu_x", "<i2"), ("pu_y", "<i2"),
+    ("pu_w", "u1"), ("pu_h", "u1"), ("metric", "u1"), ("pad", "u1"),
+    ("qmv_x", "<i2"), ("qmv_y", "<i2"),
+])
+assert COST_REQ.itemsize == 20

@@ -1,0 +1,198 @@
+"""Deterministic synthetic input for the ME cost path (host side, numpy only).
+
+Frames follow the recipe of SURVEY.md section 8(d): a smooth random texture panned a few pixels per
+frame, a handful of independently moving patches (every fourth frame displaced by half a pixel so
+that sub-pel candidates sometimes win) and +-2 noise.  Planes are laid out like the reference's
+TComPicYuv luma plane (source/Lib/TLibCommon/TComPicYuv.cpp:78-97): marginX = 96, marginY = 80,
+stride = ceil(W/64)*64 + 192, edge-extended the way extendPicBorder does (source/common/pixel.cpp:893-911).
+
+Nothing here is timed; bench.py uploads the result once and keeps it resident in HBM.
+"""
+import numpy as np
+
+from .abi import ME_JOB, MAX_MVC
+
+MARGIN_X = 96
+MARGIN_Y = 80
+CTU = 64
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix(x):
+    """splitmix64 finaliser on a uint64 array (counter-based, so every sample is reproducible)."""
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        x = x ^ (x >> np.uint64(31))
+    return x
+
+
+def hash2d(h, w, seed):
+    """uint64 noise field of shape (h, w)."""
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.uint64), np.arange(w, dtype=np.uint64), indexing="ij")
+    with np.errstate(over="ignore"):
+        key = (yy * np.uint64(0x100000001B3) + xx + np.uint64(seed) * np.uint64(0x632BE59BD9B4E019)) & _M64
+    return _mix(key)
+
+
+def _smooth(a, passes):
+    a = a.astype(np.float32)
+    for _ in range(passes):
+        a = (np.roll(a, 1, 0) + 2 * a + np.roll(a, -1, 0)) * 0.25
+        a = (np.roll(a, 1, 1) + 2 * a + np.roll(a, -1, 1)) * 0.25
+    return a
+
+
+class Sequence:
+    """Synthetic luma sequence of `width` x `height` pictures."""
+
+    def __init__(self, width, height, seed=0x265, n_patches=8):
+        self.w, self.h, self.seed = width, height, seed
+        th, tw = height + 128, width + 128  # room for the pan
+        coarse = (hash2d((th + 7) // 8, (tw + 7) // 8, seed) >> np.uint64(56)).astype(np.float32)
+        coarse = np.kron(coarse, np.ones((8, 8), np.float32))[:th, :tw]
+        mid = (hash2d((th + 1) // 2, (tw + 1) // 2, seed + 1) >> np.uint64(58)).astype(np.float32)
+        mid = np.kron(mid, np.ones((2, 2), np.float32))[:th, :tw]
+        tex = _smooth(coarse, 3) * 0.75 + _smooth(mid, 1) * 0.9 + 16.0
+        self.tex = np.clip(tex, 0, 255).astype(np.uint8)
+        p = _mix(np.arange(n_patches * 8, dtype=np.uint64) + np.uint64(seed * 7919))
+        p = p.reshape(n_patches, 8)
+        self.patches = []
+        for k in range(n_patches):
+            x0 = int(p[k, 0] % np.uint64(max(1, width - 256))) + 64
+            y0 = int(p[k, 1] % np.uint64(max(1, height - 256))) + 64
+            vx = int(p[k, 2] % np.uint64(9)) - 4
+            vy = int(p[k, 3] % np.uint64(7)) - 3
+            body = (hash2d(128 // 4, 128 // 4, seed + 100 + k) >> np.uint64(56)).astype(np.float32)
+            body = np.clip(_smooth(np.kron(body, np.ones((4, 4), np.float32)), 2), 0, 255).astype(np.uint8)
+            self.patches.append((x0, y0, vx, vy, body))
+
+    def frame(self, n):
+        w, h = self.w, self.h
+        px, py = (3 * n) % 61, (2 * n) % 37
+        f = self.tex[py:py + h, px:px + w].astype(np.int16)
+        for (x0, y0, vx, vy, body) in self.patches:
+            x = (x0 + n * vx) % max(1, w - 130)
+            y = (y0 + n * vy) % max(1, h - 130)
+            if n % 4 == 3:  # half-pel horizontal displacement: average of two integer placements
+                a = f[y:y + 128, x:x + 129].copy()
+                a[:, :128] = body
+                b = f[y:y + 128, x:x + 129].copy()
+                b[:, 1:129] = body
+                f[y:y + 128, x:x + 129] = (a + b + 1) >> 1
+            else:
+                f[y:y + 128, x:x + 128] = body
+        noise = (hash2d(h, w, self.seed + 1000 + n) >> np.uint64(60)).astype(np.int16) % 5 - 2
+        return np.clip(f + noise, 0, 255).astype(np.uint8)
+
+    def global_motion(self, n_cur, n_ref):
+        """integer displacement (dx, dy) such that cur(x, y) ~ ref(x + dx, y + dy) for the background."""
+        cx, cy = (3 * n_cur) % 61, (2 * n_cur) % 37
+        rx, ry = (3 * n_ref) % 61, (2 * n_ref) % 37
+        return cx - rx, cy - ry
+
+
+class Plane:
+    """Padded, edge-extended luma plane in the reference's TComPicYuv layout."""
+
+    def __init__(self, pic):
+        h, w = pic.shape
+        self.w, self.h = w, h
+        self.stride = -(-w // CTU) * CTU + 2 * MARGIN_X
+        self.rows = -(-h // CTU) * CTU + 2 * MARGIN_Y
+        self.origin = MARGIN_Y * self.stride + MARGIN_X
+        buf = np.zeros((self.rows, self.stride), np.uint8)
+        buf[MARGIN_Y:MARGIN_Y + h, MARGIN_X:MARGIN_X + w] = pic
+        # left / right margins of picture rows, then whole rows up and down (extendPicBorder)
+        buf[MARGIN_Y:MARGIN_Y + h, :MARGIN_X] = pic[:, :1]
+        buf[MARGIN_Y:MARGIN_Y + h, MARGIN_X + w:MARGIN_X + w + MARGIN_X] = pic[:, -1:]
+        buf[:MARGIN_Y, :] = buf[MARGIN_Y]
+        buf[MARGIN_Y + h:MARGIN_Y + h + MARGIN_Y, :] = buf[MARGIN_Y + h - 1]
+        self.buf = buf.reshape(-1)
+
+    @property
+    def nbytes(self):
+        return self.buf.size
+
+    def as_tuple(self):
+        return (self.buf, self.origin, self.stride)
+
+
+def ctu_grid(w, h):
+    return -(-w // CTU), -(-h // CTU)
+
+
+def square_pus(w, h, sizes=(64, 32, 16, 8)):
+    """All square PUs of the given sizes lying wholly inside the picture: array of (x, y, size)."""
+    out = []
+    ncx, ncy = ctu_grid(w, h)
+    for cy in range(ncy):
+        for cx in range(ncx):
+            for s in sizes:
+                n = CTU // s
+                for by in range(n):
+                    for bx in range(n):
+                        x, y = cx * CTU + bx * s, cy * CTU + by * s
+                        if x + s <= w and y + s <= h:
+                            out.append((x, y, s))
+    return np.array(out, np.int32)
+
+
+def clip_mv(qx, qy, cu_x, cu_y, w, h):
+    """TComDataCU::clipMv (source/Lib/TLibCommon/TComDataCU.cpp:2502-2514), quarter-pel in/out."""
+    xmax = (w + 8 - cu_x - 1) << 2
+    xmin = (-CTU - 8 - cu_x + 1) << 2
+    ymax = (h + 8 - cu_y - 1) << 2
+    ymin = (-CTU - 8 - cu_y + 1) << 2
+    return np.minimum(xmax, np.maximum(xmin, qx)), np.minimum(ymax, np.maximum(ymin, qy))
+
+
+def search_range(qmvp_x, qmvp_y, merange, cu_x, cu_y, w, h):
+    """TEncSearch::xSetSearchRange (source/Lib/TLibEncoder/TEncSearch.cpp:2600-2617) without the
+    frame-parallel lag clamp: returns full-pel (mvmin_x, mvmin_y, mvmax_x, mvmax_y)."""
+    px, py = clip_mv(qmvp_x, qmvp_y, cu_x, cu_y, w, h)
+    d = merange << 2
+    lox, loy = clip_mv(px - d, py - d, cu_x, cu_y, w, h)
+    hix, hiy = clip_mv(px + d, py + d, cu_x, cu_y, w, h)
+    return lox >> 2, loy >> 2, hix >> 2, hiy >> 2
+
+
+def me_jobs(w, h, fenc_plane, ref_planes, motions, method=1, subme=2, merange=57, seed=1, sizes=(64, 32, 16, 8),
+            qp_base=30, num_mvc=3):
+    """Job list of one ME-stage frame: every square PU x every reference.
+
+    `motions[i]` is the (dx, dy) background displacement towards `ref_planes[i]`; predictors are
+    that motion in quarter-pel plus a small hashed perturbation, the way AMVP neighbours scatter
+    around the true motion.  Search windows follow xSetSearchRange.
+    """
+    pus = square_pus(w, h, sizes)
+    n = len(pus)
+    jobs = np.zeros(n * len(ref_planes), ME_JOB)
+    for r, (rp, (dx, dy)) in enumerate(zip(ref_planes, motions)):
+        j = jobs[r * n:(r + 1) * n]
+        hsh = _mix(np.arange(n, dtype=np.uint64) * np.uint64(16) + np.uint64(seed * 1000003 + r * 7919))
+        j["fenc_plane"] = fenc_plane
+        j["ref_plane"] = rp
+        j["pu_x"], j["pu_y"] = pus[:, 0], pus[:, 1]
+        j["pu_w"] = j["pu_h"] = pus[:, 2]
+        j["method"], j["subme"], j["merange"] = method, subme, merange
+        ctu_x, ctu_y = (pus[:, 0] // CTU) * CTU, (pus[:, 1] // CTU) * CTU
+        j["qp"] = qp_base + ((ctu_x // CTU + 3 * (ctu_y // CTU)) % 7)
+        px = 4 * dx + ((hsh >> np.uint64(8)) % np.uint64(13)).astype(np.int64) - 6
+        py = 4 * dy + ((hsh >> np.uint64(16)) % np.uint64(13)).astype(np.int64) - 6
+        j["qmvp_x"], j["qmvp_y"] = px, py
+        lox, loy, hix, hiy = search_range(px, py, merange, ctu_x, ctu_y, w, h)
+        j["mvmin_x"], j["mvmin_y"], j["mvmax_x"], j["mvmax_y"] = lox, loy, hix, hiy
+        j["num_mvc"] = num_mvc
+        for c in range(num_mvc):
+            hx = ((hsh >> np.uint64(24 + 8 * c)) % np.uint64(17)).astype(np.int64) - 8
+            hy = ((hsh >> np.uint64(28 + 8 * c)) % np.uint64(17)).astype(np.int64) - 8
+            if c == num_mvc - 1:
+                hx = hx * 0 - 4 * dx  # one candidate is the zero vector
+                hy = hy * 0 - 4 * dy
+            j["mvc"][:, 2 * c] = 4 * dx + hx
+            j["mvc"][:, 2 * c + 1] = 4 * dy + hy
+    return jobs
