@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- ME cost path throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1]): batched integer-pel full search, 1080p, 64x64 CTUs, +-64 range.
+One step = one picture searched against one reference: every 64x64 CTU, every square PU
+(64/32/16/8) wholly inside the picture, every integer position of the window that
+xSetSearchRange gives around the CTU's predictor, SAD + mvcost, first minimum in raster order.
+`value` counts (PU, position) cost evaluations per second with planes, job lists and results resident
+in HBM.  A second timed leg (reported in extra keys) runs the full motionEstimate replay
+(HEX, subme 2, merange 57, 3 references: configs[2]) on the same pictures.
+
+For N > 1 the driver launches one rank per GPU; ranks take disjoint GOP segments of the
+sequence (no collective on the data path) and the job-wide rate is units / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 1920, 1080
+RANGE = 64
+PX_PEAK = 1.34e14     # measured v_qsad_pk_u16_u8 / v_sad_u8 pixel rate, profiles/r01_ubench_valu.txt
+LANE_PEAK = 7.86e13   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector / 2)
+HBM_PEAK = 8000.0     # GB/s
+
+
+def build_ctu_jobs(seq, cur, ref, fenc_plane, ref_plane, qp=30):
+    from x265_amd import lib, synth
+    ncx, ncy = synth.ctu_grid(W, H)
+    dx, dy = seq.global_motion(cur, ref)
+    jobs = np.zeros(ncx * ncy, lib.CTU_JOB)
+    k = 0
+    for cy in range(ncy):
+        for cx in range(ncx):
+            j = jobs[k]
+            k += 1
+            x, y = cx * 64, cy * 64
+            lox, loy, hix, hiy = synth.search_range(np.int64(4 * dx), np.int64(4 * dy), RANGE, x, y, W, H)
+            j["fenc_plane"], j["ref_plane"] = fenc_plane, ref_plane
+            j["ctu_x"], j["ctu_y"] = x, y
+            j["mvmin_x"], j["mvmin_y"], j["mvmax_x"], j["mvmax_y"] = lox, loy, hix, hiy
+            j["qmvp_x"], j["qmvp_y"] = 4 * dx, 4 * dy
+            j["qp"] = qp
+    return jobs
+
+
+def valid_pus_per_ctu():
+    """number of square PUs wholly inside the picture, per CTU in raster order"""
+    from x265_amd import synth
+    ncx, ncy = synth.ctu_grid(W, H)
+    out = np.zeros(ncx * ncy, np.int64)
+    for cy in range(ncy):
+        for cx in range(ncx):
+            n = 0
+            for s in (64, 32, 16, 8):
+                nx = min(64, W - cx * 64) // s
+                ny = min(64, H - cy * 64) // s
+                n += nx * ny
+            out[cy * ncx + cx] = n
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames", type=int, default=4, help="pictures per rank kept resident (steps cycle over them)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from x265_amd import abi, lib, synth
+
+    # ---- resident input: this rank's GOP segment -----------------------------------------------
+    nfr = args.frames
+    seq = synth.Sequence(W, H, seed=0x265)
+    first = rank * nfr  # disjoint segments of the same synthetic sequence
+    planes = [synth.Plane(seq.frame(first + i)) for i in range(nfr + 3)]
+    ctx = lib.Context(local)
+    for i, p in enumerate(planes):
+        ctx.plane_upload(i, p.buf, p.stride, p.origin)
+    for qp in range(28, 40):
+        ctx.set_qp(qp)
+
+    # step s searches picture (3 + s % nfr) against the previous picture
+    vp = valid_pus_per_ctu()
+    fs_jobs, fs_units, fs_pos = [], [], []
+    for i in range(nfr):
+        cur = 3 + i
+        j = build_ctu_jobs(seq, first + cur, first + cur - 1, cur, cur - 1)
+        npos = (j["mvmax_x"].astype(np.int64) - j["mvmin_x"] + 1) * (j["mvmax_y"].astype(np.int64) - j["mvmin_y"] + 1)
+        fs_units.append(int((npos * vp).sum()))
+        fs_pos.append(int(npos.sum()))
+        fs_jobs.append(torch.from_numpy(j.view(np.uint8).copy()).to(dev))
+    n_ctu = len(vp)
+    fs_out = torch.empty(n_ctu * lib.PUS_PER_CTU * 8, dtype=torch.uint8, device=dev)
+
+    me_jobs, me_n = [], []
+    for i in range(nfr):
+        cur = 3 + i
+        refs = [cur - 1, cur - 2, cur - 3]
+        mot = [seq.global_motion(first + cur, first + r) for r in refs]
+        j = synth.me_jobs(W, H, cur, refs, mot, method=abi.HEX, subme=2, merange=57, seed=first + cur)
+        me_n.append(len(j))
+        me_jobs.append(torch.from_numpy(j.view(np.uint8).copy()).to(dev))
+    me_out = torch.empty(max(me_n) * 8, dtype=torch.uint8, device=dev)
+
+    ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_fs(step):
+        i = step % nfr
+        ctx.fullsearch_device(fs_jobs[i].data_ptr(), n_ctu, fs_out.data_ptr())
+        return fs_units[i], fs_pos[i]
+
+    def run_me(step):
+        i = step % nfr
+        ctx.me_batch_device(me_jobs[i].data_ptr(), me_n[i], me_out.data_ptr())
+        return me_n[i]
+
+    def timed(fn, steps, warmup):
+        for s in range(warmup):
+            fn(s)
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(ext)
+        acc = []
+        for s in range(steps):
+            acc.append(fn(s))
+        e1.record(ext)
+        barrier()
+        dt = time.perf_counter() - t0
+        ev_ms = e0.elapsed_time(e1)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, ev_ms, acc
+
+    dt_fs, ev_fs, acc_fs = timed(run_fs, args.steps, args.warmup)
+    units = sum(a[0] for a in acc_fs)
+    positions = sum(a[1] for a in acc_fs)
+    dt_me, ev_me, acc_me = timed(run_me, args.steps, args.warmup)
+    me_calls = sum(acc_me)
+
+    # ---- CPU baseline: the reference's own C primitives (oracle/_ref) when present, else the port ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import pyoracle  # checker libraries: used for this baseline leg only
+        chk = pyoracle.load_ref() if pyoracle.have_ref() else pyoracle.load_oracle()
+        cores = min(16, os.cpu_count() or 1)
+        j = build_ctu_jobs(seq, first + 3, first + 2, 3, 2)
+        sample = list(range(0, n_ctu, max(1, n_ctu // (4 * cores))))[:4 * cores]
+        tab = lib.costtab_build(30)
+        pl = [p.as_tuple() for p in planes]
+
+        def one(k):
+            jj = j[k]
+            chk.ctu_fullsearch(pl[3], pl[2], tab, int(jj["ctu_x"]), int(jj["ctu_y"]),
+                               (int(jj["mvmin_x"]), int(jj["mvmin_y"])), (int(jj["mvmax_x"]), int(jj["mvmax_y"])),
+                               (int(jj["qmvp_x"]), int(jj["qmvp_y"])))
+            npos = (int(jj["mvmax_x"]) - int(jj["mvmin_x"]) + 1) * (int(jj["mvmax_y"]) - int(jj["mvmin_y"]) + 1)
+            return npos * 85
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            cu = sum(ex.map(one, sample))
+        cdt = time.perf_counter() - t0
+        cpu = {"value": cu / cdt, "unit": "candidates/s", "cores": cores, "kind": chk.kind,
+               "sample": f"{len(sample)} of {n_ctu} CTUs of one 1080p picture, same windows; "
+                         f"{'reference C primitives (no asm: no yasm in the image)' if chk.kind == 'reference' else 'C restatement'}"
+                         f", one thread per CTU, {cdt:.1f} s"}
+
+    if rank == 0:
+        total_units = units * world
+        k_ms = ev_fs / args.steps
+        px_ops = positions / args.steps * 4096  # 64x64 pixel-ops per position per CTU with full 8x8 reuse
+        alg_bytes = n_ctu * (4096 + (64 + 2 * RANGE) ** 2 + 85 * 8 + 28)
+        line = {
+            "metric": "ME candidates/sec (integer-pel SAD full search, bit-exact)",
+            "value": total_units / dt_fs, "unit": "candidates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_fs / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1080p, 64x64 CTUs, +-64 integer full search, 85 square PUs per CTU, 1 reference",
+                       "ctus_per_step": n_ctu, "gop_sharding": f"{world} segment(s) of {nfr} pictures"},
+            "me_stage": {"workload": "configs[2]: motionEstimate replay, HEX, subme 2, merange 57, 3 references, "
+                                     "square PUs 64..8",
+                         "frames_per_s": args.steps * world / dt_me, "me_calls_per_s": me_calls * world / dt_me,
+                         "satd_candidates_per_s": me_calls * world * 9 / dt_me, "ms_per_frame": dt_me / args.steps * 1e3,
+                         "kernel_ms_per_frame": ev_me / args.steps},
+            "roofline": {"bound": "valu", "achieved": px_ops / (k_ms * 1e-3) / 1e12, "peak": PX_PEAK / 1e12,
+                         "unit": "Tpixel-op/s", "frac": px_ops / (k_ms * 1e-3) / PX_PEAK,
+                         "kernel": "fullsearch_kernel", "kernel_ms": k_ms, "traffic": None,
+                         "hbm": {"achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
+                                 "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK}},
+        }
+        if cpu:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,205 @@
+/* x265_hip.h -- C ABI of the MI355X (gfx950) implementation of x265's motion-estimation cost path.
+ *
+ * This is the drop-in boundary: plain C, pointers and sizes only.  Two groups of entry points:
+ *
+ *  (1) Primitive level -- the exact signatures of the reference's function-pointer table
+ *      (struct EncoderPrimitives, source/common/primitives.h:191-283 of the reference) for the
+ *      entries on the ME cost path.  x265_hip_setup_primitives() fills a table of such pointers;
+ *      a maintainer's Setup_HIP_Primitives() copies them over the C/asm entries.
+ *      They take HOST pointers, stage the operands through the GPU and return synchronously, so
+ *      they are bit-exact drop-ins but not fast; throughput comes from group (2).
+ *
+ *  (2) Batched level -- whole-CTU-row / whole-frame candidate sets per launch with planes resident
+ *      in HBM.  These have no counterpart in the reference (it calls one primitive per candidate
+ *      from MotionEstimate::motionEstimate, source/encoder/motion.cpp:526-1124); each one cites the
+ *      reference code whose results it reproduces.
+ *
+ * Every function returns 0 on success or a negative X265_HIP_E* code; none throws.  All functions
+ * are thread-safe; a context serialises its own launches on one HIP stream.
+ *
+ * There is no CPU fallback: if no gfx950 device is usable the calls fail with X265_HIP_ENODEV.
+ */
+#ifndef X265_HIP_H
+#define X265_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X265_HIP_OK        0
+#define X265_HIP_ENODEV   -1 /* no usable gfx950 device / HIP runtime error at init */
+#define X265_HIP_EINVAL   -2 /* bad argument (null pointer, unknown plane id, bad partition ...) */
+#define X265_HIP_ENOMEM   -3 /* device or pinned-host allocation failed */
+#define X265_HIP_ERUNTIME -4 /* a HIP call failed; x265_hip_last_error() has the text */
+#define X265_HIP_ERANGE   -5 /* request exceeds a documented limit */
+
+/* LumaPartitions, in the reference's index order (source/common/primitives.h:38-46): the index is ABI. */
+enum
+{
+    X265_HIP_LUMA_4x4, X265_HIP_LUMA_8x8, X265_HIP_LUMA_8x4, X265_HIP_LUMA_4x8,
+    X265_HIP_LUMA_16x16, X265_HIP_LUMA_16x8, X265_HIP_LUMA_8x16, X265_HIP_LUMA_16x12, X265_HIP_LUMA_12x16,
+    X265_HIP_LUMA_16x4, X265_HIP_LUMA_4x16,
+    X265_HIP_LUMA_32x32, X265_HIP_LUMA_32x16, X265_HIP_LUMA_16x32, X265_HIP_LUMA_32x24, X265_HIP_LUMA_24x32,
+    X265_HIP_LUMA_32x8, X265_HIP_LUMA_8x32,
+    X265_HIP_LUMA_64x64, X265_HIP_LUMA_64x32, X265_HIP_LUMA_32x64, X265_HIP_LUMA_64x48, X265_HIP_LUMA_48x64,
+    X265_HIP_LUMA_64x16, X265_HIP_LUMA_16x64,
+    X265_HIP_NUM_LUMA_PARTITIONS
+};
+
+/* search methods, values of the reference's X265_*_SEARCH (source/x265.h:143-147) */
+enum { X265_HIP_DIA = 0, X265_HIP_HEX = 1, X265_HIP_UMH = 2, X265_HIP_STAR = 3, X265_HIP_FULL = 4 };
+enum { X265_HIP_SAD = 0, X265_HIP_SATD = 1 };
+
+#define X265_HIP_MAX_MVC    12  /* AMVP + spatial candidates, <= 11 in the reference (TEncSearch.cpp:2311) */
+#define X265_HIP_MAX_PLANES 64
+#define X265_HIP_MAX_QP     82  /* BitCost::BC_MAX_QP, source/encoder/bitcost.h:72 */
+#define X265_HIP_FENC_STRIDE 64 /* FENC_STRIDE, source/common/common.h:45 */
+
+typedef struct x265_hip_ctx x265_hip_ctx;
+
+/* ---- (0) context ------------------------------------------------------------------------------ */
+
+int x265_hip_device_count(void);
+int x265_hip_ctx_create(int device, x265_hip_ctx **out);
+void x265_hip_ctx_destroy(x265_hip_ctx *ctx);
+const char *x265_hip_last_error(void); /* thread-local text of the last failure */
+/* the context's hipStream_t, for callers that time or order work with HIP events */
+void *x265_hip_ctx_stream(x265_hip_ctx *ctx);
+int x265_hip_ctx_sync(x265_hip_ctx *ctx);
+
+/* ---- (1) primitive level ---------------------------------------------------------------------- */
+
+/* signatures of source/common/primitives.h:123-127,165-168 with pixel = uint8_t */
+typedef int (*x265_hip_pixelcmp_t)(uint8_t *fenc, intptr_t fencstride, uint8_t *fref, intptr_t frefstride);
+typedef void (*x265_hip_pixelcmp_x3_t)(uint8_t *fenc, uint8_t *fref0, uint8_t *fref1, uint8_t *fref2,
+                                       intptr_t frefstride, int32_t *res);
+typedef void (*x265_hip_pixelcmp_x4_t)(uint8_t *fenc, uint8_t *fref0, uint8_t *fref1, uint8_t *fref2, uint8_t *fref3,
+                                       intptr_t frefstride, int32_t *res);
+typedef void (*x265_hip_filter_pp_t)(uint8_t *src, intptr_t srcStride, uint8_t *dst, intptr_t dstStride, int coeffIdx);
+typedef void (*x265_hip_filter_hps_t)(uint8_t *src, intptr_t srcStride, int16_t *dst, intptr_t dstStride, int coeffIdx,
+                                      int isRowExt);
+typedef void (*x265_hip_filter_sp_t)(int16_t *src, intptr_t srcStride, uint8_t *dst, intptr_t dstStride, int coeffIdx);
+
+/* the slice of EncoderPrimitives this library replaces; member names are the reference's */
+typedef struct x265_hip_primitives
+{
+    x265_hip_pixelcmp_t    sad[X265_HIP_NUM_LUMA_PARTITIONS];      /* primitives.h:193; C: pixel.cpp:92-109  */
+    x265_hip_pixelcmp_x3_t sad_x3[X265_HIP_NUM_LUMA_PARTITIONS];   /* primitives.h:194; C: pixel.cpp:111-131 */
+    x265_hip_pixelcmp_x4_t sad_x4[X265_HIP_NUM_LUMA_PARTITIONS];   /* primitives.h:195; C: pixel.cpp:133-156 */
+    x265_hip_pixelcmp_t    satd[X265_HIP_NUM_LUMA_PARTITIONS];     /* primitives.h:199; C: pixel.cpp:201-288 */
+    x265_hip_filter_pp_t   luma_hpp[X265_HIP_NUM_LUMA_PARTITIONS]; /* primitives.h:221; C: ipfilter.cpp:76-115  */
+    x265_hip_filter_hps_t  luma_hps[X265_HIP_NUM_LUMA_PARTITIONS]; /* primitives.h:222; C: ipfilter.cpp:117-160 */
+    x265_hip_filter_pp_t   luma_vpp[X265_HIP_NUM_LUMA_PARTITIONS]; /* primitives.h:223; C: ipfilter.cpp:162-201 */
+    x265_hip_filter_sp_t   luma_vsp[X265_HIP_NUM_LUMA_PARTITIONS]; /* primitives.h:225; C: ipfilter.cpp:241-282 */
+} x265_hip_primitives;
+
+/* Replaces the assignments Setup_C_PixelPrimitives / Setup_C_IPFilterPrimitives make for these
+ * entries (pixel.cpp:914-946, 986; ipfilter.cpp:399-408).  Creates the process-wide default context
+ * on `device` on first use.  On failure the table is left untouched and a negative code returned
+ * (the reference keeps its C path in that case, primitives.cpp:137-141). */
+int x265_hip_setup_primitives(x265_hip_primitives *table, int device);
+
+/* partitionFromSizes, source/common/primitives.h:103-112: -1 for an invalid size */
+int x265_hip_partition_from_sizes(int width, int height);
+
+/* Optional: tell the primitive thunks that [host_base, host_base+bytes) is a plane that stays
+ * unchanged; fref/src pointers inside it are then served from a device copy made here instead of
+ * being staged on every call.  Unregister before the host memory changes or is freed. */
+int x265_hip_register_host_plane(const uint8_t *host_base, size_t bytes);
+int x265_hip_unregister_host_plane(const uint8_t *host_base);
+
+/* ---- (2) batched level ------------------------------------------------------------------------ */
+
+/* A plane is a padded luma picture in the layout of the reference's TComPicYuv
+ * (source/Lib/TLibCommon/TComPicYuv.cpp:78-97): `origin_offset` is the byte offset of picture
+ * sample (0,0) inside the buffer (= marginY*stride + marginX), i.e. what ReferencePlanes::fpelPlane
+ * points at (source/encoder/reference.cpp:39-47).  Margins must cover every sample a search can
+ * touch (the reference guarantees 96 / 80). */
+int x265_hip_plane_upload(x265_hip_ctx *ctx, int plane_id, const uint8_t *host_buf, size_t bytes, int stride,
+                          int origin_offset);
+/* adopt memory already in HBM (not freed by the library); must be readable 16 bytes past `bytes` */
+int x265_hip_plane_bind(x265_hip_ctx *ctx, int plane_id, const void *device_buf, size_t bytes, int stride,
+                        int origin_offset);
+int x265_hip_plane_release(x265_hip_ctx *ctx, int plane_id);
+
+/* One lambda-scaled MVD cost row as BitCost::setQP builds it (source/encoder/bitcost.cpp:31-56):
+ * tab[32768 + d] = cost of difference d, d in [-32768, 32767].  The table is an input: it is made
+ * with host floating point in the reference and is never recomputed on the GPU. */
+int x265_hip_costtab_upload(x265_hip_ctx *ctx, int qp, const uint16_t *tab65536);
+/* host-side restatement of BitCost::setQP for qp 0..69 (bitcost.cpp:31-80, x265_lambda_tab of
+ * TComRom.cpp:127-143): build fills tab65536, set_qp builds and uploads */
+int x265_hip_costtab_build(int qp, uint16_t *tab65536);
+int x265_hip_costtab_set_qp(x265_hip_ctx *ctx, int qp);
+
+/* one (block, reference, quarter-pel MV, metric) cost = MotionEstimate::subpelCompare
+ * (motion.cpp:1126-1164) followed by sad/satd; no mvcost added */
+typedef struct x265_hip_cost_req
+{
+    int32_t fenc_plane;
+    int32_t ref_plane;
+    int16_t pu_x, pu_y; /* block origin in picture samples */
+    uint8_t pu_w, pu_h; /* one of the 25 partitions */
+    uint8_t metric;     /* X265_HIP_SAD / X265_HIP_SATD */
+    uint8_t pad;
+    int16_t qmv_x, qmv_y;
+} x265_hip_cost_req;
+
+int x265_hip_cost_batch(x265_hip_ctx *ctx, const x265_hip_cost_req *reqs, int n, int32_t *costs);
+
+/* one call of MotionEstimate::motionEstimate (motion.h:93; motion.cpp:526-1124), non-lowres branch */
+typedef struct x265_hip_me_job
+{
+    int32_t fenc_plane; /* setSourcePlane (motion.h:76-80) */
+    int32_t ref_plane;  /* ReferencePlanes::fpelPlane / lumaStride (lowres.h:36-50) */
+    int16_t pu_x, pu_y; /* setSourcePU offset, as picture coordinates (motion.cpp:110-126) */
+    uint8_t pu_w, pu_h;
+    uint8_t method;     /* setSearchMethod: X265_HIP_DIA .. X265_HIP_FULL */
+    uint8_t subme;      /* setSubpelRefine: 0..7, workload[] of motion.cpp:47-57 */
+    int16_t mvmin_x, mvmin_y, mvmax_x, mvmax_y; /* full-pel, inclusive */
+    int16_t qmvp_x, qmvp_y;                     /* quarter-pel predictor */
+    int16_t merange;
+    uint8_t qp;         /* which uploaded cost table (BitCost::setQP) */
+    uint8_t num_mvc;
+    int16_t mvc[2 * X265_HIP_MAX_MVC]; /* quarter-pel candidates, x,y pairs */
+} x265_hip_me_job;
+
+typedef struct x265_hip_me_result
+{
+    int32_t cost;     /* the int motionEstimate returns */
+    int16_t mvx, mvy; /* outQMv, quarter-pel */
+} x265_hip_me_result;
+
+/* host arrays in, host arrays out (H2D + kernel + D2H, synchronous) */
+int x265_hip_me_batch(x265_hip_ctx *ctx, const x265_hip_me_job *jobs, int n, x265_hip_me_result *results);
+/* same kernel on device-resident job / result arrays, asynchronous on the context stream */
+int x265_hip_me_batch_device(x265_hip_ctx *ctx, const void *d_jobs, int n, void *d_results);
+int x265_hip_cost_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs);
+
+/* Exhaustive integer-pel search of every square PU (64,32,16,8: 85 per CTU) of the listed 64x64
+ * CTUs over [mvmin, mvmax], SAD + mvcost, first minimum in raster order -- the integer stage of
+ * motionEstimate with X265_FULL_SEARCH (motion.cpp:997-1032) started from bcost = INT_MAX, with
+ * 8x8 SADs shared by all PU sizes.  One predictor and window per CTU.  Results: 85 per CTU in the
+ * order 64x64, 32x32 (raster), 16x16 (raster), 8x8 (raster); mv in quarter-pel units. */
+typedef struct x265_hip_ctu_job
+{
+    int32_t fenc_plane;
+    int32_t ref_plane;
+    int16_t ctu_x, ctu_y;
+    int16_t mvmin_x, mvmin_y, mvmax_x, mvmax_y; /* (mvmax-mvmin) <= 131 in x and y */
+    int16_t qmvp_x, qmvp_y;
+    uint8_t qp;
+    uint8_t pad[3];
+} x265_hip_ctu_job;
+
+#define X265_HIP_PUS_PER_CTU 85
+
+int x265_hip_fullsearch(x265_hip_ctx *ctx, const x265_hip_ctu_job *jobs, int n, x265_hip_me_result *results);
+int x265_hip_fullsearch_device(x265_hip_ctx *ctx, const void *d_jobs, int n, void *d_results);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X265_HIP_H */

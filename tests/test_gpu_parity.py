@@ -1,0 +1,123 @@
+"""GPU parity tests: the HIP path through the C ABI against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import random_me_jobs
+
+pytestmark = pytest.mark.gpu
+
+
+def _planes(small_seq):
+    return [p.as_tuple() for p in small_seq]
+
+
+def test_cost_batch_all_partitions_all_fractions(gpu_ctx, oracle, small_seq):
+    from x265_amd import abi
+    rng = np.random.default_rng(11)
+    W, H = small_seq[0].w, small_seq[0].h
+    reqs = []
+    for part in range(25):
+        w, h = abi.PARTS[part]
+        for metric in (0, 1):
+            for fx in range(4):
+                for fy in range(4):
+                    x = int(rng.integers(0, W - w + 1))
+                    y = int(rng.integers(0, H - h + 1))
+                    reqs.append((1, int(rng.choice([0, 2])), x, y, w, h, metric, 0,
+                                 4 * int(rng.integers(-20, 20)) + fx, 4 * int(rng.integers(-20, 20)) + fy))
+    reqs = np.array(reqs, dtype=abi.COST_REQ)
+    got = gpu_ctx.cost_batch(reqs)
+    want = oracle.cost_batch(_planes(small_seq), reqs)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("method", [0, 1, 2, 3])
+def test_me_batch_methods(gpu_ctx, oracle, small_seq, costtabs, method):
+    from x265_amd import abi, synth
+    rng = np.random.default_rng(100 + method)
+    W, H = small_seq[0].w, small_seq[0].h
+    for subme in range(8):
+        jobs = random_me_jobs(rng, 120, method, subme, W, H, abi.ME_JOB, synth.search_range, abi.PARTS)
+        got = gpu_ctx.me_batch(jobs)
+        want = oracle.me_batch(_planes(small_seq), costtabs, jobs)
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, f"method {method} subme {subme}: job {jobs[bad[0]]} got {got[bad[0]]} want {want[bad[0]]}"
+
+
+def test_me_batch_full_search(gpu_ctx, oracle, small_seq, costtabs):
+    from x265_amd import abi, synth
+    rng = np.random.default_rng(5)
+    W, H = small_seq[0].w, small_seq[0].h
+    jobs = random_me_jobs(rng, 24, 4, 2, W, H, abi.ME_JOB, synth.search_range, abi.PARTS, meranges=(3, 6, 9))
+    got = gpu_ctx.me_batch(jobs)
+    want = oracle.me_batch(_planes(small_seq), costtabs, jobs)
+    assert np.array_equal(got, want)
+
+
+def test_fullsearch_ctu(gpu_ctx, oracle, small_seq, costtabs):
+    from x265_amd import lib
+    jobs = np.zeros(4, lib.CTU_JOB)
+    cfg = [(64, 64, -16, -12, 15, 11, 3, -5, 30), (128, 64, -33, -20, 31, 22, -40, 17, 24),
+           (0, 0, -8, -8, 8, 8, 0, 0, 38), (320, 128, -64, -64, 64, 64, 9, 2, 33)]
+    for j, c in zip(jobs, cfg):
+        j["fenc_plane"], j["ref_plane"] = 1, 0
+        (j["ctu_x"], j["ctu_y"], j["mvmin_x"], j["mvmin_y"], j["mvmax_x"], j["mvmax_y"], j["qmvp_x"], j["qmvp_y"],
+         j["qp"]) = c
+    got = gpu_ctx.fullsearch(jobs)
+    pl = _planes(small_seq)
+    for k, c in enumerate(cfg):
+        want = oracle.ctu_fullsearch(pl[1], pl[0], costtabs[c[8]], c[0], c[1], (c[2], c[3]), (c[4], c[5]), (c[6], c[7]))
+        bad = np.nonzero(got[k] != want)[0]
+        assert len(bad) == 0, f"ctu {k}: pu {bad[0]} got {got[k][bad[0]]} want {want[bad[0]]}"
+
+
+def test_primitive_table(oracle):
+    """the function-pointer table (host pointers), inputs shaped like the reference's TestBench:
+    random / all-0 / all-255 buffers, fref stride 64 and FENC_STRIDE-5, offsets stepping by 32
+    (test/pixelharness.cpp:152-171, 215-272); filters with random strides (ipfilterharness.cpp:344-488)"""
+    import ctypes as C
+    from x265_amd import lib
+    t = lib.setup_primitives(0)
+    rng = np.random.default_rng(2)
+    size = 64 * 128 + 32 * 100
+    bufs = [rng.integers(0, 256, size, dtype=np.uint8), np.zeros(size, np.uint8), np.full(size, 255, np.uint8)]
+
+    def addr(a, off=0):
+        return C.c_void_p(a.ctypes.data + off)
+
+    for part in range(25):
+        for it in range(6):
+            a, b = bufs[it % 3], bufs[(it // 3 + it) % 3] if it else bufs[0]
+            ro = 32 * it
+            for rs in (64, 59):
+                assert t.sad[part](addr(a), 64, addr(b, ro), rs) == oracle.sad(part, a, 0, 64, b, ro, rs)
+                assert t.satd[part](addr(a), 64, addr(b, ro), rs) == oracle.satd(part, a, 0, 64, b, ro, rs)
+            res = np.full(4, -1, np.int32)
+            t.sad_x3[part](addr(a), addr(b, ro), addr(b, ro + 1), addr(b, ro + 2), 59, addr(res))
+            assert np.array_equal(res[:3], oracle.sad_x3(part, a, 0, b, [ro, ro + 1, ro + 2], 59)) and res[3] == -1
+            t.sad_x4[part](addr(a), addr(b, ro), addr(b, ro + 1), addr(b, ro + 2), addr(b, ro + 3), 59, addr(res))
+            assert np.array_equal(res, oracle.sad_x4(part, a, 0, b, [ro, ro + 1, ro + 2, ro + 3], 59))
+
+    src = rng.integers(0, 256, 200 * 200, dtype=np.uint8)
+    s16 = rng.integers(-12000, 12000, 200 * 200).astype(np.int16)
+    for part in range(25):
+        for coeff in range(4):
+            ss, ds = int(rng.integers(72, 100)), int(rng.integers(64, 164))
+            so = 6 * ss + 6
+            for name in ("luma_hpp", "luma_vpp"):
+                d1 = np.full(200 * 200, 0x5A, np.uint8)
+                d2 = d1.copy()
+                getattr(t, name)[part](addr(src, so), ss, addr(d1), ds, coeff)
+                getattr(oracle, name)(part, src, so, ss, d2, 0, ds, coeff)
+                assert np.array_equal(d1, d2), (name, part, coeff)  # whole buffer: nothing outside w x h written
+            for ext in (0, 1):
+                d1 = np.full(200 * 200, 0x5A5A, np.int16)
+                d2 = d1.copy()
+                t.luma_hps[part](addr(src, so), ss, addr(d1), ds, coeff, ext)
+                oracle.luma_hps(part, src, so, ss, d2, 0, ds, coeff, ext)
+                assert np.array_equal(d1, d2), ("hps", part, coeff, ext)
+            d1 = np.full(200 * 200, 0x5A, np.uint8)
+            d2 = d1.copy()
+            t.luma_vsp[part](addr(s16, 2 * so), ss, addr(d1), ds, coeff)
+            oracle.luma_vsp(part, s16, so, ss, d2, 0, ds, coeff)
+            assert np.array_equal(d1, d2), ("vsp", part, coeff)

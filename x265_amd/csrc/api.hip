@@ -1,0 +1,793 @@
+// api.hip -- host side of the C ABI declared in include/x265_hip.h.
+//
+// A context owns one HIP stream, the plane / cost-table directory the kernels read
+// (DeviceTables) and grow-on-demand device + pinned-host staging for the host-array entry points.
+// The primitive-level thunks share one process-wide context and serialise on its mutex.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <mutex>
+#include <new>
+#include <shared_mutex>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "kernels.h"
+#include "me_device.h"
+
+using namespace x265hip;
+
+namespace {
+
+thread_local char t_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do                                                                                                  \
+    {                                                                                                   \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? X265_HIP_ENOMEM : X265_HIP_ERUNTIME, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                                         \
+    } while (0)
+
+const uint8_t k_part_w[X265_HIP_NUM_LUMA_PARTITIONS] = { 4, 8, 8, 4, 16, 16, 8, 16, 12, 16, 4, 32, 32, 16, 32,
+                                                         24, 32, 8, 64, 64, 32, 64, 48, 64, 16 };
+const uint8_t k_part_h[X265_HIP_NUM_LUMA_PARTITIONS] = { 4, 8, 4, 8, 16, 8, 16, 12, 16, 4, 16, 32, 16, 32, 24,
+                                                         32, 8, 32, 64, 32, 64, 48, 64, 16, 64 };
+
+struct Buf
+{
+    void *d = nullptr;
+    void *h = nullptr; // pinned mirror
+    size_t cap = 0;
+};
+
+} // namespace
+
+struct x265_hip_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    DeviceTables host_tabs;
+    DeviceTables *dev_tabs = nullptr;
+    bool tabs_dirty = true;
+    void *owned_plane[X265_HIP_MAX_PLANES] = {};
+    size_t plane_bytes[X265_HIP_MAX_PLANES] = {};
+    uint16_t *owned_tab[X265_HIP_MAX_QP] = {};
+    Buf in, out;       // staging of the host-array batch calls
+    Buf prim_a, prim_b; // staging of the primitive thunks
+};
+
+namespace {
+
+int ensure(x265_hip_ctx *c, Buf &b, size_t bytes)
+{
+    if (bytes <= b.cap)
+        return 0;
+    size_t cap = bytes + bytes / 2 + 4096;
+    if (b.d)
+        (void)hipFree(b.d);
+    if (b.h)
+        (void)hipHostFree(b.h);
+    b.d = b.h = nullptr;
+    b.cap = 0;
+    HIP_TRY(hipMalloc(&b.d, cap));
+    HIP_TRY(hipHostMalloc(&b.h, cap, hipHostMallocDefault));
+    b.cap = cap;
+    (void)c;
+    return 0;
+}
+
+int push_tabs(x265_hip_ctx *c)
+{
+    if (!c->tabs_dirty)
+        return 0;
+    HIP_TRY(hipMemcpyAsync(c->dev_tabs, &c->host_tabs, sizeof(DeviceTables), hipMemcpyHostToDevice, c->stream));
+    // host_tabs may change right after this call returns
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->tabs_dirty = false;
+    return 0;
+}
+
+bool is_gfx950(int device)
+{
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess)
+        return false;
+    return strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *x265_hip_last_error(void) { return t_err; }
+
+int x265_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int x265_hip_partition_from_sizes(int width, int height)
+{
+    for (int p = 0; p < X265_HIP_NUM_LUMA_PARTITIONS; p++)
+        if (k_part_w[p] == width && k_part_h[p] == height)
+            return p;
+    return -1;
+}
+
+int x265_hip_ctx_create(int device, x265_hip_ctx **out)
+{
+    if (!out)
+        return fail(X265_HIP_EINVAL, "null out pointer");
+    *out = nullptr;
+    int n = x265_hip_device_count();
+    if (device < 0 || device >= n)
+        return fail(X265_HIP_ENODEV, "device %d not present (%d HIP devices)", device, n);
+    if (!is_gfx950(device))
+        return fail(X265_HIP_ENODEV, "device %d is not gfx950; this library carries gfx950 code only", device);
+    HIP_TRY(hipSetDevice(device));
+    x265_hip_ctx *c = new (std::nothrow) x265_hip_ctx;
+    if (!c)
+        return fail(X265_HIP_ENOMEM, "out of host memory");
+    c->device = device;
+    memset(&c->host_tabs, 0, sizeof(c->host_tabs));
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&c->dev_tabs, sizeof(DeviceTables));
+    if (e != hipSuccess)
+    {
+        delete c;
+        return fail(X265_HIP_ERUNTIME, "context setup: %s", hipGetErrorString(e));
+    }
+    if (fullsearch_setup() != 0)
+    {
+        delete c;
+        return fail(X265_HIP_ERUNTIME, "fullsearch kernel attribute setup failed");
+    }
+    *out = c;
+    return X265_HIP_OK;
+}
+
+void x265_hip_ctx_destroy(x265_hip_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < X265_HIP_MAX_PLANES; i++)
+        if (c->owned_plane[i])
+            (void)hipFree(c->owned_plane[i]);
+    for (int i = 0; i < X265_HIP_MAX_QP; i++)
+        if (c->owned_tab[i])
+            (void)hipFree(c->owned_tab[i]);
+    Buf *bufs[4] = { &c->in, &c->out, &c->prim_a, &c->prim_b };
+    for (Buf *b : bufs)
+    {
+        if (b->d)
+            (void)hipFree(b->d);
+        if (b->h)
+            (void)hipHostFree(b->h);
+    }
+    if (c->dev_tabs)
+        (void)hipFree(c->dev_tabs);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void *x265_hip_ctx_stream(x265_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int x265_hip_ctx_sync(x265_hip_ctx *c)
+{
+    if (!c)
+        return fail(X265_HIP_EINVAL, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return X265_HIP_OK;
+}
+
+// ---- planes and cost tables ---------------------------------------------------------------------
+
+static int plane_set(x265_hip_ctx *c, int id, const void *dev, size_t bytes, int stride, int origin)
+{
+    if (stride <= 0 || origin < 0 || (size_t)origin >= bytes)
+        return fail(X265_HIP_EINVAL, "plane %d: bad stride/origin (%d, %d, %zu bytes)", id, stride, origin, bytes);
+    c->host_tabs.planes[id].origin = (const uint8_t *)dev + origin;
+    c->host_tabs.planes[id].stride = stride;
+    c->plane_bytes[id] = bytes;
+    c->tabs_dirty = true;
+    return X265_HIP_OK;
+}
+
+int x265_hip_plane_release(x265_hip_ctx *c, int id)
+{
+    if (!c || id < 0 || id >= X265_HIP_MAX_PLANES)
+        return fail(X265_HIP_EINVAL, "bad plane id %d", id);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->owned_plane[id])
+        (void)hipFree(c->owned_plane[id]);
+    c->owned_plane[id] = nullptr;
+    c->host_tabs.planes[id].origin = nullptr;
+    c->host_tabs.planes[id].stride = 0;
+    c->plane_bytes[id] = 0;
+    c->tabs_dirty = true;
+    return X265_HIP_OK;
+}
+
+int x265_hip_plane_upload(x265_hip_ctx *c, int id, const uint8_t *host_buf, size_t bytes, int stride, int origin)
+{
+    if (!c || !host_buf || id < 0 || id >= X265_HIP_MAX_PLANES || bytes == 0)
+        return fail(X265_HIP_EINVAL, "plane_upload: bad argument (id %d)", id);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->owned_plane[id] || c->plane_bytes[id] != bytes)
+    {
+        if (c->owned_plane[id])
+            (void)hipFree(c->owned_plane[id]);
+        c->owned_plane[id] = nullptr;
+        // 64 bytes of slack: dword loads at unaligned byte addresses may run past the last sample
+        HIP_TRY(hipMalloc(&c->owned_plane[id], bytes + 64));
+        HIP_TRY(hipMemsetAsync((uint8_t *)c->owned_plane[id] + bytes, 0, 64, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(c->owned_plane[id], host_buf, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return plane_set(c, id, c->owned_plane[id], bytes, stride, origin);
+}
+
+int x265_hip_plane_bind(x265_hip_ctx *c, int id, const void *device_buf, size_t bytes, int stride, int origin)
+{
+    if (!c || !device_buf || id < 0 || id >= X265_HIP_MAX_PLANES || bytes == 0)
+        return fail(X265_HIP_EINVAL, "plane_bind: bad argument (id %d)", id);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->owned_plane[id])
+        (void)hipFree(c->owned_plane[id]);
+    c->owned_plane[id] = nullptr;
+    return plane_set(c, id, device_buf, bytes, stride, origin);
+}
+
+int x265_hip_costtab_upload(x265_hip_ctx *c, int qp, const uint16_t *tab)
+{
+    if (!c || !tab || qp < 0 || qp >= X265_HIP_MAX_QP)
+        return fail(X265_HIP_EINVAL, "costtab_upload: bad argument (qp %d)", qp);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->owned_tab[qp])
+        HIP_TRY(hipMalloc((void **)&c->owned_tab[qp], 65536 * sizeof(uint16_t)));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(c->owned_tab[qp], tab, 65536 * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->host_tabs.costtab[qp] = c->owned_tab[qp];
+    c->tabs_dirty = true;
+    return X265_HIP_OK;
+}
+
+// BitCost::setQP / CalculateLogs restated (encoder/bitcost.cpp:31-80; lambda table
+// Lib/TLibCommon/TComRom.cpp:127-143).  Host floating point, as in the reference: bits[i] =
+// log(i+1) * (2/ln2) + 1.718 evaluated in double (the reference's unqualified log() is the double
+// overload) and stored as float; cost = min(bits * lambda + 0.5, 65535) truncated to uint16.
+static const double k_lambda_tab[70] = {
+    0.2500, 0.2806, 0.3150, 0.3536, 0.3969, 0.4454, 0.5000, 0.5612, 0.6300, 0.7071,
+    0.7937, 0.8909, 1.0000, 1.1225, 1.2599, 1.4142, 1.5874, 1.7818, 2.0000, 2.2449,
+    2.5198, 2.8284, 3.1748, 3.5636, 4.0000, 4.4898, 5.0397, 5.6569, 6.3496, 7.1272,
+    8.0000, 8.9797, 10.0794, 11.3137, 12.6992, 14.2544, 16.0000, 17.9594, 20.1587, 22.6274,
+    25.3984, 28.5088, 32.0000, 35.9188, 40.3175, 45.2548, 50.7968, 57.0175, 64.0000, 71.8376,
+    80.6349, 90.5097, 101.5937, 114.0350, 128.0000, 143.6751, 161.2699, 181.0193, 203.1873, 228.0701,
+    256.0000, 287.3503, 322.5398, 362.0387, 406.3747, 456.1401, 512.0000, 574.7006, 645.0796, 724.0773
+};
+
+int x265_hip_costtab_build(int qp, uint16_t *tab)
+{
+    if (!tab || qp < 0 || qp >= 70)
+        return fail(X265_HIP_EINVAL, "costtab_build: qp %d outside the lambda table (0..69)", qp);
+    const float scale = (float)(2.0f / log((double)2.0f));
+    const double lambda = k_lambda_tab[qp];
+    for (int i = 0; i < 32768; i++)
+    {
+        const float bits = i ? (float)(log((double)(float)(i + 1)) * scale + 1.718f) : 0.718f;
+        const double v = bits * lambda + 0.5f;
+        const uint16_t c = (uint16_t)(v < 65535.0 ? v : 65535.0);
+        tab[32768 + i] = c;
+        tab[32768 - i] = c;
+    }
+    tab[0] = tab[1]; // difference -32768 is never written by the reference; defined here
+    return X265_HIP_OK;
+}
+
+int x265_hip_costtab_set_qp(x265_hip_ctx *c, int qp)
+{
+    if (!c)
+        return fail(X265_HIP_EINVAL, "null context");
+    std::vector<uint16_t> tab(65536);
+    int r = x265_hip_costtab_build(qp, tab.data());
+    if (r)
+        return r;
+    return x265_hip_costtab_upload(c, qp, tab.data());
+}
+
+// ---- validation of batched requests (host arrays only; device arrays are the caller's contract) --
+
+static int check_block(const x265_hip_ctx *c, int fp, int rp, int w, int h, const char *what, int i)
+{
+    if (fp < 0 || fp >= X265_HIP_MAX_PLANES || rp < 0 || rp >= X265_HIP_MAX_PLANES || !c->host_tabs.planes[fp].origin ||
+        !c->host_tabs.planes[rp].origin)
+        return fail(X265_HIP_EINVAL, "%s[%d]: plane %d or %d not uploaded", what, i, fp, rp);
+    if (x265_hip_partition_from_sizes(w, h) < 0)
+        return fail(X265_HIP_EINVAL, "%s[%d]: %dx%d is not a luma partition", what, i, w, h);
+    return 0;
+}
+
+static int check_jobs(const x265_hip_ctx *c, const x265_hip_me_job *jobs, int n)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const x265_hip_me_job &j = jobs[i];
+        int r = check_block(c, j.fenc_plane, j.ref_plane, j.pu_w, j.pu_h, "me_job", i);
+        if (r)
+            return r;
+        if (j.method > X265_HIP_FULL || j.subme > 7 || j.num_mvc > X265_HIP_MAX_MVC)
+            return fail(X265_HIP_EINVAL, "me_job[%d]: method %d / subme %d / num_mvc %d out of range", i, j.method, j.subme,
+                        j.num_mvc);
+        if (j.qp >= X265_HIP_MAX_QP || !c->host_tabs.costtab[j.qp])
+            return fail(X265_HIP_EINVAL, "me_job[%d]: no cost table uploaded for qp %d", i, j.qp);
+        if (j.mvmin_x > j.mvmax_x || j.mvmin_y > j.mvmax_y)
+            return fail(X265_HIP_EINVAL, "me_job[%d]: empty search range", i);
+    }
+    return 0;
+}
+
+// ---- batched entry points -----------------------------------------------------------------------
+
+int x265_hip_me_batch_device(x265_hip_ctx *c, const void *d_jobs, int n, void *d_results)
+{
+    if (!c || n < 0 || (n && (!d_jobs || !d_results)))
+        return fail(X265_HIP_EINVAL, "me_batch_device: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = push_tabs(c);
+    if (r)
+        return r;
+    launch_me(c->dev_tabs, (const x265_hip_me_job *)d_jobs, n, (x265_hip_me_result *)d_results, c->stream);
+    HIP_TRY(hipGetLastError());
+    return X265_HIP_OK;
+}
+
+int x265_hip_me_batch(x265_hip_ctx *c, const x265_hip_me_job *jobs, int n, x265_hip_me_result *results)
+{
+    if (!c || n < 0 || (n && (!jobs || !results)))
+        return fail(X265_HIP_EINVAL, "me_batch: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = check_jobs(c, jobs, n);
+    if (r || (r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*jobs))) ||
+        (r = ensure(c, c->out, (size_t)n * sizeof(*results))))
+        return r;
+    memcpy(c->in.h, jobs, (size_t)n * sizeof(*jobs));
+    HIP_TRY(hipMemcpyAsync(c->in.d, c->in.h, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
+    launch_me(c->dev_tabs, (const x265_hip_me_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(*results), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(results, c->out.h, (size_t)n * sizeof(*results));
+    return X265_HIP_OK;
+}
+
+int x265_hip_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void *d_costs)
+{
+    if (!c || n < 0 || (n && (!d_reqs || !d_costs)))
+        return fail(X265_HIP_EINVAL, "cost_batch_device: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = push_tabs(c);
+    if (r)
+        return r;
+    launch_cost(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, c->stream);
+    HIP_TRY(hipGetLastError());
+    return X265_HIP_OK;
+}
+
+int x265_hip_cost_batch(x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n, int32_t *costs)
+{
+    if (!c || n < 0 || (n && (!reqs || !costs)))
+        return fail(X265_HIP_EINVAL, "cost_batch: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++)
+    {
+        int r = check_block(c, reqs[i].fenc_plane, reqs[i].ref_plane, reqs[i].pu_w, reqs[i].pu_h, "cost_req", i);
+        if (r)
+            return r;
+        if (reqs[i].metric > X265_HIP_SATD)
+            return fail(X265_HIP_EINVAL, "cost_req[%d]: unknown metric %d", i, reqs[i].metric);
+    }
+    int r;
+    if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))) ||
+        (r = ensure(c, c->out, (size_t)n * sizeof(int32_t))))
+        return r;
+    memcpy(c->in.h, reqs, (size_t)n * sizeof(*reqs));
+    HIP_TRY(hipMemcpyAsync(c->in.d, c->in.h, (size_t)n * sizeof(*reqs), hipMemcpyHostToDevice, c->stream));
+    launch_cost(c->dev_tabs, (const x265_hip_cost_req *)c->in.d, n, (int32_t *)c->out.d, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(costs, c->out.h, (size_t)n * sizeof(int32_t));
+    return X265_HIP_OK;
+}
+
+int x265_hip_fullsearch_device(x265_hip_ctx *c, const void *d_jobs, int n, void *d_results)
+{
+    if (!c || n < 0 || (n && (!d_jobs || !d_results)))
+        return fail(X265_HIP_EINVAL, "fullsearch_device: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = push_tabs(c);
+    if (r)
+        return r;
+    launch_fullsearch(c->dev_tabs, (const x265_hip_ctu_job *)d_jobs, n, (x265_hip_me_result *)d_results, c->stream);
+    HIP_TRY(hipGetLastError());
+    return X265_HIP_OK;
+}
+
+int x265_hip_fullsearch(x265_hip_ctx *c, const x265_hip_ctu_job *jobs, int n, x265_hip_me_result *results)
+{
+    if (!c || n < 0 || (n && (!jobs || !results)))
+        return fail(X265_HIP_EINVAL, "fullsearch: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++)
+    {
+        const x265_hip_ctu_job &j = jobs[i];
+        int r = check_block(c, j.fenc_plane, j.ref_plane, 64, 64, "ctu_job", i);
+        if (r)
+            return r;
+        if (j.qp >= X265_HIP_MAX_QP || !c->host_tabs.costtab[j.qp])
+            return fail(X265_HIP_EINVAL, "ctu_job[%d]: no cost table uploaded for qp %d", i, j.qp);
+        if (j.mvmin_x > j.mvmax_x || j.mvmin_y > j.mvmax_y)
+            return fail(X265_HIP_EINVAL, "ctu_job[%d]: empty search range", i);
+        if (j.mvmax_x - j.mvmin_x > 131 || j.mvmax_y - j.mvmin_y > 131)
+            return fail(X265_HIP_ERANGE, "ctu_job[%d]: window wider than 132 positions", i);
+    }
+    const size_t ob = (size_t)n * X265_HIP_PUS_PER_CTU * sizeof(*results);
+    int r;
+    if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*jobs))) || (r = ensure(c, c->out, ob)))
+        return r;
+    memcpy(c->in.h, jobs, (size_t)n * sizeof(*jobs));
+    HIP_TRY(hipMemcpyAsync(c->in.d, c->in.h, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
+    launch_fullsearch(c->dev_tabs, (const x265_hip_ctu_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(results, c->out.h, ob);
+    return X265_HIP_OK;
+}
+
+} // extern "C"
+
+// =================================================================================================
+// primitive level: host-pointer thunks with the reference's signatures
+
+namespace {
+
+x265_hip_ctx *g_prim_ctx = nullptr;
+std::mutex g_prim_init_mu;
+
+struct HostPlane
+{
+    const uint8_t *base;
+    size_t bytes;
+    uint8_t *dev;
+};
+std::vector<HostPlane> g_host_planes;
+std::shared_mutex g_host_planes_mu;
+
+// device address serving host address p (+- the bytes a primitive may touch), or null
+const uint8_t *resolve(const uint8_t *p, long before, long after)
+{
+    std::shared_lock<std::shared_mutex> g(g_host_planes_mu);
+    for (const HostPlane &hp : g_host_planes)
+        if (p - before >= hp.base && p + after <= hp.base + hp.bytes)
+            return hp.dev + (p - hp.base);
+    return nullptr;
+}
+
+[[noreturn]] void prim_fatal(const char *what)
+{
+    // the reference's primitives have no error channel; a silent wrong cost would be worse than a stop
+    fprintf(stderr, "x265_hip primitive %s failed: %s\n", what, t_err);
+    abort();
+}
+
+// copy a w x rows region (elements of `es` bytes) starting `pre_cols` left and `pre_rows` above p
+// into packed staging; returns the packed stride in elements
+int pack_region(uint8_t *dst, const uint8_t *p, long stride, int es, int w, int rows, int pre_cols, int pre_rows)
+{
+    const uint8_t *s = p - ((long)pre_rows * stride + pre_cols) * es;
+    for (int y = 0; y < rows; y++)
+        memcpy(dst + (size_t)y * w * es, s + (long)y * stride * es, (size_t)w * es);
+    return w;
+}
+
+int prim_cmp(int part, int metric, const uint8_t *fenc, intptr_t fstride, const uint8_t *const *fref, int nref,
+             intptr_t rstride, int32_t *res)
+{
+    x265_hip_ctx *c = g_prim_ctx;
+    if (!c)
+        return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
+    const int w = k_part_w[part], h = k_part_h[part];
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t blk = (size_t)w * h;
+    int r;
+    if ((r = ensure(c, c->prim_a, 5 * blk + 64)) || (r = ensure(c, c->prim_b, 64)))
+        return r;
+    uint8_t *hs = (uint8_t *)c->prim_a.h, *ds = (uint8_t *)c->prim_a.d;
+    PrimCmpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.w = w;
+    a.h = h;
+    a.nref = nref;
+    a.metric = metric;
+    size_t used = 0;
+    pack_region(hs, fenc, fstride, 1, w, h, 0, 0);
+    a.fenc = ds;
+    a.fstride = w;
+    used = blk;
+    bool all_resolved = true;
+    const uint8_t *dev[4];
+    for (int i = 0; i < nref; i++)
+    {
+        dev[i] = resolve(fref[i], 0, (long)(h - 1) * rstride + w);
+        all_resolved = all_resolved && dev[i];
+    }
+    if (all_resolved)
+    {
+        for (int i = 0; i < nref; i++)
+            a.fref[i] = dev[i];
+        a.rstride = (int)rstride;
+    }
+    else
+    {
+        for (int i = 0; i < nref; i++)
+        {
+            pack_region(hs + used, fref[i], rstride, 1, w, h, 0, 0);
+            a.fref[i] = ds + used;
+            used += blk;
+        }
+        a.rstride = w;
+    }
+    HIP_TRY(hipMemcpyAsync(ds, hs, used, hipMemcpyHostToDevice, c->stream));
+    launch_prim_cmp(a, (int32_t *)c->prim_b.d, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->prim_b.h, c->prim_b.d, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(res, c->prim_b.h, nref * sizeof(int32_t));
+    return 0;
+}
+
+// kind: PRIM_HPP / PRIM_VPP / PRIM_HPS / PRIM_VSP.  Writes exactly w x rows elements of dst.
+int prim_filter(int part, int kind, const void *src, intptr_t sstride, void *dst, intptr_t dstride, int coeff, int row_ext)
+{
+    x265_hip_ctx *c = g_prim_ctx;
+    if (!c)
+        return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
+    if (coeff < 0 || coeff > 3)
+        return fail(X265_HIP_EINVAL, "coeffIdx %d out of range", coeff);
+    const int w = k_part_w[part];
+    int rows = k_part_h[part];
+    const int ses = kind == PRIM_VSP ? 2 : 1, des = kind == PRIM_HPS ? 2 : 1;
+    const uint8_t *sp = (const uint8_t *)src;
+    if (kind == PRIM_HPS && row_ext)
+    {
+        sp -= 3 * sstride * ses; // luma_hps with isRowExt starts three rows up (ipfilter.cpp:128-132)
+        rows += 7;
+    }
+    const bool horiz = kind == PRIM_HPP || kind == PRIM_HPS;
+    const int pre_c = horiz ? 3 : 0, post_c = horiz ? 4 : 0, pre_r = horiz ? 0 : 3, post_r = horiz ? 0 : 4;
+    const int sw = w + pre_c + post_c, sr = rows + pre_r + post_r;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    const size_t sbytes = (size_t)sw * sr * ses, dbytes = (size_t)w * rows * des;
+    if ((r = ensure(c, c->prim_a, sbytes + 64)) || (r = ensure(c, c->prim_b, dbytes + 64)))
+        return r;
+    PrimFilterArgs a;
+    a.kind = kind;
+    a.coeff = coeff;
+    a.w = w;
+    a.rows = rows;
+    a.dst = c->prim_b.d;
+    a.dstride = w;
+    const uint8_t *dev = ses == 1 ? resolve(sp, (long)pre_r * sstride + pre_c, (long)(rows - 1 + post_r) * sstride + w + post_c)
+                                  : nullptr;
+    if (dev)
+    {
+        a.src = dev;
+        a.sstride = (int)sstride;
+    }
+    else
+    {
+        pack_region((uint8_t *)c->prim_a.h, sp, sstride, ses, sw, sr, pre_c, pre_r);
+        HIP_TRY(hipMemcpyAsync(c->prim_a.d, c->prim_a.h, sbytes, hipMemcpyHostToDevice, c->stream));
+        a.src = (const uint8_t *)c->prim_a.d + ((size_t)pre_r * sw + pre_c) * ses;
+        a.sstride = sw;
+    }
+    launch_prim_filter(a, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->prim_b.h, c->prim_b.d, dbytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int y = 0; y < rows; y++)
+        memcpy((uint8_t *)dst + (size_t)y * dstride * des, (uint8_t *)c->prim_b.h + (size_t)y * w * des, (size_t)w * des);
+    return 0;
+}
+
+template <int P>
+int t_sad(uint8_t *fenc, intptr_t fs, uint8_t *fref, intptr_t rs)
+{
+    int32_t res[4];
+    const uint8_t *r[1] = { fref };
+    if (prim_cmp(P, X265_HIP_SAD, fenc, fs, r, 1, rs, res))
+        prim_fatal("sad");
+    return res[0];
+}
+
+template <int P>
+int t_satd(uint8_t *fenc, intptr_t fs, uint8_t *fref, intptr_t rs)
+{
+    int32_t res[4];
+    const uint8_t *r[1] = { fref };
+    if (prim_cmp(P, X265_HIP_SATD, fenc, fs, r, 1, rs, res))
+        prim_fatal("satd");
+    return res[0];
+}
+
+template <int P>
+void t_sad_x3(uint8_t *fenc, uint8_t *r0, uint8_t *r1, uint8_t *r2, intptr_t rs, int32_t *res)
+{
+    const uint8_t *r[3] = { r0, r1, r2 };
+    if (prim_cmp(P, X265_HIP_SAD, fenc, X265_HIP_FENC_STRIDE, r, 3, rs, res))
+        prim_fatal("sad_x3");
+}
+
+template <int P>
+void t_sad_x4(uint8_t *fenc, uint8_t *r0, uint8_t *r1, uint8_t *r2, uint8_t *r3, intptr_t rs, int32_t *res)
+{
+    const uint8_t *r[4] = { r0, r1, r2, r3 };
+    if (prim_cmp(P, X265_HIP_SAD, fenc, X265_HIP_FENC_STRIDE, r, 4, rs, res))
+        prim_fatal("sad_x4");
+}
+
+template <int P>
+void t_hpp(uint8_t *src, intptr_t ss, uint8_t *dst, intptr_t ds, int coeff)
+{
+    if (prim_filter(P, PRIM_HPP, src, ss, dst, ds, coeff, 0))
+        prim_fatal("luma_hpp");
+}
+
+template <int P>
+void t_vpp(uint8_t *src, intptr_t ss, uint8_t *dst, intptr_t ds, int coeff)
+{
+    if (prim_filter(P, PRIM_VPP, src, ss, dst, ds, coeff, 0))
+        prim_fatal("luma_vpp");
+}
+
+template <int P>
+void t_hps(uint8_t *src, intptr_t ss, int16_t *dst, intptr_t ds, int coeff, int ext)
+{
+    if (prim_filter(P, PRIM_HPS, src, ss, dst, ds, coeff, ext))
+        prim_fatal("luma_hps");
+}
+
+template <int P>
+void t_vsp(int16_t *src, intptr_t ss, uint8_t *dst, intptr_t ds, int coeff)
+{
+    if (prim_filter(P, PRIM_VSP, src, ss, dst, ds, coeff, 0))
+        prim_fatal("luma_vsp");
+}
+
+template <int P>
+void fill(x265_hip_primitives *t)
+{
+    t->sad[P] = t_sad<P>;
+    t->sad_x3[P] = t_sad_x3<P>;
+    t->sad_x4[P] = t_sad_x4<P>;
+    t->satd[P] = t_satd<P>;
+    t->luma_hpp[P] = t_hpp<P>;
+    t->luma_hps[P] = t_hps<P>;
+    t->luma_vpp[P] = t_vpp<P>;
+    t->luma_vsp[P] = t_vsp<P>;
+    if constexpr (P + 1 < X265_HIP_NUM_LUMA_PARTITIONS)
+        fill<P + 1>(t);
+}
+
+} // namespace
+
+extern "C" {
+
+int x265_hip_setup_primitives(x265_hip_primitives *table, int device)
+{
+    if (!table)
+        return fail(X265_HIP_EINVAL, "null table");
+    std::lock_guard<std::mutex> g(g_prim_init_mu);
+    if (!g_prim_ctx)
+    {
+        x265_hip_ctx *c = nullptr;
+        int r = x265_hip_ctx_create(device, &c);
+        if (r)
+            return r;
+        g_prim_ctx = c;
+    }
+    fill<0>(table);
+    return X265_HIP_OK;
+}
+
+int x265_hip_register_host_plane(const uint8_t *host_base, size_t bytes)
+{
+    x265_hip_ctx *c = g_prim_ctx;
+    if (!c)
+        return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
+    if (!host_base || !bytes)
+        return fail(X265_HIP_EINVAL, "register_host_plane: bad argument");
+    uint8_t *dev = nullptr;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipMalloc((void **)&dev, bytes + 64));
+        HIP_TRY(hipMemcpy(dev, host_base, bytes, hipMemcpyHostToDevice));
+    }
+    std::unique_lock<std::shared_mutex> g(g_host_planes_mu);
+    g_host_planes.push_back({ host_base, bytes, dev });
+    return X265_HIP_OK;
+}
+
+int x265_hip_unregister_host_plane(const uint8_t *host_base)
+{
+    x265_hip_ctx *c = g_prim_ctx;
+    if (!c)
+        return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
+    uint8_t *dev = nullptr;
+    {
+        std::unique_lock<std::shared_mutex> g(g_host_planes_mu);
+        for (size_t i = 0; i < g_host_planes.size(); i++)
+            if (g_host_planes[i].base == host_base)
+            {
+                dev = g_host_planes[i].dev;
+                g_host_planes.erase(g_host_planes.begin() + i);
+                break;
+            }
+    }
+    if (!dev)
+        return fail(X265_HIP_EINVAL, "unregister_host_plane: not registered");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(dev));
+    return X265_HIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,40 @@
+// kernels.h -- host-visible launchers of the kernels in kernels.hip
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/x265_hip.h"
+
+namespace x265hip {
+
+struct DeviceTables;
+
+enum { PRIM_HPP = 0, PRIM_VPP = 1, PRIM_HPS = 2, PRIM_VSP = 3 };
+
+struct PrimCmpArgs
+{
+    const uint8_t *fenc;
+    const uint8_t *fref[4];
+    int fstride, rstride;
+    int w, h, nref, metric;
+};
+
+struct PrimFilterArgs
+{
+    const void *src; // uint8 for hpp/vpp/hps, int16 for vsp; points at output sample (0,0)'s source
+    void *dst;       // uint8 for hpp/vpp/vsp, int16 for hps
+    int sstride, dstride; // in elements
+    int w, rows, coeff, kind;
+};
+
+void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st);
+void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, hipStream_t st);
+void launch_prim_cmp(const PrimCmpArgs &a, int32_t *out, hipStream_t st);
+void launch_prim_filter(const PrimFilterArgs &a, hipStream_t st);
+void launch_fullsearch(const DeviceTables *tabs, const x265_hip_ctu_job *jobs, int n, x265_hip_me_result *out,
+                       hipStream_t st);
+int fullsearch_setup();
+size_t fullsearch_lds_bytes();
+
+} // namespace x265hip

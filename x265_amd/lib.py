@@ -1,0 +1,169 @@
+"""ctypes binding of libx265_hip.so (the C ABI in include/x265_hip.h).
+
+Host-side plumbing only: arrays go in and come out as numpy; device-resident entry points take raw
+device addresses (e.g. ``torch.Tensor.data_ptr()``).  There is no fallback: if the shared library is
+missing or no gfx950 device is present, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .abi import COST_REQ, ME_JOB, ME_RESULT, NUM_PARTS
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libx265_hip.so")
+
+CTU_JOB = np.dtype([
+    ("fenc_plane", "<i4"), ("ref_plane", "<i4"),
+    ("ctu_x", "<i2"), ("ctu_y", "<i2"),
+    ("mvmin_x", "<i2"), ("mvmin_y", "<i2"), ("mvmax_x", "<i2"), ("mvmax_y", "<i2"),
+    ("qmvp_x", "<i2"), ("qmvp_y", "<i2"),
+    ("qp", "u1"), ("pad", "u1", (3,)),
+])
+assert CTU_JOB.itemsize == 28
+PUS_PER_CTU = 85
+
+EXPORTS = [
+    "x265_hip_device_count", "x265_hip_ctx_create", "x265_hip_ctx_destroy", "x265_hip_last_error",
+    "x265_hip_ctx_stream", "x265_hip_ctx_sync", "x265_hip_setup_primitives", "x265_hip_partition_from_sizes",
+    "x265_hip_register_host_plane", "x265_hip_unregister_host_plane", "x265_hip_plane_upload",
+    "x265_hip_plane_bind", "x265_hip_plane_release", "x265_hip_costtab_upload", "x265_hip_cost_batch",
+    "x265_hip_me_batch", "x265_hip_me_batch_device", "x265_hip_cost_batch_device", "x265_hip_fullsearch",
+    "x265_hip_fullsearch_device", "x265_hip_costtab_build", "x265_hip_costtab_set_qp",
+]
+
+
+class X265HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise X265HipError(f"{LIB_PATH} is missing: build it with `make -C x265_amd/csrc` "
+                               "(or __graft_entry__.build()); there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.x265_hip_last_error.restype = C.c_char_p
+        _lib.x265_hip_ctx_stream.restype = C.c_void_p
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise X265HipError(f"x265_hip error {rc}: {load().x265_hip_last_error().decode()}")
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Primitives(C.Structure):
+    """x265_hip_primitives: the function-pointer table with the reference's signatures."""
+    _cmp = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t)
+    _x3 = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p)
+    _x4 = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p)
+    _pp = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int)
+    _hps = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int)
+    _fields_ = [
+        ("sad", _cmp * NUM_PARTS), ("sad_x3", _x3 * NUM_PARTS), ("sad_x4", _x4 * NUM_PARTS),
+        ("satd", _cmp * NUM_PARTS), ("luma_hpp", _pp * NUM_PARTS), ("luma_hps", _hps * NUM_PARTS),
+        ("luma_vpp", _pp * NUM_PARTS), ("luma_vsp", _pp * NUM_PARTS),
+    ]
+
+
+def setup_primitives(device=0):
+    t = Primitives()
+    _check(load().x265_hip_setup_primitives(C.byref(t), C.c_int(device)))
+    return t
+
+
+def costtab_build(qp):
+    """BitCost::setQP's table for qp (host computation inside the library)."""
+    out = np.zeros(65536, np.uint16)
+    _check(load().x265_hip_costtab_build(C.c_int(qp), _p(out)))
+    return out
+
+
+def device_count():
+    return load().x265_hip_device_count()
+
+
+class Context:
+    """x265_hip_ctx: one device, one stream, planes and cost tables resident in HBM."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(load().x265_hip_ctx_create(C.c_int(device), C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            load().x265_hip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return load().x265_hip_ctx_stream(self._h)
+
+    def sync(self):
+        _check(load().x265_hip_ctx_sync(self._h))
+
+    def plane_upload(self, plane_id, buf, stride, origin):
+        buf = np.ascontiguousarray(buf, np.uint8)
+        _check(load().x265_hip_plane_upload(self._h, C.c_int(plane_id), _p(buf), C.c_size_t(buf.size), C.c_int(stride),
+                                            C.c_int(origin)))
+
+    def plane_bind(self, plane_id, dev_ptr, nbytes, stride, origin):
+        _check(load().x265_hip_plane_bind(self._h, C.c_int(plane_id), C.c_void_p(dev_ptr), C.c_size_t(nbytes),
+                                          C.c_int(stride), C.c_int(origin)))
+
+    def plane_release(self, plane_id):
+        _check(load().x265_hip_plane_release(self._h, C.c_int(plane_id)))
+
+    def costtab_upload(self, qp, tab):
+        tab = np.ascontiguousarray(tab, np.uint16)
+        assert tab.size == 65536
+        _check(load().x265_hip_costtab_upload(self._h, C.c_int(qp), _p(tab)))
+
+    def set_qp(self, qp):
+        _check(load().x265_hip_costtab_set_qp(self._h, C.c_int(qp)))
+
+    def cost_batch(self, reqs):
+        reqs = np.ascontiguousarray(reqs, COST_REQ)
+        out = np.zeros(len(reqs), np.int32)
+        _check(load().x265_hip_cost_batch(self._h, _p(reqs), C.c_int(len(reqs)), _p(out)))
+        return out
+
+    def me_batch(self, jobs):
+        jobs = np.ascontiguousarray(jobs, ME_JOB)
+        out = np.zeros(len(jobs), ME_RESULT)
+        _check(load().x265_hip_me_batch(self._h, _p(jobs), C.c_int(len(jobs)), _p(out)))
+        return out
+
+    def fullsearch(self, jobs):
+        jobs = np.ascontiguousarray(jobs, CTU_JOB)
+        out = np.zeros(len(jobs) * PUS_PER_CTU, ME_RESULT)
+        _check(load().x265_hip_fullsearch(self._h, _p(jobs), C.c_int(len(jobs)), _p(out)))
+        return out.reshape(len(jobs), PUS_PER_CTU)
+
+    # device-resident variants: raw device addresses, asynchronous on self.stream
+    def me_batch_device(self, d_jobs, n, d_results):
+        _check(load().x265_hip_me_batch_device(self._h, C.c_void_p(d_jobs), C.c_int(n), C.c_void_p(d_results)))
+
+    def cost_batch_device(self, d_reqs, n, d_costs):
+        _check(load().x265_hip_cost_batch_device(self._h, C.c_void_p(d_reqs), C.c_int(n), C.c_void_p(d_costs)))
+
+    def fullsearch_device(self, d_jobs, n, d_results):
+        _check(load().x265_hip_fullsearch_device(self._h, C.c_void_p(d_jobs), C.c_int(n), C.c_void_p(d_results)))
