@@ -155,7 +155,7 @@ int x265_hip_ctx_create(int device, x265_hip_ctx **out)
         delete c;
         return fail(X265_HIP_ERUNTIME, "context setup: %s", hipGetErrorString(e));
     }
-    if (fullsearch_setup() != 0)
+    if (fullsearch_setup() != 0 || fullsearch2_setup() != 0)
     {
         delete c;
         return fail(X265_HIP_ERUNTIME, "fullsearch kernel attribute setup failed");
@@ -447,7 +447,7 @@ int x265_hip_fullsearch_device(x265_hip_ctx *c, const void *d_jobs, int n, void 
     int r = push_tabs(c);
     if (r)
         return r;
-    launch_fullsearch(c->dev_tabs, (const x265_hip_ctu_job *)d_jobs, n, (x265_hip_me_result *)d_results, c->stream);
+    launch_fullsearch2(c->dev_tabs, (const x265_hip_ctu_job *)d_jobs, n, (x265_hip_me_result *)d_results, c->stream);
     HIP_TRY(hipGetLastError());
     return X265_HIP_OK;
 }
@@ -479,7 +479,7 @@ int x265_hip_fullsearch(x265_hip_ctx *c, const x265_hip_ctu_job *jobs, int n, x2
         return r;
     memcpy(c->in.h, jobs, (size_t)n * sizeof(*jobs));
     HIP_TRY(hipMemcpyAsync(c->in.d, c->in.h, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
-    launch_fullsearch(c->dev_tabs, (const x265_hip_ctu_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, c->stream);
+    launch_fullsearch2(c->dev_tabs, (const x265_hip_ctu_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

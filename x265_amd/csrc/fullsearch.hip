@@ -1,0 +1,344 @@
+// fullsearch.hip -- exhaustive integer-pel search of one 64x64 CTU per workgroup (gfx950, wave64).
+//
+// Reproduces, for each of the CTU's 85 square PUs, the integer stage of motionEstimate with
+// X265_FULL_SEARCH (reference encoder/motion.cpp:997-1032): raster order over [mvmin, mvmax],
+// cost = sad + mvcost(mv << 2), strict-less update, i.e. the first minimum in raster order.
+//
+// Structure
+//   * The (64+nx-1) x (64+ny-1) reference window and the source CTU are staged in LDS once.
+//   * A lane owns one 16x16 block (its four 8x8 blocks) and four adjacent x positions.  Its 16x16
+//     source pixels stay in 64 VGPRs.  Walking down the window one row per step, every new row of
+//     reference bytes (five aligned dwords per block row) feeds v_qsad_pk_u16_u8: one instruction =
+//     four SADs of 4 pixels at four consecutive x positions, accumulated as 4 x u16.  Eight
+//     positions (y .. y+7) are in flight per lane in a rotating set of accumulators; one completes
+//     per step.
+//   * A wave's 16-lane DPP row holds the 16 blocks of one x group, so 32x32 and 64x64 sums are two
+//     quad_perm and two row_ror additions; 16x16 sums are plain 32-bit adds of the packed pairs
+//     (16x16 SAD <= 65280, no carry between halves).
+//   * Per PU and x position a lane keeps min((cost << 8) | y); ascending y and the packed y make the
+//     first minimum win.  At the end (cost, y, x) keys meet in LDS through 64-bit atomic minima.
+//   * x positions beyond a multiple of four (the 129th column of a +-64 window) go through a small
+//     tail pass that evaluates one position per thread with v_sad_u8.
+#include "kernels.h"
+#include "me_device.h"
+
+namespace x265hip {
+
+#define FS_MAXPOS 132
+#define FS_WS 200 // window row pitch in bytes (>= 64 + 132 - 1 + 3, multiple of 4)
+#define FS_WROWS (64 + FS_MAXPOS - 1 + 8)
+#define FS_THREADS 512
+
+struct Fs2Lds
+{
+    uint8_t win[FS_WROWS * FS_WS];
+    uint8_t fenc[64 * 64];
+    unsigned long long best[X265_HIP_PUS_PER_CTU]; // (cost << 16) | (y << 8) | x
+    unsigned pass_best[X265_HIP_PUS_PER_CTU];
+    unsigned cy[FS_MAXPOS];
+};
+
+__device__ __forceinline__ int fs_s16(int v) { return (int)(int16_t)v; }
+
+// (half of `packed`) * 256 + add in one instruction
+template <int HI>
+__device__ __forceinline__ unsigned mad16_256(unsigned packed, unsigned add)
+{
+    unsigned r;
+    if (HI)
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(packed), "s"(256u), "v"(add));
+    else
+        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(packed), "s"(256u), "v"(add));
+    return r;
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_add(unsigned v)
+{
+    return v + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ unsigned fs_wave_min_u32(unsigned v)
+{
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0xB1, 0xf, 0xf, false));  // quad_perm 1,0,3,2
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xf, 0xf, false));  // quad_perm 2,3,0,1
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x141, 0xf, 0xf, false)); // row_half_mirror
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x140, 0xf, 0xf, false)); // row_mirror
+    unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+    unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+__device__ __forceinline__ unsigned long long u64min(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
+
+__global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTables *tabs, const x265_hip_ctu_job *jobs,
+                                                                 int n, x265_hip_me_result *out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Fs2Lds &L = *(Fs2Lds *)smem;
+    const int id = blockIdx.x;
+    if (id >= n)
+        return;
+    const x265_hip_ctu_job j = jobs[id];
+    const int tid = threadIdx.x;
+    const PlaneDesc fp = tabs->planes[j.fenc_plane], rp = tabs->planes[j.ref_plane];
+    const uint16_t *tab = tabs->costtab[j.qp];
+    const int nx = j.mvmax_x - j.mvmin_x + 1, ny = j.mvmax_y - j.mvmin_y + 1;
+    const int ww = 64 + nx - 1, wh = 64 + ny - 1;
+
+    // ---- stage source CTU, reference window, per-row cost, result keys --------------------------
+    {
+        const uint8_t *fsrc = fp.origin + (long)j.ctu_y * fp.stride + j.ctu_x;
+        for (int i = tid; i < 64 * 16; i += FS_THREADS)
+        {
+            int y = i >> 4, x = i & 15;
+            *(uint32_t *)(L.fenc + y * 64 + 4 * x) = ld4u(fsrc + (long)y * fp.stride + 4 * x);
+        }
+        const uint8_t *rsrc = rp.origin + (long)(j.ctu_y + j.mvmin_y) * rp.stride + j.ctu_x + j.mvmin_x;
+        const int wdw = (ww + 3) >> 2;
+        for (int i = tid; i < wh * wdw; i += FS_THREADS)
+        {
+            int y = i / wdw, x = i - y * wdw;
+            *(uint32_t *)(L.win + y * FS_WS + 4 * x) = ld4u(rsrc + (long)y * rp.stride + 4 * x);
+        }
+        if (tid < ny)
+            L.cy[tid] = tab_at(tab, j.qmvp_y, fs_s16((j.mvmin_y + tid) << 2));
+        if (tid < X265_HIP_PUS_PER_CTU)
+        {
+            L.best[tid] = ~0ull;
+            L.pass_best[tid] = 0xffffffffu;
+        }
+    }
+    __syncthreads();
+
+    // ---- main pass: x positions [0, 4G) --------------------------------------------------------
+    const int G = min(32, nx >> 2);
+    if (G > 0)
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int q = lane & 15;                 // 16x16 block, z-order: bits 3:2 = 32x32 quadrant
+        const int g = wave * 4 + (lane >> 4);    // x group
+        const bool active = g < G;
+        const int gc = active ? g : G - 1;
+        const int q32 = q >> 2, sub = q & 3;
+        const int bx16 = (q32 & 1) * 32 + (sub & 1) * 16, by16 = (q32 >> 1) * 32 + (sub >> 1) * 16;
+
+        uint32_t f[16][4];
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+        {
+            const uint4 v = *(const uint4 *)(L.fenc + (by16 + r) * 64 + bx16);
+            f[r][0] = v.x;
+            f[r][1] = v.y;
+            f[r][2] = v.z;
+            f[r][3] = v.w;
+        }
+        unsigned cx[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            cx[i] = tab_at(tab, j.qmvp_x, fs_s16((j.mvmin_x + 4 * gc + i) << 2));
+
+        unsigned best8[4][4], best16[4], best32[4], best64[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            best16[i] = best32[i] = best64[i] = 0xffffffffu;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                best8[b][i] = 0xffffffffu;
+        }
+
+        uint64_t acc[8][4]; // [slot][TL, TR, BL, BR], 4 x u16 each
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                acc[k][b] = 0;
+
+        const uint32_t *wtop = (const uint32_t *)(L.win + by16 * FS_WS + bx16 + 4 * gc);
+        const int S = ny + 7;
+        for (int s0 = 0; s0 < S; s0 += 8)
+        {
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++)
+            {
+                const int s = s0 + jj;
+                const uint32_t *pt = wtop + s * (FS_WS / 4);
+                const uint32_t *pb = pt + 8 * (FS_WS / 4);
+                const uint32_t t0 = pt[0], t1 = pt[1], t2 = pt[2], t3 = pt[3], t4 = pt[4];
+                const uint32_t b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3], b4 = pb[4];
+                const uint64_t t01 = ((uint64_t)t1 << 32) | t0, t12 = ((uint64_t)t2 << 32) | t1;
+                const uint64_t t23 = ((uint64_t)t3 << 32) | t2, t34 = ((uint64_t)t4 << 32) | t3;
+                const uint64_t b01 = ((uint64_t)b1 << 32) | b0, b12 = ((uint64_t)b2 << 32) | b1;
+                const uint64_t b23 = ((uint64_t)b3 << 32) | b2, b34 = ((uint64_t)b4 << 32) | b3;
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                {
+                    const int k = (jj - i) & 7; // position y = s - i lives in slot y & 7
+                    // a position's first source row (i == 0) restarts its accumulators
+                    const uint64_t z0 = i ? acc[k][0] : 0, z1 = i ? acc[k][1] : 0;
+                    const uint64_t z2 = i ? acc[k][2] : 0, z3 = i ? acc[k][3] : 0;
+                    acc[k][0] = __builtin_amdgcn_qsad_pk_u16_u8(t12, f[i][1], __builtin_amdgcn_qsad_pk_u16_u8(t01, f[i][0], z0));
+                    acc[k][1] = __builtin_amdgcn_qsad_pk_u16_u8(t34, f[i][3], __builtin_amdgcn_qsad_pk_u16_u8(t23, f[i][2], z1));
+                    acc[k][2] = __builtin_amdgcn_qsad_pk_u16_u8(b12, f[8 + i][1], __builtin_amdgcn_qsad_pk_u16_u8(b01, f[8 + i][0], z2));
+                    acc[k][3] = __builtin_amdgcn_qsad_pk_u16_u8(b34, f[8 + i][3], __builtin_amdgcn_qsad_pk_u16_u8(b23, f[8 + i][2], z3));
+                }
+                // position y = s - 7 is complete in slot (jj + 1) & 7
+                const int y = s - 7;
+                if (y >= 0 && y < ny)
+                {
+                    const int k = (jj + 1) & 7;
+                    const unsigned cyv = L.cy[y];
+                    unsigned kmv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        kmv[i] = (((cx[i] + cyv) & 0xffffu) << 8) | (unsigned)y; // mvcost() wraps at 16 bits
+                    unsigned lo[4], hi[4];
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                    {
+                        lo[b] = (unsigned)acc[k][b];
+                        hi[b] = (unsigned)(acc[k][b] >> 32);
+                        best8[b][0] = min(best8[b][0], mad16_256<0>(lo[b], kmv[0]));
+                        best8[b][1] = min(best8[b][1], mad16_256<1>(lo[b], kmv[1]));
+                        best8[b][2] = min(best8[b][2], mad16_256<0>(hi[b], kmv[2]));
+                        best8[b][3] = min(best8[b][3], mad16_256<1>(hi[b], kmv[3]));
+                    }
+                    // 16x16: the packed pairs add without carry (4 * 16320 < 65536)
+                    const unsigned slo = lo[0] + lo[1] + lo[2] + lo[3], shi = hi[0] + hi[1] + hi[2] + hi[3];
+                    best16[0] = min(best16[0], mad16_256<0>(slo, kmv[0]));
+                    best16[1] = min(best16[1], mad16_256<1>(slo, kmv[1]));
+                    best16[2] = min(best16[2], mad16_256<0>(shi, kmv[2]));
+                    best16[3] = min(best16[3], mad16_256<1>(shi, kmv[3]));
+                    unsigned v[4] = { slo & 0xffffu, slo >> 16, shi & 0xffffu, shi >> 16 };
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                    {
+                        unsigned s32 = dpp_add<0x4E>(dpp_add<0xB1>(v[i]));     // 4 lanes of a quad = one 32x32
+                        best32[i] = min(best32[i], (s32 << 8) + kmv[i]);
+                        unsigned s64 = dpp_add<0x128>(dpp_add<0x124>(s32));    // row_ror 4, 8: the four quads
+                        best64[i] = min(best64[i], (s64 << 8) + kmv[i]);
+                    }
+                }
+            }
+        }
+
+        if (active)
+        {
+            // fold the four x positions (lowest x wins ties), then meet the other lanes in LDS
+            auto fold = [&](const unsigned *b4) {
+                unsigned long long r = ~0ull;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    r = u64min(r, ((unsigned long long)b4[i] << 8) | (unsigned)(4 * g + i));
+                return r;
+            };
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+            {
+                const int x8 = bx16 + (b & 1) * 8, y8 = by16 + (b >> 1) * 8;
+                atomicMin(&L.best[21 + (y8 >> 3) * 8 + (x8 >> 3)], fold(best8[b]));
+            }
+            atomicMin(&L.best[5 + (by16 >> 4) * 4 + (bx16 >> 4)], fold(best16));
+            if (sub == 0)
+                atomicMin(&L.best[1 + q32], fold(best32));
+            if (q == 0)
+                atomicMin(&L.best[0], fold(best64));
+        }
+    }
+    __syncthreads();
+
+    // ---- tail pass: x positions [4G, nx), one position per thread, raster order = thread order --
+    const int ntail = nx - 4 * G;
+    const int total = ntail * ny;
+    for (int base = 0; base < total; base += FS_THREADS)
+    {
+        const int idx = base + tid;
+        const bool live = idx < total;
+        const int py = live ? idx / ntail : 0, px = live ? 4 * G + (idx - py * ntail) : 0;
+        int mvc = 0;
+        if (live)
+            mvc = mvcost_q(tab, j.qmvp_x, j.qmvp_y, fs_s16((j.mvmin_x + px) << 2), fs_s16((j.mvmin_y + py) << 2));
+        const uint8_t *wbase = L.win + py * FS_WS + px;
+        unsigned s64 = 0;
+        for (int q32 = 0; q32 < 4; q32++)
+        {
+            unsigned s32 = 0;
+            for (int q16 = 0; q16 < 4; q16++)
+            {
+                unsigned s16sum = 0;
+                const int x16 = (q32 & 1) * 32 + (q16 & 1) * 16, y16 = (q32 >> 1) * 32 + (q16 >> 1) * 16;
+#pragma unroll
+                for (int q8 = 0; q8 < 4; q8++)
+                {
+                    const int x8 = x16 + (q8 & 1) * 8, y8 = y16 + (q8 >> 1) * 8;
+                    unsigned s8 = 0;
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+                    {
+                        const uint2 fv = *(const uint2 *)(L.fenc + (y8 + r) * 64 + x8);
+                        const uint8_t *w = wbase + (y8 + r) * FS_WS + x8;
+                        s8 = __builtin_amdgcn_sad_u8(fv.x, ld4u(w), s8);
+                        s8 = __builtin_amdgcn_sad_u8(fv.y, ld4u(w + 4), s8);
+                    }
+                    s16sum += s8;
+                    unsigned key = fs_wave_min_u32(live ? ((s8 + mvc) << 9) | tid : 0xffffffffu);
+                    if ((tid & 63) == 0)
+                        atomicMin(&L.pass_best[21 + (y8 >> 3) * 8 + (x8 >> 3)], key);
+                }
+                s32 += s16sum;
+                unsigned key = fs_wave_min_u32(live ? ((s16sum + mvc) << 9) | tid : 0xffffffffu);
+                if ((tid & 63) == 0)
+                    atomicMin(&L.pass_best[5 + (y16 >> 4) * 4 + (x16 >> 4)], key);
+            }
+            s64 += s32;
+            unsigned key = fs_wave_min_u32(live ? ((s32 + mvc) << 9) | tid : 0xffffffffu);
+            if ((tid & 63) == 0)
+                atomicMin(&L.pass_best[1 + q32], key);
+        }
+        {
+            unsigned key = fs_wave_min_u32(live ? ((s64 + mvc) << 9) | tid : 0xffffffffu);
+            if ((tid & 63) == 0)
+                atomicMin(&L.pass_best[0], key);
+        }
+        __syncthreads();
+        if (tid < X265_HIP_PUS_PER_CTU)
+        {
+            const unsigned k = L.pass_best[tid];
+            if (k != 0xffffffffu)
+            {
+                const int widx = base + (int)(k & 511);
+                const int wy = widx / ntail, wx = 4 * G + (widx - wy * ntail);
+                const unsigned long long key64 = ((unsigned long long)(k >> 9) << 16) | ((unsigned)wy << 8) | (unsigned)wx;
+                L.best[tid] = u64min(L.best[tid], key64);
+            }
+            L.pass_best[tid] = 0xffffffffu;
+        }
+        __syncthreads();
+    }
+
+    if (tid < X265_HIP_PUS_PER_CTU)
+    {
+        const unsigned long long k = L.best[tid];
+        x265_hip_me_result r;
+        r.cost = (int)(k >> 16);
+        r.mvx = (int16_t)((j.mvmin_x + (int)(k & 255)) << 2);
+        r.mvy = (int16_t)((j.mvmin_y + (int)((k >> 8) & 255)) << 2);
+        out[(long)id * X265_HIP_PUS_PER_CTU + tid] = r;
+    }
+}
+
+int fullsearch2_setup()
+{
+    return (int)hipFuncSetAttribute((const void *)fullsearch2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sizeof(Fs2Lds));
+}
+
+void launch_fullsearch2(const DeviceTables *tabs, const x265_hip_ctu_job *jobs, int n, x265_hip_me_result *out,
+                        hipStream_t st)
+{
+    if (n > 0)
+        hipLaunchKernelGGL(fullsearch2_kernel, dim3(n), dim3(FS_THREADS), sizeof(Fs2Lds), st, tabs, jobs, n, out);
+}
+
+} // namespace x265hip
