@@ -50,7 +50,7 @@ PARTS = [(4, 4), (8, 8), (8, 4), (4, 8), (16, 16), (16, 8), (8, 16), (16, 12), (
 
 
 def _ptr(a, off=0):
-    return C.c_void_p(a.ctypes.data + off)
+    return C.c_void_p(a.ctypes.data + int(off))
 
 
 class Checker:

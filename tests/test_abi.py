@@ -1,0 +1,80 @@
+"""CPU tests of the C-ABI library and host logic: it loads, exports every declared symbol, and the
+host-side pieces that need no GPU behave (no compute call is made here)."""
+import os
+import re
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from x265_amd import lib
+    text = open(os.path.join(ROOT, "include", "x265_hip.h")).read()
+    declared = set(re.findall(r"\b(x265_hip_[a-z0-9_]+)\s*\(", text))
+    declared = {d for d in declared if not d.endswith("_t")}
+    assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    handle = lib.load()
+    for name in declared:
+        assert getattr(handle, name) is not None
+
+
+def test_struct_layouts_match_header():
+    from x265_amd import abi, lib
+    assert abi.ME_JOB.itemsize == 80 and abi.ME_RESULT.itemsize == 8 and abi.COST_REQ.itemsize == 20
+    assert lib.CTU_JOB.itemsize == 28
+    assert abi.ME_JOB.fields["mvc"][1] == 32 and abi.ME_JOB.fields["qp"][1] == 30
+
+
+def test_partition_from_sizes():
+    from x265_amd import abi, lib
+    h = lib.load()
+    for p, (w, hh) in enumerate(abi.PARTS):
+        assert h.x265_hip_partition_from_sizes(w, hh) == p
+    for bad in ((12, 12), (0, 0), (64, 8), (128, 128)):
+        assert h.x265_hip_partition_from_sizes(*bad) == -1
+
+
+def test_costtab_build_matches_reference_fixture():
+    from x265_amd import lib
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bitcost.npz"))
+    for q in range(70):
+        t = lib.costtab_build(q)
+        assert zlib.crc32(t.tobytes()) == int(g["crc"][q]), q
+    with pytest.raises(lib.X265HipError):
+        lib.costtab_build(70)
+
+
+def test_no_gpu_means_error_not_fallback():
+    """without a gfx950 device the library refuses to create a context (no CPU path behind it)"""
+    from x265_amd import lib
+    if lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(lib.X265HipError):
+        lib.Context(0)
+    with pytest.raises(lib.X265HipError):
+        lib.setup_primitives(0)
+
+
+def test_product_does_not_import_oracle():
+    """nothing under x265_amd/ or include/ may reference the checker"""
+    for base in ("x265_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "oracle" not in text.lower(), (dirpath, f)
+
+
+def test_synth_search_range_matches_reference_rule():
+    """xSetSearchRange / clipMv restated in x265_amd.synth (TEncSearch.cpp:2600-2617, TComDataCU.cpp:2502-2514)"""
+    from x265_amd import synth
+    # interior CTU: window is predictor +- merange
+    assert tuple(int(v) for v in synth.search_range(np.int64(12), np.int64(-8), 57, 640, 320, 1920, 1080)) == (-54, -59, 60, 55)
+    # top-left CTU: clipped at -(64 + 8) + 1 = -71
+    lox, loy, hix, hiy = (int(v) for v in synth.search_range(np.int64(0), np.int64(0), 57, 0, 0, 1920, 1080))
+    assert (lox, loy, hix, hiy) == (-57, -57, 57, 57)
+    lox, loy, hix, hiy = (int(v) for v in synth.search_range(np.int64(-200), np.int64(0), 64, 0, 0, 1920, 1080))
+    assert lox == -71 and hix == 14

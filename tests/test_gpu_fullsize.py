@@ -1,0 +1,149 @@
+"""GPU tests at BASELINE.json's full sizes (1080p whole pictures, 4K samples): exact comparison with the
+oracle where it finishes in seconds, and size-independent properties for everything else."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THREADS = 16
+
+
+@pytest.fixture(scope="module")
+def hd():
+    from x265_amd import lib, synth
+    seq = synth.Sequence(1920, 1080, seed=0x265)
+    planes = [synth.Plane(seq.frame(i)) for i in range(4)]
+    ctx = lib.Context(0)
+    for i, p in enumerate(planes):
+        ctx.plane_upload(i, p.buf, p.stride, p.origin)
+    for q in range(28, 40):
+        ctx.set_qp(q)
+    yield seq, planes, ctx
+    ctx.close()
+
+
+def test_me_stage_whole_1080p_frame_three_refs(hd, oracle):
+    """every motionEstimate call of a medium-preset ME stage (HEX, subme 2, merange 57), 3 references"""
+    from x265_amd import abi, lib, synth
+    seq, planes, ctx = hd
+    refs = [2, 1, 0]
+    jobs = synth.me_jobs(1920, 1080, 3, refs, [seq.global_motion(3, r) for r in refs], method=abi.HEX, subme=2, merange=57)
+    assert len(jobs) == 3 * 42900
+    got = ctx.me_batch(jobs)
+    tabs = {q: lib.costtab_build(q) for q in range(28, 40)}
+    want = oracle.me_batch([p.as_tuple() for p in planes], tabs, jobs, nthreads=THREADS)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, (len(bad), jobs[bad[0]], got[bad[0]], want[bad[0]])
+    # the search finds the synthetic motion for most background blocks
+    dx, dy = seq.global_motion(3, 2)
+    n = len(jobs) // 3
+    hit = (np.abs(got["mvx"][:n] - 4 * dx) <= 4) & (np.abs(got["mvy"][:n] - 4 * dy) <= 4)
+    assert hit.mean() > 0.5
+
+
+@pytest.mark.parametrize("method,subme", [(0, 1), (2, 5), (3, 3), (2, 7)])
+def test_me_other_presets_1080p_sample(hd, oracle, method, subme):
+    from x265_amd import lib, synth
+    seq, planes, ctx = hd
+    jobs = synth.me_jobs(1920, 1080, 3, [2], [seq.global_motion(3, 2)], method=method, subme=subme, merange=57, seed=method)
+    jobs = jobs[::7][:4000].copy()
+    got = ctx.me_batch(jobs)
+    tabs = {q: lib.costtab_build(q) for q in range(28, 40)}
+    want = oracle.me_batch([p.as_tuple() for p in planes], tabs, jobs, nthreads=THREADS)
+    assert np.array_equal(got, want)
+
+
+def test_fullsearch_whole_1080p_frame(hd, oracle):
+    import sys
+    sys.path.insert(0, ".")
+    from bench import build_ctu_jobs
+    from x265_amd import abi, lib
+    seq, planes, ctx = hd
+    jobs = build_ctu_jobs(seq, 3, 2, 3, 2, qp=30)
+    assert len(jobs) == 510
+    res = ctx.fullsearch(jobs)
+    tab = lib.costtab_build(30)
+    pl = [p.as_tuple() for p in planes]
+    # (a) exact against the oracle on CTUs from the corners, the edges and the interior
+    for k in (0, 29, 15 * 30 + 14, 16 * 30, 509, 7 * 30 + 3):
+        j = jobs[k]
+        want = oracle.ctu_fullsearch(pl[3], pl[2], tab, int(j["ctu_x"]), int(j["ctu_y"]), (int(j["mvmin_x"]), int(j["mvmin_y"])),
+                                     (int(j["mvmax_x"]), int(j["mvmax_y"])), (int(j["qmvp_x"]), int(j["qmvp_y"])))
+        bad = np.nonzero(res[k] != want)[0]
+        assert len(bad) == 0, (k, bad[0], res[k][bad[0]], want[bad[0]])
+    # (b) every one of the 43,350 results is self-consistent: cost == SAD(at the returned mv) + mvcost,
+    #     the mv lies inside the window, and no better cost exists at the window centre
+    pus = []
+    for lvl in range(4):
+        s, n = 64 >> lvl, 1 << lvl
+        for by in range(n):
+            for bx in range(n):
+                pus.append((bx * s, by * s, s))
+    pus = np.array(pus)
+    reqs = np.zeros(510 * 85, abi.COST_REQ)
+    reqs["fenc_plane"], reqs["ref_plane"] = 3, 2
+    reqs["pu_x"] = (jobs["ctu_x"][:, None] + pus[None, :, 0]).reshape(-1)
+    reqs["pu_y"] = (jobs["ctu_y"][:, None] + pus[None, :, 1]).reshape(-1)
+    reqs["pu_w"] = reqs["pu_h"] = np.tile(pus[:, 2], 510)
+    reqs["qmv_x"], reqs["qmv_y"] = res["mvx"].reshape(-1), res["mvy"].reshape(-1)
+    sad = ctx.cost_batch(reqs).astype(np.int64)
+    mvpx, mvpy = np.repeat(jobs["qmvp_x"].astype(np.int64), 85), np.repeat(jobs["qmvp_y"].astype(np.int64), 85)
+    mvc = (tab[(reqs["qmv_x"] - mvpx + 32768) & 0xffff].astype(np.int64) + tab[(reqs["qmv_y"] - mvpy + 32768) & 0xffff]) & 0xffff
+    assert np.array_equal(sad + mvc, res["cost"].reshape(-1))
+    fx, fy = res["mvx"] >> 2, res["mvy"] >> 2
+    assert (fx >= jobs["mvmin_x"][:, None]).all() and (fx <= jobs["mvmax_x"][:, None]).all()
+    assert (fy >= jobs["mvmin_y"][:, None]).all() and (fy <= jobs["mvmax_y"][:, None]).all()
+    reqs["qmv_x"], reqs["qmv_y"] = mvpx, mvpy  # the predictor (window centre) is a candidate: cannot beat the winner
+    centre = ctx.cost_batch(reqs).astype(np.int64) + (2 * int(tab[32768]) & 0xffff)
+    assert (res["cost"].reshape(-1) <= centre).all()
+
+
+def test_cost_batch_large_random(hd, oracle):
+    from x265_amd import abi
+    seq, planes, ctx = hd
+    rng = np.random.default_rng(31)
+    n = 60000
+    reqs = np.zeros(n, abi.COST_REQ)
+    parts = rng.integers(1, 25, n)
+    wh = np.array(abi.PARTS)[parts]
+    reqs["pu_w"], reqs["pu_h"] = wh[:, 0], wh[:, 1]
+    reqs["pu_x"] = (rng.random(n) * (1920 - wh[:, 0])).astype(int)
+    reqs["pu_y"] = (rng.random(n) * (1080 - wh[:, 1])).astype(int)
+    reqs["fenc_plane"], reqs["ref_plane"] = 3, rng.integers(0, 3, n)
+    reqs["metric"] = rng.integers(0, 2, n)
+    reqs["qmv_x"], reqs["qmv_y"] = rng.integers(-240, 240, n), rng.integers(-240, 240, n)
+    got = ctx.cost_batch(reqs)
+    want = oracle.cost_batch([p.as_tuple() for p in planes], reqs, nthreads=THREADS)
+    assert np.array_equal(got, want)
+
+
+def test_4k_sample(oracle):
+    """3840x2160: coordinates beyond 2048 and the 4032-byte stride; sample of ME calls and CTUs vs the oracle"""
+    from x265_amd import abi, lib, synth
+    seq = synth.Sequence(3840, 2160, seed=0x4B)
+    planes = [synth.Plane(seq.frame(i)) for i in range(2)]
+    assert planes[0].stride == 4032 and planes[0].rows == 2336
+    ctx = lib.Context(0)
+    for i, p in enumerate(planes):
+        ctx.plane_upload(i, p.buf, p.stride, p.origin)
+    for q in range(28, 40):
+        ctx.set_qp(q)
+    jobs = synth.me_jobs(3840, 2160, 1, [0], [seq.global_motion(1, 0)], method=abi.HEX, subme=2, merange=57)
+    assert len(jobs) > 170000
+    sample = jobs[::23].copy()
+    got = ctx.me_batch(sample)
+    tabs = {q: lib.costtab_build(q) for q in range(28, 40)}
+    pl = [p.as_tuple() for p in planes]
+    assert np.array_equal(got, oracle.me_batch(pl, tabs, sample, nthreads=THREADS))
+    cj = np.zeros(2, lib.CTU_JOB)
+    for j, (x, y) in zip(cj, ((3776, 2112), (1984, 1024))):
+        j["fenc_plane"], j["ref_plane"], j["ctu_x"], j["ctu_y"], j["qp"] = 1, 0, x, y, 33
+        j["mvmin_x"], j["mvmin_y"], j["mvmax_x"], j["mvmax_y"] = -64, -64, 64, 64
+        j["qmvp_x"], j["qmvp_y"] = 5, -7
+    res = ctx.fullsearch(cj)
+    for k, j in enumerate(cj):
+        want = oracle.ctu_fullsearch(pl[1], pl[0], tabs[33], int(j["ctu_x"]), int(j["ctu_y"]), (-64, -64), (64, 64), (5, -7))
+        # (3776, 2112) is in the partial bottom CTU row (2160 = 33.75 CTUs): PUs that leave the picture read
+        # the edge-extended margin on both sides and still match
+        assert np.array_equal(res[k], want)
+    ctx.close()

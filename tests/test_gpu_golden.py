@@ -1,0 +1,119 @@
+"""GPU tests against the committed reference fixtures (no oracle involved): the HIP path through the
+C ABI must reproduce what the real reference produced."""
+import os
+
+import numpy as np
+import pytest
+
+from test_oracle_golden import GOLD, check_prims, golden_planes
+
+pytestmark = pytest.mark.gpu
+
+
+class TableAdapter:
+    """presents the x265_hip_primitives function-pointer table with the checker's call interface"""
+
+    def __init__(self, t):
+        self.t = t
+
+    @staticmethod
+    def _a(buf, off=0):
+        import ctypes as C
+        return C.c_void_p(buf.ctypes.data + int(off))
+
+    def sad(self, part, a, fo, fs, b, ro, rs):
+        return self.t.sad[part](self._a(a, fo), fs, self._a(b, ro), rs)
+
+    def satd(self, part, a, fo, fs, b, ro, rs):
+        return self.t.satd[part](self._a(a, fo), fs, self._a(b, ro), rs)
+
+    def sad_x3(self, part, a, fo, b, ro, rs):
+        res = np.zeros(3, np.int32)
+        self.t.sad_x3[part](self._a(a, fo), self._a(b, ro[0]), self._a(b, ro[1]), self._a(b, ro[2]), rs, self._a(res))
+        return res
+
+    def sad_x4(self, part, a, fo, b, ro, rs):
+        res = np.zeros(4, np.int32)
+        self.t.sad_x4[part](self._a(a, fo), self._a(b, ro[0]), self._a(b, ro[1]), self._a(b, ro[2]), self._a(b, ro[3]),
+                            rs, self._a(res))
+        return res
+
+    def luma_hpp(self, part, src, so, ss, dst, do, ds, c):
+        self.t.luma_hpp[part](self._a(src, so), ss, self._a(dst, do), ds, c)
+
+    def luma_vpp(self, part, src, so, ss, dst, do, ds, c):
+        self.t.luma_vpp[part](self._a(src, so), ss, self._a(dst, do), ds, c)
+
+    def luma_hps(self, part, src, so, ss, dst, do, ds, c, ext):
+        self.t.luma_hps[part](self._a(src, so), ss, self._a(dst, 2 * do), ds, c, ext)
+
+    def luma_vsp(self, part, src, so, ss, dst, do, ds, c):
+        self.t.luma_vsp[part](self._a(src, 2 * so), ss, self._a(dst, do), ds, c)
+
+
+def test_primitive_table_reproduces_reference_fixtures():
+    from x265_amd import lib
+    check_prims(TableAdapter(lib.setup_primitives(0)), np.load(os.path.join(GOLD, "prims.npz")))
+
+
+def test_registered_host_plane_gives_same_answers():
+    """fref inside a registered host plane is served from its device copy"""
+    import ctypes as C
+    from x265_amd import lib
+    t = lib.setup_primitives(0)
+    g = np.load(os.path.join(GOLD, "prims.npz"))
+    b = np.ascontiguousarray(g["bufs"][0])
+    a = np.ascontiguousarray(g["bufs"][2])
+    h = lib.load()
+    assert h.x265_hip_register_host_plane(C.c_void_p(b.ctypes.data), C.c_size_t(b.size)) == 0
+    try:
+        ad = TableAdapter(t)
+        for k, (part, ia, ib, ro) in enumerate(g["cases"]):
+            if ia == 2 and ib == 0:
+                assert ad.sad(int(part), a, 0, 64, b, int(ro), 59) == g["sad"][k, 1]
+                assert ad.satd(int(part), a, 0, 64, b, int(ro), 64) == g["satd"][k, 0]
+    finally:
+        assert h.x265_hip_unregister_host_plane(C.c_void_p(b.ctypes.data)) == 0
+
+
+def test_motion_estimate_reproduces_reference_fixtures():
+    from x265_amd import lib
+    g = np.load(os.path.join(GOLD, "me.npz"))
+    ctx = lib.Context(0)
+    for i, p in enumerate(golden_planes()):
+        ctx.plane_upload(i, p.buf, p.stride, p.origin)
+    for q in range(20, 45):
+        ctx.set_qp(q)
+    got = ctx.me_batch(g["jobs"])
+    want = g["results"].view(got.dtype)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, (g["jobs"][bad[0]], got[bad[0]], want[bad[0]])
+    cj = np.zeros(len(g["ctu_cfg"]), lib.CTU_JOB)
+    for j, c in zip(cj, g["ctu_cfg"]):
+        j["fenc_plane"], j["ref_plane"] = 1, 0
+        (j["ctu_x"], j["ctu_y"], j["mvmin_x"], j["mvmin_y"], j["mvmax_x"], j["mvmax_y"], j["qmvp_x"], j["qmvp_y"],
+         j["qp"]) = [int(v) for v in c]
+    fs = ctx.fullsearch(cj)
+    assert np.array_equal(fs, g["ctu_res"].view(fs.dtype))
+    ctx.close()
+
+
+def test_bad_arguments_are_rejected(gpu_ctx):
+    from x265_amd import abi, lib
+    jobs = np.zeros(1, abi.ME_JOB)
+    jobs["fenc_plane"], jobs["ref_plane"], jobs["pu_w"], jobs["pu_h"], jobs["qp"] = 1, 0, 12, 12, 30
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.me_batch(jobs)  # 12x12 is not a partition
+    jobs["pu_w"] = jobs["pu_h"] = 16
+    jobs["ref_plane"] = 40
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.me_batch(jobs)  # plane never uploaded
+    jobs["ref_plane"] = 0
+    jobs["qp"] = 5
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.me_batch(jobs)  # no table for this qp
+    cj = np.zeros(1, lib.CTU_JOB)
+    cj["fenc_plane"], cj["ref_plane"], cj["qp"], cj["mvmax_x"], cj["mvmax_y"] = 1, 0, 30, 200, 3
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.fullsearch(cj)  # window wider than 132 positions
+    assert len(gpu_ctx.me_batch(np.zeros(0, abi.ME_JOB))) == 0  # empty batch is fine

@@ -1,0 +1,122 @@
+"""CPU tests: the oracle restatement against fixtures generated from the real reference
+(tests/golden/*.npz, made by oracle/gen_golden.py from oracle/_ref/libx265ref.so)."""
+import os
+import zlib
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).view(np.uint8).tobytes())
+
+
+def check_prims(impl, g):
+    """impl: object with the pyoracle.Checker primitive interface"""
+    bufs = g["bufs"]
+    for k, (part, ia, ib, ro) in enumerate(g["cases"]):
+        part, ro = int(part), int(ro)
+        a, b = bufs[ia], bufs[ib]
+        for si, rs in enumerate((64, 59)):
+            assert impl.sad(part, a, 0, 64, b, ro, rs) == g["sad"][k, si]
+            assert impl.satd(part, a, 0, 64, b, ro, rs) == g["satd"][k, si]
+        assert np.array_equal(impl.sad_x3(part, a, 0, b, [ro, ro + 1, ro + 2], 59), g["x3"][k])
+        assert np.array_equal(impl.sad_x4(part, a, 0, b, [ro, ro + 1, ro + 2, ro + 3], 59), g["x4"][k])
+    src, s16 = g["src"], g["s16"]
+    for (part, coeff, ss, ds), want in zip(g["fcases"], g["fcrc"]):
+        part, coeff, ss, ds = int(part), int(coeff), int(ss), int(ds)
+        so = 6 * ss + 6
+        got = []
+        for name in ("luma_hpp", "luma_vpp"):
+            d = np.full(200 * 200, 0x5A, np.uint8)
+            getattr(impl, name)(part, src, so, ss, d, 0, ds, coeff)
+            got.append(crc(d))
+        for ext in (0, 1):
+            d = np.full(200 * 200, 0x5A5A, np.int16)
+            impl.luma_hps(part, src, so, ss, d, 0, ds, coeff, ext)
+            got.append(crc(d))
+        d = np.full(200 * 200, 0x5A, np.uint8)
+        impl.luma_vsp(part, s16, so, ss, d, 0, ds, coeff)
+        got.append(crc(d))
+        assert got == [int(v) for v in want], (part, coeff)
+
+
+def golden_planes():
+    from x265_amd import synth
+    seq = synth.Sequence(416, 240, seed=7, n_patches=3)
+    return [synth.Plane(seq.frame(i)) for i in range(3)]
+
+
+def test_primitives_match_reference_fixtures(oracle):
+    check_prims(oracle, np.load(os.path.join(GOLD, "prims.npz")))
+
+
+def test_extremes_from_survey(oracle):
+    """known answers recorded from the reference in SURVEY.md appendix B"""
+    z, f = np.zeros(64 * 64, np.uint8), np.full(64 * 64, 255, np.uint8)
+    assert oracle.sad(18, z, 0, 64, f, 0, 64) == 1044480
+    assert oracle.satd(18, z, 0, 64, f, 0, 64) == 522240
+    t = oracle.bitcost_table(30)
+
+    def mvcost(x, y):
+        return (int(t[32768 + x]) + int(t[32768 + y])) & 0xffff
+    assert (mvcost(0, 0), mvcost(4, 0), mvcost(-4, 0), mvcost(100, -37), mvcost(32767, 32767)) == (12, 57, 57, 218, 508)
+
+
+def test_partition_table(oracle):
+    from oracle import pyoracle
+    for p, (w, h) in enumerate(pyoracle.PARTS):
+        assert oracle.partition_from_sizes(w, h) == p
+    assert oracle.partition_from_sizes(12, 12) == -1
+
+
+def test_bitcost_tables(oracle):
+    g = np.load(os.path.join(GOLD, "bitcost.npz"))
+    for q in range(70):
+        t = oracle.bitcost_table(q)
+        assert crc(t) == int(g["crc"][q]), q
+        assert np.array_equal(t[32768 + g["probes"]], g["vals"][q])
+        assert np.array_equal(t[32768 - g["probes"]], g["vals"][q])  # symmetric in the sign of the difference
+
+
+def test_synthetic_generator_is_pinned():
+    g = np.load(os.path.join(GOLD, "me.npz"))
+    assert [crc(p.buf) for p in golden_planes()] == [int(v) for v in g["plane_crc"]]
+
+
+def test_motion_estimate_matches_reference_fixtures(oracle):
+    g = np.load(os.path.join(GOLD, "me.npz"))
+    planes = [p.as_tuple() for p in golden_planes()]
+    tabs = {q: oracle.bitcost_table(q) for q in range(20, 45)}
+    got = oracle.me_batch(planes, tabs, g["jobs"])
+    want = g["results"].view(got.dtype)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, (g["jobs"][bad[0]], got[bad[0]], want[bad[0]])
+    # the threaded driver gives the same answers
+    assert np.array_equal(oracle.me_batch(planes, tabs, g["jobs"], nthreads=4), got)
+
+
+def test_ctu_fullsearch_matches_reference_fixtures(oracle):
+    g = np.load(os.path.join(GOLD, "me.npz"))
+    planes = [p.as_tuple() for p in golden_planes()]
+    for c, want in zip(g["ctu_cfg"], g["ctu_res"]):
+        c = [int(v) for v in c]
+        got = oracle.ctu_fullsearch(planes[1], planes[0], oracle.bitcost_table(c[8]), c[0], c[1], (c[2], c[3]),
+                                    (c[4], c[5]), (c[6], c[7]))
+        assert np.array_equal(got, want.view(got.dtype))
+
+
+def test_ctu_fullsearch_cost_is_sad_plus_mvcost(oracle):
+    """the per-CTU search result re-derived from an explicit cost request (composition rule in DESIGN.md)"""
+    from oracle import pyoracle
+    planes = [p.as_tuple() for p in golden_planes()]
+    tab = oracle.bitcost_table(30)
+    res = oracle.ctu_fullsearch(planes[1], planes[0], tab, 64, 64, (-6, -6), (6, 6), (0, 0))
+    req = np.zeros(1, pyoracle.COST_REQ)
+    r = req[0]
+    r["fenc_plane"], r["ref_plane"], r["pu_x"], r["pu_y"], r["pu_w"], r["pu_h"] = 1, 0, 64, 64, 64, 64
+    r["qmv_x"], r["qmv_y"] = res[0]["mvx"], res[0]["mvy"]
+    sad = int(oracle.cost_batch(planes, req)[0])
+    mvc = (int(tab[32768 + int(res[0]["mvx"])]) + int(tab[32768 + int(res[0]["mvy"])])) & 0xffff
+    assert sad + mvc == int(res[0]["cost"])

@@ -1,0 +1,64 @@
+"""CPU differential test: oracle restatement vs the real reference build, random inputs.
+Skipped where oracle/_ref/libx265ref.so is absent (it is built only where /root/reference exists)."""
+import numpy as np
+import pytest
+
+from conftest import random_me_jobs
+from oracle import pyoracle
+
+pytestmark = pytest.mark.skipif(not pyoracle.have_ref(), reason="reference build not present")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return pyoracle.load_ref()
+
+
+def test_pixelcmp_random(oracle, ref):
+    rng = np.random.default_rng(1)
+    n = 64 * 200 + 4000
+    bufs = [rng.integers(0, 256, n, dtype=np.uint8), np.zeros(n, np.uint8), np.full(n, 255, np.uint8)]
+    for part in range(25):
+        for _ in range(12):
+            a, b = bufs[rng.integers(3)], bufs[rng.integers(3)]
+            fo, ro = int(rng.integers(0, 16)) * 16, int(rng.integers(0, 3000))
+            for rs in (64, 59, 100):
+                assert oracle.sad(part, a, fo, 64, b, ro, rs) == ref.sad(part, a, fo, 64, b, ro, rs)
+                assert oracle.satd(part, a, fo, 64, b, ro, rs) == ref.satd(part, a, fo, 64, b, ro, rs)
+                assert np.array_equal(oracle.sad_x4(part, a, fo, b, [ro, ro + 1, ro + 2, ro + 3], rs),
+                                      ref.sad_x4(part, a, fo, b, [ro, ro + 1, ro + 2, ro + 3], rs))
+
+
+def test_bitcost_all_qp(oracle, ref):
+    for q in range(70):
+        assert np.array_equal(oracle.bitcost_table(q), ref.bitcost_table(q))
+
+
+@pytest.mark.parametrize("method", range(5))
+def test_motion_estimate_random(oracle, ref, small_seq, costtabs, method):
+    from x265_amd import synth
+    rng = np.random.default_rng(40 + method)
+    planes = [p.as_tuple() for p in small_seq]
+    W, H = small_seq[0].w, small_seq[0].h
+    for subme in range(8):
+        n, mer = (150, (4, 8, 16, 57)) if method != 4 else (8, (3, 6))
+        jobs = random_me_jobs(rng, n, method, subme, W, H, pyoracle.ME_JOB, synth.search_range, pyoracle.PARTS, meranges=mer)
+        a, b = oracle.me_batch(planes, costtabs, jobs), ref.me_batch(planes, costtabs, jobs)
+        assert np.array_equal(a, b), (method, subme)
+
+
+def test_motion_estimate_flat_and_extreme_content(oracle, ref):
+    """ties everywhere (flat pictures) and saturated differences exercise the tie-break order"""
+    from x265_amd import synth
+    rng = np.random.default_rng(9)
+    W, H = 192, 128
+    pics = [np.zeros((H, W), np.uint8), np.full((H, W), 255, np.uint8), np.zeros((H, W), np.uint8)]
+    pics[2][::2, ::2] = 255
+    planes = [synth.Plane(p) for p in pics]
+    pl = [p.as_tuple() for p in planes]
+    tabs = {q: oracle.bitcost_table(q) for q in range(20, 45)}
+    for method in range(4):
+        for fenc, refp in ((0, 0), (0, 1), (2, 0), (2, 2)):
+            jobs = random_me_jobs(rng, 60, method, int(rng.integers(0, 8)), W, H, pyoracle.ME_JOB, synth.search_range,
+                                  pyoracle.PARTS, planes=(fenc, (refp,)))
+            assert np.array_equal(oracle.me_batch(pl, tabs, jobs), ref.me_batch(pl, tabs, jobs))
