@@ -35,6 +35,8 @@ struct Wave
     int mvpx, mvpy;
     int lane;
     int nq;
+    // after q_eval: lane k holds candidate k's cost / position / aux word
+    int vc, vx, vy, va;
 };
 
 __device__ __forceinline__ void wave_init(Wave &wv, WaveLds *s, int w, int h)
@@ -61,41 +63,74 @@ __device__ __forceinline__ void load_fenc(Wave &wv, const uint8_t *src, int sstr
     wave_sync();
 }
 
+// how q_eval seeds a candidate's cost with its motion-vector rate
+enum { MV_NONE = 0,  // distortion only
+       MV_COST = 1,  // BitCost::mvcost(): sum of the two entries truncated to uint16 (bitcost.h:45)
+       MV_RAW = 2 }; // plain int sum of the two entries (UMH hexagon grid, motion.cpp:832)
+
 // queue values are wave-uniform: every lane stores the same word
-__device__ __forceinline__ void q_push(Wave &wv, int qx, int qy, int aux = 0)
+__device__ __forceinline__ void q_push(Wave &wv, int qx, int qy, int mvmode, int aux = 0)
 {
     wv.s->qx[wv.nq] = qx;
     wv.s->qy[wv.nq] = qy;
-    wv.s->aux[wv.nq] = aux;
+    wv.s->aux[wv.nq] = (aux << 2) | mvmode;
     wv.nq++;
 }
 
-// Evaluate every queued candidate: cost[c] = SAD or SATD of the PU against the reference at the
-// candidate's quarter-pel position (subpelCompare + cmp, motion.cpp:1126-1164).  Work items are
-// (candidate, 4x4 tile) pairs dealt round-robin to the lanes; partial sums meet in LDS.
-__device__ __noinline__ void q_eval(Wave &wv, int metric)
+// Evaluate every queued candidate: cost[c] = mv rate (per its mode) + SAD or SATD of the PU against
+// the reference at the candidate's quarter-pel position (subpelCompare + cmp, motion.cpp:1126-1164).
+// Work items are (candidate, 4x4 tile) pairs dealt round-robin to the lanes; partial sums meet in
+// LDS.  Out of line and by value on purpose: there are ~25 call sites, and arguments by value keep
+// the caller's search state in registers.
+__device__ __noinline__ int q_eval_core(WaveLds *s, const uint8_t *ref, int stride, int ntx, int nt, const uint16_t *tab,
+                                        int mvpx, int mvpy, int nq, int metric)
 {
-    if (wv.lane < QMAX)
-        wv.s->cost[wv.lane] = 0;
-    wave_sync();
-    const int total = wv.nq * wv.nt;
-    for (int i = wv.lane; i < total; i += 64)
+    const int lane = threadIdx.x & 63;
+    // lane c fetches candidate c's mv rate; the table reads stay in flight under the pixel work
+    int seed = 0;
+    if (lane < nq)
     {
-        int c = i / wv.nt, t = i - c * wv.nt;
-        int ty = t / wv.ntx, tx = t - ty * wv.ntx;
-        int qx = wv.s->qx[c], qy = wv.s->qy[c];
+        const int mode = s->aux[lane] & 3;
+        if (mode != MV_NONE)
+        {
+            const int a = tab_at(tab, mvpx, s->qx[lane]), b = tab_at(tab, mvpy, s->qy[lane]);
+            seed = mode == MV_COST ? (int)(uint16_t)(a + b) : a + b;
+        }
+    }
+    if (lane < QMAX)
+        s->cost[lane] = 0;
+    wave_sync();
+    const int total = nq * nt;
+    // i / nt and t / ntx by reciprocal: exact for i < 4096, nt <= 256 (error 4e-4 << 0.5 / nt)
+    const float inv_nt = 1.0f / (float)nt, inv_ntx = 1.0f / (float)ntx;
+    for (int i = lane; i < total; i += 64)
+    {
+        const int c = (int)(((float)i + 0.5f) * inv_nt), t = i - c * nt;
+        const int ty = (int)(((float)t + 0.5f) * inv_ntx), tx = t - ty * ntx;
+        const int qx = s->qx[c], qy = s->qy[c];
         int pix[4][4];
-        ref_tile(wv.ref + ((qy >> 2) + 4 * ty) * wv.stride + (qx >> 2) + 4 * tx, wv.stride, qx & 3, qy & 3, pix);
-        int v = tile_metric(wv.s->fenc + ty * 4 * 64 + tx * 4, 64, pix, metric);
-        atomicAdd(&wv.s->cost[c], v);
+        ref_tile(ref + ((qy >> 2) + 4 * ty) * stride + (qx >> 2) + 4 * tx, stride, qx & 3, qy & 3, pix);
+        const int v = tile_metric(s->fenc + ty * 4 * 64 + tx * 4, 64, pix, metric);
+        atomicAdd(&s->cost[c], v);
     }
     wave_sync();
+    return lane < nq ? s->cost[lane] + seed : 0x7fffffff;
 }
 
-__device__ __forceinline__ int q_cost(const Wave &wv, int k) { return uniform(wv.s->cost[k]); }
-__device__ __forceinline__ int q_x(const Wave &wv, int k) { return uniform(wv.s->qx[k]); }
-__device__ __forceinline__ int q_y(const Wave &wv, int k) { return uniform(wv.s->qy[k]); }
-__device__ __forceinline__ int q_aux(const Wave &wv, int k) { return uniform(wv.s->aux[k]); }
+__device__ __forceinline__ void q_eval(Wave &wv, int metric)
+{
+    wv.vc = q_eval_core(wv.s, wv.ref, wv.stride, wv.ntx, wv.nt, wv.tab, wv.mvpx, wv.mvpy, wv.nq, metric);
+    const int l = wv.lane & (QMAX - 1);
+    wv.vx = wv.s->qx[l];
+    wv.vy = wv.s->qy[l];
+    wv.va = wv.s->aux[l];
+}
+
+// k is wave-uniform at every call site
+__device__ __forceinline__ int q_cost(const Wave &wv, int k) { return __builtin_amdgcn_readlane(wv.vc, k); }
+__device__ __forceinline__ int q_x(const Wave &wv, int k) { return __builtin_amdgcn_readlane(wv.vx, k); }
+__device__ __forceinline__ int q_y(const Wave &wv, int k) { return __builtin_amdgcn_readlane(wv.vy, k); }
+__device__ __forceinline__ int q_aux(const Wave &wv, int k) { return __builtin_amdgcn_readlane(wv.va, k) >> 2; }
 
 __device__ __forceinline__ int s16(int v) { return (int)(int16_t)v; }
 
@@ -128,20 +163,21 @@ __device__ __forceinline__ bool in_range(const Srch &s, int x, int y)
 // queue a full-pel point; aux carries (point << 16) | dist for the STAR pattern
 __device__ __forceinline__ void push_f(Wave &wv, int mx, int my, int point = 0, int dist = 0)
 {
-    q_push(wv, s16(mx) * 4, s16(my) * 4, (point << 16) | dist);
+    // mvcost(mv << 2): the shift is an int16 operation in the reference (mv.h:63)
+    q_push(wv, s16(s16(mx) << 2), s16(s16(my) << 2), MV_COST, (point << 16) | dist);
 }
 
 // Evaluate the queued full-pel points with SAD + mvcost and apply the strict-less updates in push
 // order (COST_MV / COST_MV_X4 / COST_MV_PT_DIST*, motion.cpp:165-235).  Empties the queue.
 template <bool STAR>
-__device__ __noinline__ void flush_f(Wave &wv, Srch &s)
+__device__ __forceinline__ void flush_f(Wave &wv, Srch &s)
 {
     if (wv.nq)
         q_eval(wv, X265_HIP_SAD);
     for (int k = 0; k < wv.nq; k++)
     {
         int mx = q_x(wv, k) >> 2, my = q_y(wv, k) >> 2;
-        int cost = q_cost(wv, k) + mvc_f(wv, mx, my);
+        int cost = q_cost(wv, k);
         if (cost < s.bcost)
         {
             s.bcost = cost;
@@ -158,12 +194,11 @@ __device__ __noinline__ void flush_f(Wave &wv, Srch &s)
     wv.nq = 0;
 }
 
-// push with automatic flush when the queue is full (order of updates is preserved)
+// queue one full-pel point; callers flush before the queue (QMAX entries) can overflow
 template <bool STAR>
 __device__ __forceinline__ void try_f(Wave &wv, Srch &s, int mx, int my, int point = 0, int dist = 0)
 {
-    if (wv.nq == QMAX)
-        flush_f<STAR>(wv, s);
+    (void)s;
     push_f(wv, mx, my, point, dist);
 }
 
@@ -181,7 +216,7 @@ __device__ __constant__ const uint8_t k_range_mul[4][4] = { { 3, 3, 4, 4 }, { 3,
 
 // StarPatternSearch, motion.cpp:284-524.  The reference's sad_x4 fast path and its guarded scalar
 // path visit the same points in the same order, so the guarded form covers both.
-__device__ void star_pattern(Wave &wv, Srch &s, int early_exit_iters, int merange)
+__device__ __forceinline__ void star_pattern(Wave &wv, Srch &s, int early_exit_iters, int merange)
 {
     const int ox = s.bx, oy = s.by;
     int saved = s.bcost;
@@ -263,12 +298,14 @@ __device__ void star_pattern(Wave &wv, Srch &s, int early_exit_iters, int merang
 }
 
 // CROSS macro of the UMH search (motion.cpp:258-282) around (ox, oy)
-__device__ void umh_cross(Wave &wv, Srch &s, int ox, int oy, int start, int x_max, int y_max)
+__device__ __forceinline__ void umh_cross(Wave &wv, Srch &s, int ox, int oy, int start, int x_max, int y_max)
 {
     int i = s16(start);
     if (x_max <= min(s.hix - ox, ox - s.lox))
         for (; i < x_max - 2; i = s16(i + 4))
         {
+            if (wv.nq > QMAX - 4)
+                flush_f<false>(wv, s);
             try_f<false>(wv, s, ox + i, oy);
             try_f<false>(wv, s, ox - i, oy);
             try_f<false>(wv, s, ox + i + 2, oy);
@@ -276,6 +313,8 @@ __device__ void umh_cross(Wave &wv, Srch &s, int ox, int oy, int start, int x_ma
         }
     for (; i < x_max; i = s16(i + 2))
     {
+        if (wv.nq > QMAX - 2)
+            flush_f<false>(wv, s);
         if (ox + i <= s.hix)
             try_f<false>(wv, s, ox + i, oy);
         if (ox - i >= s.lox)
@@ -285,6 +324,8 @@ __device__ void umh_cross(Wave &wv, Srch &s, int ox, int oy, int start, int x_ma
     if (y_max <= min(s.hiy - oy, oy - s.loy))
         for (; i < y_max - 2; i = s16(i + 4))
         {
+            if (wv.nq > QMAX - 4)
+                flush_f<false>(wv, s);
             try_f<false>(wv, s, ox, oy + i);
             try_f<false>(wv, s, ox, oy - i);
             try_f<false>(wv, s, ox, oy + i + 2);
@@ -292,6 +333,8 @@ __device__ void umh_cross(Wave &wv, Srch &s, int ox, int oy, int start, int x_ma
         }
     for (; i < y_max; i = s16(i + 2))
     {
+        if (wv.nq > QMAX - 2)
+            flush_f<false>(wv, s);
         if (oy + i <= s.hiy)
             try_f<false>(wv, s, ox, oy + i);
         if (oy - i >= s.loy)
@@ -336,7 +379,7 @@ __device__ __forceinline__ int wave_min_i32(int v)
 // search (motion.cpp:997-1032, step 1) and the STAR raster refinement (motion.cpp:924-958, step 5).
 // In the STAR form every fourth point of a complete group of four is charged mvcost(mv << 3), a
 // quirk of the reference (motion.cpp:951) that is reproduced.
-__device__ void raster_scan(Wave &wv, Srch &s, int step, bool star_quirk)
+__device__ __forceinline__ void raster_scan(Wave &wv, Srch &s, int step, bool star_quirk)
 {
     if (s.hix < s.lox || s.hiy < s.loy)
         return;
@@ -370,7 +413,7 @@ __device__ void raster_scan(Wave &wv, Srch &s, int step, bool star_quirk)
 // ---------------------------------------------------------------------------------------------
 // MotionEstimate::motionEstimate, motion.cpp:526-1124 (non-lowres branch), one wave per call
 
-__device__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_result *out)
+__device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_result *out)
 {
     Srch s;
     s.lox = j.mvmin_x;
@@ -395,11 +438,11 @@ __device__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_
     const bool sub = ((pmx | pmy) & 3) != 0;
     const bool nz = (pmx | pmy) != 0;
     wv.nq = 0;
-    q_push(wv, pmx, pmy);
+    q_push(wv, pmx, pmy, MV_NONE);
     if (sub)
-        q_push(wv, rfx * 4, rfy * 4);
+        q_push(wv, s16(rfx << 2), s16(rfy << 2), MV_COST);
     if (nz)
-        q_push(wv, 0, 0);
+        q_push(wv, 0, 0, MV_COST);
     int first_mvc = wv.nq;
     for (int i = 0; i < nmvc; i++)
     {
@@ -408,7 +451,7 @@ __device__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_
         my = max(my, qloy);
         // zero and pmv are skipped here; equality with a changing bestpre is resolved below
         if ((mx | my) && !(mx == pmx && my == pmy))
-            q_push(wv, mx, my, 1);
+            q_push(wv, mx, my, MV_COST);
     }
     q_eval(wv, X265_HIP_SAD);
     int bprecost;
@@ -419,10 +462,10 @@ __device__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_
         s.by = rfy;
         s.bcost = bprecost;
         if (sub)
-            s.bcost = q_cost(wv, k++) + mvc_f(wv, rfx, rfy);
+            s.bcost = q_cost(wv, k++);
         if (nz)
         {
-            int cost = q_cost(wv, k++) + mvc_q(wv, 0, 0);
+            int cost = q_cost(wv, k++);
             if (cost < s.bcost)
             {
                 s.bcost = cost;
@@ -434,7 +477,7 @@ __device__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_
             int mx = q_x(wv, k), my = q_y(wv, k);
             if (mx == bpx && my == bpy) // "m != bestpre", motion.cpp:584
                 continue;
-            int cost = q_cost(wv, k) + mvc_q(wv, mx, my);
+            int cost = q_cost(wv, k);
             if (cost < bprecost)
             {
                 bprecost = cost;
@@ -462,10 +505,10 @@ __device__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_
             push_f(wv, s.bx + 1, s.by);
             q_eval(wv, X265_HIP_SAD);
             int best = s.bcost << 4;
-            int c0 = ((q_cost(wv, 0) + mvc_f(wv, s.bx, s.by - 1)) << 4) + 1;
-            int c1 = ((q_cost(wv, 1) + mvc_f(wv, s.bx, s.by + 1)) << 4) + 3;
-            int c2 = ((q_cost(wv, 2) + mvc_f(wv, s.bx - 1, s.by)) << 4) + 4;
-            int c3 = ((q_cost(wv, 3) + mvc_f(wv, s.bx + 1, s.by)) << 4) + 12;
+            int c0 = (q_cost(wv, 0) << 4) + 1;
+            int c1 = (q_cost(wv, 1) << 4) + 3;
+            int c2 = (q_cost(wv, 2) << 4) + 4;
+            int c3 = (q_cost(wv, 3) << 4) + 12;
             wv.nq = 0;
             best = min(best, c0);
             best = min(best, c1);
@@ -573,15 +616,13 @@ __device__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_
                 else
                 {
                     for (int k = 0; k < 16; k++)
-                        push_f(wv, ox + k_hex4[k][0] * i, oy + k_hex4[k][1] * i);
+                        q_push(wv, (ox + k_hex4[k][0] * i) * 4, (oy + k_hex4[k][1] * i) * 4, MV_RAW);
                     q_eval(wv, X265_HIP_SAD);
                     int dirx = 0, diry = 0;
                     bool moved = false;
                     for (int k = 0; k < 16; k++)
                     {
-                        int hx = k_hex4[k][0] * i, hy = k_hex4[k][1] * i;
-                        int cost = q_cost(wv, k) + uniform(tab_at(wv.tab, wv.mvpx, ox * 4 + hx * 4)) +
-                                   uniform(tab_at(wv.tab, wv.mvpy, oy * 4 + hy * 4));
+                        int cost = q_cost(wv, k);
                         if (cost < s.bcost)
                         {
                             s.bcost = cost;
@@ -667,7 +708,7 @@ __device__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_
         int best = s.bcost << 3;
         for (int k = 0; k < 6; k++)
         {
-            int v = ((q_cost(wv, k) + mvc_f(wv, s.bx + k_hex2[k + 1][0], s.by + k_hex2[k + 1][1])) << 3) + (k + 2);
+            int v = (q_cost(wv, k) << 3) + (k + 2);
             best = min(best, v);
         }
         wv.nq = 0;
@@ -684,7 +725,7 @@ __device__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_
                 best &= ~7;
                 for (int k = 0; k < 3; k++)
                 {
-                    int v = ((q_cost(wv, k) + mvc_f(wv, s.bx + k_hex2[dir + k][0], s.by + k_hex2[dir + k][1])) << 3) + (k + 1);
+                    int v = (q_cost(wv, k) << 3) + (k + 1);
                     best = min(best, v);
                 }
                 wv.nq = 0;
@@ -704,7 +745,7 @@ __device__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_
         int dir = 0;
         for (int k = 1; k <= 8; k++)
         {
-            int cost = q_cost(wv, k - 1) + mvc_f(wv, s.bx + k_square1[k][0], s.by + k_square1[k][1]);
+            int cost = q_cost(wv, k - 1);
             if (cost < s.bcost)
             {
                 s.bcost = cost;
@@ -746,17 +787,17 @@ __device__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_
         {
             const bool centre = hsatd && it == 0;
             if (centre)
-                q_push(wv, bx, by);
+                q_push(wv, bx, by, MV_COST);
             for (int i = 1; i <= hpel_dirs; i++)
-                q_push(wv, s16(bx + k_square1[i][0] * 2), s16(by + k_square1[i][1] * 2));
+                q_push(wv, s16(bx + k_square1[i][0] * 2), s16(by + k_square1[i][1] * 2), MV_COST);
             q_eval(wv, hsatd);
             int k = 0;
             if (centre)
-                bcost = q_cost(wv, k++) + mvc_q(wv, bx, by);
+                bcost = q_cost(wv, k++);
             int bdir = 0;
             for (int i = 1; i <= hpel_dirs; i++, k++)
             {
-                int cost = q_cost(wv, k) + mvc_q(wv, q_x(wv, k), q_y(wv, k));
+                int cost = q_cost(wv, k);
                 if (cost < bcost)
                 {
                     bcost = cost;
@@ -769,20 +810,20 @@ __device__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_
         }
         if (!hsatd)
         {
-            q_push(wv, bx, by);
+            q_push(wv, bx, by, MV_COST);
             q_eval(wv, X265_HIP_SATD);
-            bcost = q_cost(wv, 0) + mvc_q(wv, bx, by);
+            bcost = q_cost(wv, 0);
             wv.nq = 0;
         }
         for (int it = 0; it < qpel_iters; it++)
         {
             for (int i = 1; i <= qpel_dirs; i++)
-                q_push(wv, s16(bx + k_square1[i][0]), s16(by + k_square1[i][1]));
+                q_push(wv, s16(bx + k_square1[i][0]), s16(by + k_square1[i][1]), MV_COST);
             q_eval(wv, X265_HIP_SATD);
             int bdir = 0;
             for (int i = 1; i <= qpel_dirs; i++)
             {
-                int cost = q_cost(wv, i - 1) + mvc_q(wv, q_x(wv, i - 1), q_y(wv, i - 1));
+                int cost = q_cost(wv, i - 1);
                 if (cost < bcost)
                 {
                     bcost = cost;
@@ -836,10 +877,10 @@ __global__ __launch_bounds__(64) void cost_kernel(const DeviceTables *tabs, cons
     wv.stride = rp.stride;
     wv.ref = rp.origin + (long)r.pu_y * rp.stride + r.pu_x;
     load_fenc(wv, fp.origin + (long)r.pu_y * fp.stride + r.pu_x, fp.stride);
-    q_push(wv, r.qmv_x, r.qmv_y);
+    q_push(wv, r.qmv_x, r.qmv_y, MV_NONE);
     q_eval(wv, r.metric);
     if (wv.lane == 0)
-        out[id] = wv.s->cost[0];
+        out[id] = wv.vc;
 }
 
 // ---------------------------------------------------------------------------------------------

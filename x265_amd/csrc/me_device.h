@@ -78,14 +78,14 @@ __device__ __forceinline__ void wave_sync()
 
 // Fetch (or interpolate) the 4x4 reference tile whose top-left full-pel sample is `r`, for the
 // quarter-pel fraction (xf, yf).  Output pix[row][col] in 0..255.  All work stays in registers.
-__device__ __forceinline__ void ref_tile(const uint8_t *r, int stride, int xf, int yf, int pix[4][4])
+__device__ __forceinline__ void ref_tile(const uint8_t *r_, int stride, int xf, int yf, int pix[4][4])
 {
     if ((xf | yf) == 0)
     {
 #pragma unroll
         for (int y = 0; y < 4; y++)
         {
-            uint32_t d = ld4u(r + y * stride);
+            uint32_t d = ld4u(r_ + y * stride);
 #pragma unroll
             for (int x = 0; x < 4; x++)
                 pix[y][x] = byte_of(d, x);
@@ -101,7 +101,7 @@ __device__ __forceinline__ void ref_tile(const uint8_t *r, int stride, int xf, i
 #pragma unroll
         for (int y = 0; y < 4; y++)
         {
-            const uint8_t *p = r + y * stride - 3;
+            const uint8_t *p = r_ + y * stride - 3;
             uint32_t d0 = ld4u(p), d1 = ld4u(p + 4), d2 = ld4u(p + 8);
             int s[11];
 #pragma unroll
@@ -126,36 +126,34 @@ __device__ __forceinline__ void ref_tile(const uint8_t *r, int stride, int xf, i
     }
     else if (xf == 0)
     {
-        // luma_vpp: same rounding, taps run down the column
+        // luma_vpp: same rounding, taps run down the column.  Source rows stream through once and
+        // are scattered into the 16 running sums (row r feeds output row y with tap r - y).
         int c[8];
 #pragma unroll
         for (int k = 0; k < 8; k++)
             c[k] = k_taps[yf][k];
-        int s[11][4];
+        int acc[4][4] = {};
 #pragma unroll
-        for (int y = 0; y < 11; y++)
+        for (int r = 0; r < 11; r++)
         {
-            uint32_t d = ld4u(r + (y - 3) * stride);
+            uint32_t d = ld4u(r_ + (r - 3) * stride);
 #pragma unroll
-            for (int x = 0; x < 4; x++)
-                s[y][x] = byte_of(d, x);
+            for (int y = 0; y < 4; y++)
+                if (r - y >= 0 && r - y < 8)
+#pragma unroll
+                    for (int x = 0; x < 4; x++)
+                        acc[y][x] += byte_of(d, x) * c[r - y];
         }
 #pragma unroll
         for (int y = 0; y < 4; y++)
 #pragma unroll
             for (int x = 0; x < 4; x++)
-            {
-                int acc = 0;
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    acc += s[y + k][x] * c[k];
-                pix[y][x] = clip_pixel((acc + 32) >> 6);
-            }
+                pix[y][x] = clip_pixel((acc[y][x] + 32) >> 6);
     }
     else
     {
         // luma_hps (isRowExt = 1: rows -3 .. +7, value = sum - 8192 kept as int16) followed by
-        // luma_vsp: clip((sum_k im[y-3+k]*c[k] + 2048 + (8192 << 6)) >> 12)
+        // luma_vsp: clip((sum_k im[y-3+k]*c[k] + 2048 + (8192 << 6)) >> 12), streamed row by row
         int cx[8], cy[8];
 #pragma unroll
         for (int k = 0; k < 8; k++)
@@ -163,11 +161,11 @@ __device__ __forceinline__ void ref_tile(const uint8_t *r, int stride, int xf, i
             cx[k] = k_taps[xf][k];
             cy[k] = k_taps[yf][k];
         }
-        int im[11][4];
+        int acc[4][4] = {};
 #pragma unroll
-        for (int y = 0; y < 11; y++)
+        for (int r = 0; r < 11; r++)
         {
-            const uint8_t *p = r + (y - 3) * stride - 3;
+            const uint8_t *p = r_ + (r - 3) * stride - 3;
             uint32_t d0 = ld4u(p), d1 = ld4u(p + 4), d2 = ld4u(p + 8);
             int s[11];
 #pragma unroll
@@ -182,24 +180,22 @@ __device__ __forceinline__ void ref_tile(const uint8_t *r, int stride, int xf, i
 #pragma unroll
             for (int x = 0; x < 4; x++)
             {
-                int acc = 0;
+                int h = 0;
 #pragma unroll
                 for (int k = 0; k < 8; k++)
-                    acc += s[x + k] * cx[k];
-                im[y][x] = (int)(int16_t)(acc - 8192);
+                    h += s[x + k] * cx[k];
+                h = (int)(int16_t)(h - 8192);
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                    if (r - y >= 0 && r - y < 8)
+                        acc[y][x] += h * cy[r - y];
             }
         }
 #pragma unroll
         for (int y = 0; y < 4; y++)
 #pragma unroll
             for (int x = 0; x < 4; x++)
-            {
-                int acc = 0;
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    acc += im[y + k][x] * cy[k];
-                pix[y][x] = clip_pixel((acc + 2048 + (8192 << 6)) >> 12);
-            }
+                pix[y][x] = clip_pixel((acc[y][x] + 2048 + (8192 << 6)) >> 12);
     }
 }
 
