@@ -178,7 +178,6 @@ def main():
         chk = pyoracle.load_ref() if pyoracle.have_ref() else pyoracle.load_oracle()
         cores = min(16, os.cpu_count() or 1)
         j = build_ctu_jobs(seq, first + 3, first + 2, 3, 2)
-        sample = list(range(0, n_ctu, max(1, n_ctu // (4 * cores))))[:4 * cores]
         tab = lib.costtab_build(30)
         pl = [p.as_tuple() for p in planes]
 
@@ -188,15 +187,31 @@ def main():
                                (int(jj["mvmin_x"]), int(jj["mvmin_y"])), (int(jj["mvmax_x"]), int(jj["mvmax_y"])),
                                (int(jj["qmvp_x"]), int(jj["qmvp_y"])))
             npos = (int(jj["mvmax_x"]) - int(jj["mvmin_x"]) + 1) * (int(jj["mvmax_y"]) - int(jj["mvmin_y"]) + 1)
-            return npos * 85
+            return npos * int(vp[k])
+        # whole pictures of the same workload, repeated until about 10 s of wall time have passed
         t0 = time.perf_counter()
+        cu, passes = 0, 0
         with ThreadPoolExecutor(cores) as ex:
-            cu = sum(ex.map(one, sample))
+            while time.perf_counter() - t0 < 10.0:
+                cu += sum(ex.map(one, range(n_ctu)))
+                passes += 1
         cdt = time.perf_counter() - t0
         cpu = {"value": cu / cdt, "unit": "candidates/s", "cores": cores, "kind": chk.kind,
-               "sample": f"{len(sample)} of {n_ctu} CTUs of one 1080p picture, same windows; "
-                         f"{'reference C primitives (no asm: no yasm in the image)' if chk.kind == 'reference' else 'C restatement'}"
+               "sample": f"{passes} pass(es) over the {n_ctu} CTUs of one 1080p picture, same windows; "
+                         f"{'reference C sad primitives, -O3 (no asm: no yasm in the image)' if chk.kind == 'reference' else 'C restatement'}"
                          f", one thread per CTU, {cdt:.1f} s"}
+        # the same for the ME stage: the job list of one picture through the reference MotionEstimate
+        mj = synth.me_jobs(W, H, 3, [2, 1, 0], [seq.global_motion(first + 3, first + r) for r in (2, 1, 0)],
+                           method=abi.HEX, subme=2, merange=57, seed=first + 3)
+        tabs = {q: lib.costtab_build(q) for q in range(28, 40)}
+        t0 = time.perf_counter()
+        mp = 0
+        while time.perf_counter() - t0 < 8.0:
+            chk.me_batch(pl, tabs, mj, nthreads=cores)
+            mp += 1
+        mdt = time.perf_counter() - t0
+        cpu_me = {"frames_per_s": mp / mdt, "me_calls_per_s": mp * len(mj) / mdt, "cores": cores, "kind": chk.kind,
+                  "sample": f"{mp} pass(es) over one picture's {len(mj)} motionEstimate calls, {mdt:.1f} s"}
 
     if rank == 0:
         total_units = units * world
@@ -225,6 +240,7 @@ def main():
         }
         if cpu:
             line["cpu_baseline"] = cpu
+            line["me_stage"]["cpu_baseline"] = cpu_me
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

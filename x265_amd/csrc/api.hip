@@ -155,7 +155,7 @@ int x265_hip_ctx_create(int device, x265_hip_ctx **out)
         delete c;
         return fail(X265_HIP_ERUNTIME, "context setup: %s", hipGetErrorString(e));
     }
-    if (fullsearch_setup() != 0 || fullsearch2_setup() != 0)
+    if (fullsearch2_setup() != 0)
     {
         delete c;
         return fail(X265_HIP_ERUNTIME, "fullsearch kernel attribute setup failed");

@@ -32,12 +32,8 @@ void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x26
 void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, hipStream_t st);
 void launch_prim_cmp(const PrimCmpArgs &a, int32_t *out, hipStream_t st);
 void launch_prim_filter(const PrimFilterArgs &a, hipStream_t st);
-void launch_fullsearch(const DeviceTables *tabs, const x265_hip_ctu_job *jobs, int n, x265_hip_me_result *out,
-                       hipStream_t st);
 void launch_fullsearch2(const DeviceTables *tabs, const x265_hip_ctu_job *jobs, int n, x265_hip_me_result *out,
                         hipStream_t st);
 int fullsearch2_setup();
-int fullsearch_setup();
-size_t fullsearch_lds_bytes();
 
 } // namespace x265hip

@@ -1,0 +1,1081 @@
+// me_kernel.hip -- MotionEstimate::motionEstimate replayed on gfx950, one wavefront per call.
+//
+// Reference: encoder/motion.cpp:526-1164 (non-lowres branch): all five search methods, sub-pel
+// levels 0..7, with the reference's visiting order, strict-less tie-breaks and quirks.
+//
+// Shape of the kernel.  A search is a chain of small candidate groups, each depending on the
+// winner of the previous one.  The wave runs a state machine:
+//
+//     loop:  evaluate the queued group (if any)      <- the only place pixels are touched
+//            apply the group's results in push order  <- COPYn_IF_LT semantics
+//            switch (state): decide, queue the next group, pick the next state
+//
+// The evaluation is written once and inlined once, so the whole kernel is a single function whose
+// register budget the compiler sees (no calls, no stack).  All search state is wave-uniform; the
+// queue (<= 16 candidates: position, mv-rate mode, tag) lives in LDS; after an evaluation lane k
+// holds candidate k's cost, and the scalar side reads it with v_readlane.
+//
+// Evaluation: work items are (candidate, 4x4 tile) pairs dealt round-robin to the 64 lanes; a lane
+// fetches or interpolates its reference tile in registers (me_device.h: full-pel, hpp, vpp, or
+// hps -> vsp over an 11x11 footprint), takes SAD or the 4x4 Hadamard against the PU's source tile
+// (LDS) and adds into the candidate's LDS slot.  Lane c meanwhile fetches candidate c's mv rate.
+#include "kernels.h"
+#include "me_device.h"
+
+namespace x265hip {
+
+#define QMAX 16
+
+struct WaveLds
+{
+    uint8_t fenc[64 * 64]; // PU source pixels at stride 64 (setSourcePU, motion.cpp:110-126)
+    int qx[QMAX];          // candidate position, quarter-pel
+    int qy[QMAX];
+    int cost[QMAX];
+    int aux[QMAX];         // (tag << 2) | mv-rate mode
+};
+
+// how the evaluation seeds a candidate's cost with its motion-vector rate
+enum { MV_NONE = 0,  // distortion only
+       MV_COST = 1,  // BitCost::mvcost(): sum of the two entries truncated to uint16 (bitcost.h:45)
+       MV_RAW = 2 }; // plain int sum of the two entries (UMH hexagon grid, motion.cpp:832)
+
+// how a group's results are applied before the state code runs
+enum { FL_NONE = 0,  // the state reads the costs itself
+       FL_BEST = 1,  // strict-less into (bcost, bmv), push order (COST_MV / COST_MV_X4)
+       FL_STAR = 2 }; // same, also recording point and distance (COST_MV_PT_DIST*)
+
+struct Wave
+{
+    WaveLds *s;
+    const uint8_t *ref; // reference plane at the PU origin (fref of motion.cpp:537)
+    int stride;
+    int w, h, ntx, nt;  // PU size, 4x4 tiles per row, tiles in the PU
+    const uint16_t *tab;
+    int mvpx, mvpy;
+    int lane;
+    int nq;
+    int vc, vx, vy, va; // after an evaluation: lane k holds candidate k's cost / position / aux word
+};
+
+__device__ __forceinline__ void wave_init(Wave &wv, WaveLds *s, int w, int h)
+{
+    wv.s = s;
+    wv.w = w;
+    wv.h = h;
+    wv.ntx = w >> 2;
+    wv.nt = (w >> 2) * (h >> 2);
+    wv.lane = threadIdx.x & 63;
+    wv.nq = 0;
+    wv.tab = nullptr;
+    wv.mvpx = wv.mvpy = 0;
+    wv.vc = wv.vx = wv.vy = wv.va = 0;
+}
+
+__device__ __forceinline__ void load_fenc(Wave &wv, const uint8_t *src, int sstride)
+{
+    const int ndw = wv.ntx * wv.h;
+    for (int i = wv.lane; i < ndw; i += 64)
+    {
+        int y = i / wv.ntx, x = i - y * wv.ntx;
+        *(uint32_t *)(wv.s->fenc + y * 64 + 4 * x) = ld4u(src + y * sstride + 4 * x);
+    }
+    wave_sync();
+}
+
+// queue values are wave-uniform: every lane stores the same word
+__device__ __forceinline__ void q_push(Wave &wv, int qx, int qy, int mvmode, int tag = 0)
+{
+    wv.s->qx[wv.nq] = qx;
+    wv.s->qy[wv.nq] = qy;
+    wv.s->aux[wv.nq] = (tag << 2) | mvmode;
+    wv.nq++;
+}
+
+// cost[c] = mv rate (per its mode) + SAD or SATD of the PU against the reference at candidate c's
+// quarter-pel position (subpelCompare + cmp, motion.cpp:1126-1164)
+__device__ __forceinline__ void q_eval(Wave &wv, int metric)
+{
+    WaveLds *s = wv.s;
+    const int lane = wv.lane, nq = wv.nq;
+    int seed = 0, px = 0, py = 0, pa = 0;
+    if (lane < nq)
+    {
+        px = s->qx[lane];
+        py = s->qy[lane];
+        pa = s->aux[lane];
+        const int mode = pa & 3;
+        if (mode != MV_NONE)
+        {
+            const int a = tab_at(wv.tab, wv.mvpx, px), b = tab_at(wv.tab, wv.mvpy, py);
+            seed = mode == MV_COST ? (int)(uint16_t)(a + b) : a + b;
+        }
+    }
+    if (lane < QMAX)
+        s->cost[lane] = 0;
+    wave_sync();
+    const int total = nq * wv.nt;
+    // i / nt and t / ntx by reciprocal: exact for i < 4096, nt <= 256 (error 4e-4 << 0.5 / nt)
+    const float inv_nt = 1.0f / (float)wv.nt, inv_ntx = 1.0f / (float)wv.ntx;
+    for (int i = lane; i < total; i += 64)
+    {
+        const int c = (int)(((float)i + 0.5f) * inv_nt), t = i - c * wv.nt;
+        const int ty = (int)(((float)t + 0.5f) * inv_ntx), tx = t - ty * wv.ntx;
+        const int qx = s->qx[c], qy = s->qy[c];
+        int pix[4][4];
+        ref_tile(wv.ref + ((qy >> 2) + 4 * ty) * wv.stride + (qx >> 2) + 4 * tx, wv.stride, qx & 3, qy & 3, pix);
+        const int v = tile_metric(s->fenc + ty * 4 * 64 + tx * 4, 64, pix, metric);
+        atomicAdd(&s->cost[c], v);
+    }
+    wave_sync();
+    wv.vc = lane < nq ? s->cost[lane & (QMAX - 1)] + seed : 0x7fffffff;
+    wv.vx = px;
+    wv.vy = py;
+    wv.va = pa;
+}
+
+// k is wave-uniform at every call site
+__device__ __forceinline__ int q_cost(const Wave &wv, int k) { return __builtin_amdgcn_readlane(wv.vc, k); }
+__device__ __forceinline__ int q_x(const Wave &wv, int k) { return __builtin_amdgcn_readlane(wv.vx, k); }
+__device__ __forceinline__ int q_y(const Wave &wv, int k) { return __builtin_amdgcn_readlane(wv.vy, k); }
+__device__ __forceinline__ int q_tag(const Wave &wv, int k) { return __builtin_amdgcn_readlane(wv.va, k) >> 2; }
+
+__device__ __forceinline__ int s16(int v) { return (int)(int16_t)v; }
+
+// queue a full-pel point with mvcost(mv << 2); the shift is an int16 operation in the reference
+// (mv.h:63).  tag carries (point << 16) | dist for the STAR pattern.
+__device__ __forceinline__ void push_f(Wave &wv, int mx, int my, int point = 0, int dist = 0)
+{
+    q_push(wv, s16(s16(mx) << 2), s16(s16(my) << 2), MV_COST, (point << 16) | dist);
+}
+
+__device__ __constant__ const int8_t k_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
+__device__ __constant__ const uint8_t k_mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+__device__ __constant__ const int8_t k_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+__device__ __constant__ const int8_t k_hex4[16][2] = { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 },
+                                                      { -4, 0 }, { 4, 0 }, { -4, 1 }, { 4, 1 }, { -4, 2 }, { 4, 2 }, { -2, 3 }, { 2, 3 } };
+__device__ __constant__ const int8_t k_twopoint[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
+                                                          { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
+// {hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd}, motion.cpp:47-57
+__device__ __constant__ const uint8_t k_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
+                                                          { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+__device__ __constant__ const int8_t k_umh_oct[8][2] = { { 0, -2 }, { -1, -1 }, { 1, -1 }, { -2, 0 }, { 2, 0 }, { -1, 1 }, { 1, 1 }, { 0, 2 } };
+__device__ __constant__ const int8_t k_umh_hex[8][2] = { { -1, -2 }, { 1, -2 }, { -2, -1 }, { 2, -1 }, { -2, 1 }, { 2, 1 }, { -1, 2 }, { 1, 2 } };
+__device__ __constant__ const uint8_t k_range_mul[4][4] = { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } };
+
+// One position per lane: SAD of the whole PU at full-pel (mx, my), source pixels broadcast from LDS
+__device__ __forceinline__ int lane_sad(const Wave &wv, int mx, int my)
+{
+    const uint8_t *r = wv.ref + my * wv.stride + mx;
+    uint32_t acc = 0;
+    for (int y = 0; y < wv.h; y++)
+    {
+        const uint8_t *rr = r + y * wv.stride;
+        const uint8_t *ff = wv.s->fenc + y * 64;
+        for (int x = 0; x < wv.ntx; x++)
+            acc = __builtin_amdgcn_sad_u8(*(const uint32_t *)(ff + 4 * x), ld4u(rr + 4 * x), acc);
+    }
+    return (int)acc;
+}
+
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+enum State
+{
+    ST_PRE, ST_INT_BEGIN, ST_DIA, ST_HEX_BEGIN, ST_HEX1, ST_HEXN, ST_SQ,
+    ST_U0, ST_U1, ST_U2, ST_CROSS, ST_U3, ST_U3B, ST_U4, ST_U5, ST_U5B, ST_URING,
+    ST_STAR_BEGIN, ST_STAR_RING, ST_STAR_END, ST_STAR_TPA, ST_STAR_AFTER_A, ST_STAR_LOOP, ST_STAR_TPB,
+    ST_RASTER, ST_POST, ST_HPEL, ST_REM, ST_QPEL_BEGIN, ST_QPEL, ST_DONE
+};
+
+__device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_result *out)
+{
+    // integer-stage state, all wave-uniform
+    const int lox = j.mvmin_x, loy = j.mvmin_y, hix = j.mvmax_x, hiy = j.mvmax_y; // full-pel, inclusive
+    int bcost = 0, bx = 0, by = 0; // best so far: full-pel during the integer stage, quarter-pel after ST_POST
+    int point = 0, dist = 0;       // STAR bookkeeping
+    const int qlox = s16(lox << 2), qloy = s16(loy << 2), qhix = s16(hix << 2), qhiy = s16(hiy << 2);
+    int merange = j.merange;
+    const int method = j.method;
+    const int nmvc = j.num_mvc;
+    const int subme = j.subme;
+    const int hpel_iters = k_workload[subme][0], hpel_dirs = k_workload[subme][1];
+    const int qpel_iters = k_workload[subme][2], qpel_dirs = k_workload[subme][3];
+    const int hsatd = k_workload[subme][4];
+
+#define IN_RANGE(x, y) ((x) >= lox && (x) <= hix && (y) >= loy && (y) <= hiy)
+
+    // clipped quarter-pel predictor (motion.cpp:552; MV::clipped, mv.h:89-94)
+    int pmx = min((int)j.qmvp_x, qhix), pmy = min((int)j.qmvp_y, qhiy);
+    pmx = max(pmx, qlox);
+    pmy = max(pmy, qloy);
+    int bpx = pmx, bpy = pmy, bprecost = 0;                              // bestpre
+    const int fpx = s16(s16(pmx + 2) >> 2), fpy = s16(s16(pmy + 2) >> 2); // pmv.roundToFPel(), mv.h:76
+    const bool sub = ((pmx | pmy) & 3) != 0;
+    const bool nz = (pmx | pmy) != 0;
+
+    // first group: predictor (SAD only, no mv rate), its full-pel rounding, the zero vector and the
+    // candidates (motion.cpp:551-598); consumed in the reference's order in ST_PRE
+    wv.nq = 0;
+    q_push(wv, pmx, pmy, MV_NONE);
+    if (sub)
+        q_push(wv, s16(fpx << 2), s16(fpy << 2), MV_COST);
+    if (nz)
+        q_push(wv, 0, 0, MV_COST);
+    const int first_mvc = wv.nq;
+    for (int i = 0; i < nmvc; i++)
+    {
+        int mx = min((int)j.mvc[2 * i], qhix), my = min((int)j.mvc[2 * i + 1], qhiy);
+        mx = max(mx, qlox);
+        my = max(my, qloy);
+        // zero and pmv are skipped here; "m != bestpre" (motion.cpp:584) is resolved when consuming
+        if ((mx | my) && !(mx == pmx && my == pmy))
+            q_push(wv, mx, my, MV_COST);
+    }
+
+    int st = ST_PRE, metric = X265_HIP_SAD, flush = FL_NONE;
+    // per-method scratch (uniform)
+    int cnt = 0, dir = 0, packed = 0;                 // DIA / HEX iteration count, hexagon direction, packed best
+    int ox = 0, oy = 0;                               // pattern origin
+    int ucost1 = 0, ucost2 = 0, cross_start = 1, urange = 0, ring = 1;
+    bool ring_raw = false;
+    int cr_i = 0, cr_phase = 4, cr_xmax = 0, cr_ymax = 0, cr_start = 0, cr_next = ST_POST; // CROSS generator
+    int saved = 0, rounds = 0, early = 3, sd = 1, star_phase = 0;                          // STAR
+    int ras_step = 1, ras_next = ST_POST;
+    bool ras_quirk = false;
+    int sub_it = 0;
+
+    for (;;)
+    {
+        if (wv.nq)
+            q_eval(wv, metric);
+        if (flush != FL_NONE)
+        {
+            for (int k = 0; k < wv.nq; k++)
+            {
+                const int cost = q_cost(wv, k);
+                if (cost < bcost)
+                {
+                    bcost = cost;
+                    bx = q_x(wv, k) >> 2;
+                    by = q_y(wv, k) >> 2;
+                    if (flush == FL_STAR)
+                    {
+                        const int a = q_tag(wv, k);
+                        point = a >> 16;
+                        dist = a & 0xffff;
+                    }
+                }
+            }
+            wv.nq = 0;
+        }
+        flush = FL_NONE;
+        if (st == ST_DONE)
+            break;
+
+        switch (st)
+        {
+        case ST_PRE:
+        {
+            int k = 0;
+            bprecost = q_cost(wv, k++);
+            bx = fpx;
+            by = fpy;
+            bcost = bprecost;
+            if (sub)
+                bcost = q_cost(wv, k++); // full-pel start re-measured with its mv rate (:562-567)
+            if (nz)
+            {
+                const int cost = q_cost(wv, k++); // zero vector (:570-578)
+                if (cost < bcost)
+                {
+                    bcost = cost;
+                    bx = by = 0;
+                }
+            }
+            for (k = first_mvc; k < wv.nq; k++)
+            {
+                const int mx = q_x(wv, k), my = q_y(wv, k);
+                if (mx == bpx && my == bpy)
+                    continue;
+                const int cost = q_cost(wv, k);
+                if (cost < bprecost) // candidates compete with bprecost only (:592)
+                {
+                    bprecost = cost;
+                    bpx = mx;
+                    bpy = my;
+                }
+            }
+            wv.nq = 0;
+            st = ST_INT_BEGIN;
+            break;
+        }
+
+        case ST_INT_BEGIN:
+            if (method == X265_HIP_DIA)
+            {
+                cnt = merange;
+                push_f(wv, bx, by - 1);
+                push_f(wv, bx, by + 1);
+                push_f(wv, bx - 1, by);
+                push_f(wv, bx + 1, by);
+                st = ST_DIA;
+            }
+            else if (method == X265_HIP_HEX)
+                st = ST_HEX_BEGIN;
+            else if (method == X265_HIP_UMH)
+            {
+                // refine predictors: DIA1_ITER(pmv), DIA1_ITER(0) (motion.cpp:707-712)
+                ucost1 = bcost;
+                push_f(wv, fpx, fpy - 1);
+                push_f(wv, fpx, fpy + 1);
+                push_f(wv, fpx - 1, fpy);
+                push_f(wv, fpx + 1, fpy);
+                if (fpx | fpy)
+                {
+                    push_f(wv, 0, -1);
+                    push_f(wv, 0, 1);
+                    push_f(wv, -1, 0);
+                    push_f(wv, 1, 0);
+                }
+                flush = FL_BEST;
+                st = ST_U0;
+            }
+            else if (method == X265_HIP_STAR)
+            {
+                point = dist = 0;
+                star_phase = 0;
+                early = 3;
+                st = ST_STAR_BEGIN;
+            }
+            else
+            {
+                ras_step = 1;
+                ras_quirk = false;
+                ras_next = ST_POST;
+                st = ST_RASTER;
+            }
+            break;
+
+        // ---- DIA: radius-1 diamond, packed (cost << 4) + code, centre wins ties (motion.cpp:605-626)
+        case ST_DIA:
+        {
+            int best = bcost << 4;
+            best = min(best, (q_cost(wv, 0) << 4) + 1);
+            best = min(best, (q_cost(wv, 1) << 4) + 3);
+            best = min(best, (q_cost(wv, 2) << 4) + 4);
+            best = min(best, (q_cost(wv, 3) << 4) + 12);
+            wv.nq = 0;
+            if (!(best & 15))
+            {
+                st = ST_POST;
+                break;
+            }
+            bx = s16(bx - (((int)((unsigned)best << 28)) >> 30));
+            by = s16(by - (((int)((unsigned)best << 30)) >> 30));
+            bcost = best >> 4;
+            if (--cnt && IN_RANGE(bx, by))
+            {
+                push_f(wv, bx, by - 1);
+                push_f(wv, bx, by + 1);
+                push_f(wv, bx - 1, by);
+                push_f(wv, bx + 1, by);
+            }
+            else
+                st = ST_POST;
+            break;
+        }
+
+        // ---- HEX: radius-2 hexagon then square refine (motion.cpp:628-700)
+        case ST_HEX_BEGIN:
+            for (int k = 1; k <= 6; k++) // hex2[1..6] = (-2,0)(-1,2)(1,2)(2,0)(1,-2)(-1,-2): codes 2..7
+                push_f(wv, bx + k_hex2[k][0], by + k_hex2[k][1]);
+            st = ST_HEX1;
+            break;
+
+        case ST_HEX1:
+        case ST_HEXN:
+        {
+            bool go_on = false;
+            if (st == ST_HEX1)
+            {
+                packed = bcost << 3;
+                for (int k = 0; k < 6; k++)
+                    packed = min(packed, (q_cost(wv, k) << 3) + (k + 2));
+                wv.nq = 0;
+                if (packed & 7)
+                {
+                    dir = (packed & 7) - 2;
+                    bx = s16(bx + k_hex2[dir + 1][0]);
+                    by = s16(by + k_hex2[dir + 1][1]);
+                    cnt = (merange >> 1) - 1;
+                    go_on = cnt > 0 && IN_RANGE(bx, by);
+                }
+            }
+            else
+            {
+                packed &= ~7;
+                for (int k = 0; k < 3; k++)
+                    packed = min(packed, (q_cost(wv, k) << 3) + (k + 1));
+                wv.nq = 0;
+                if (packed & 7)
+                {
+                    dir += (packed & 7) - 2;
+                    dir = k_mod6m1[dir + 1];
+                    bx = s16(bx + k_hex2[dir + 1][0]);
+                    by = s16(by + k_hex2[dir + 1][1]);
+                    cnt--;
+                    go_on = cnt > 0 && IN_RANGE(bx, by);
+                }
+            }
+            if (go_on)
+            {
+                // half hexagon, not overlapping the previous one
+                for (int k = 0; k < 3; k++)
+                    push_f(wv, bx + k_hex2[dir + k][0], by + k_hex2[dir + k][1]);
+                st = ST_HEXN;
+            }
+            else
+            {
+                bcost = packed >> 3;
+                for (int k = 1; k <= 8; k++)
+                    push_f(wv, bx + k_square1[k][0], by + k_square1[k][1]);
+                st = ST_SQ;
+            }
+            break;
+        }
+
+        case ST_SQ:
+        {
+            int d = 0;
+            for (int k = 1; k <= 8; k++)
+            {
+                const int cost = q_cost(wv, k - 1);
+                if (cost < bcost)
+                {
+                    bcost = cost;
+                    d = k;
+                }
+            }
+            wv.nq = 0;
+            bx = s16(bx + k_square1[d][0]);
+            by = s16(by + k_square1[d][1]);
+            st = ST_POST;
+            break;
+        }
+
+        // ---- UMH (motion.cpp:702-885)
+#define THRESH(v) (bcost < (((v) >> 4) * ((wv.h * wv.h) >> 4))) /* SAD_THRESH, size_scale (motion.cpp:60-66) */
+        case ST_U0:
+            ucost2 = bcost;
+            if ((bx | by) && !(bx == fpx && by == fpy))
+            {
+                push_f(wv, bx, by - 1);
+                push_f(wv, bx, by + 1);
+                push_f(wv, bx - 1, by);
+                push_f(wv, bx + 1, by);
+                flush = FL_BEST;
+            }
+            st = ST_U1;
+            break;
+
+        case ST_U1:
+            if (bcost == ucost2)
+                cross_start = 3;
+            ox = bx;
+            oy = by;
+            if (bcost == ucost2 && THRESH(2000))
+            {
+                for (int k = 0; k < 8; k++)
+                    push_f(wv, ox + k_umh_oct[k][0], oy + k_umh_oct[k][1]);
+                flush = FL_BEST;
+                st = ST_U2;
+            }
+            else
+                st = ST_U4;
+            break;
+
+        case ST_U2:
+            if (bcost == ucost1 && THRESH(500))
+                st = ST_POST;
+            else if (bcost == ucost2)
+            {
+                urange = s16((merange >> 1) | 1);
+                cr_start = 3;
+                cr_xmax = cr_ymax = urange;
+                cr_i = s16(cr_start);
+                cr_phase = 0;
+                cr_next = ST_U3;
+                st = ST_CROSS;
+            }
+            else
+                st = ST_U4;
+            break;
+
+        // CROSS macro as a resumable generator around (ox, oy) (motion.cpp:258-282): phase 0 paired
+        // x4 steps in x (only when the arm fits the range), 1 guarded steps in x, 2 / 3 the same in y
+        case ST_CROSS:
+        {
+            while (cr_phase < 4 && wv.nq <= QMAX - 4)
+            {
+                if (cr_phase == 0)
+                {
+                    if (cr_xmax <= min(hix - ox, ox - lox) && cr_i < cr_xmax - 2)
+                    {
+                        push_f(wv, ox + cr_i, oy);
+                        push_f(wv, ox - cr_i, oy);
+                        push_f(wv, ox + cr_i + 2, oy);
+                        push_f(wv, ox - cr_i - 2, oy);
+                        cr_i = s16(cr_i + 4);
+                    }
+                    else
+                        cr_phase = 1;
+                }
+                else if (cr_phase == 1)
+                {
+                    if (cr_i < cr_xmax)
+                    {
+                        if (ox + cr_i <= hix)
+                            push_f(wv, ox + cr_i, oy);
+                        if (ox - cr_i >= lox)
+                            push_f(wv, ox - cr_i, oy);
+                        cr_i = s16(cr_i + 2);
+                    }
+                    else
+                    {
+                        cr_i = s16(cr_start);
+                        cr_phase = 2;
+                    }
+                }
+                else if (cr_phase == 2)
+                {
+                    if (cr_ymax <= min(hiy - oy, oy - loy) && cr_i < cr_ymax - 2)
+                    {
+                        push_f(wv, ox, oy + cr_i);
+                        push_f(wv, ox, oy - cr_i);
+                        push_f(wv, ox, oy + cr_i + 2);
+                        push_f(wv, ox, oy - cr_i - 2);
+                        cr_i = s16(cr_i + 4);
+                    }
+                    else
+                        cr_phase = 3;
+                }
+                else
+                {
+                    if (cr_i < cr_ymax)
+                    {
+                        if (oy + cr_i <= hiy)
+                            push_f(wv, ox, oy + cr_i);
+                        if (oy - cr_i >= loy)
+                            push_f(wv, ox, oy - cr_i);
+                        cr_i = s16(cr_i + 2);
+                    }
+                    else
+                        cr_phase = 4;
+                }
+            }
+            flush = FL_BEST;
+            if (cr_phase == 4)
+                st = cr_next;
+            break;
+        }
+
+        case ST_U3:
+        {
+            for (int k = 0; k < 8; k++)
+                push_f(wv, ox + k_umh_hex[k][0], oy + k_umh_hex[k][1]);
+            flush = FL_BEST;
+            st = ST_U3B;
+            break;
+        }
+
+        case ST_U3B:
+            if (bcost == ucost2)
+                st = ST_POST;
+            else
+            {
+                cross_start = urange + 2;
+                st = ST_U4;
+            }
+            break;
+
+        case ST_U4:
+        {
+            // adaptive search range from predictor agreement and the current SAD (motion.cpp:743-795)
+            if (nmvc)
+            {
+                int mvd, denom = 1;
+                const bool is64 = (wv.w == 64 && wv.h == 64);
+                const int d0 = abs(j.qmvp_x - j.mvc[0]) + abs(j.qmvp_y - j.mvc[1]);
+                if (nmvc == 1)
+                    mvd = is64 ? 25 : d0;
+                else
+                {
+                    denom = nmvc - 1;
+                    mvd = 0;
+                    if (!is64)
+                    {
+                        mvd = d0;
+                        denom++;
+                    }
+                    for (int i = 0; i < nmvc - 1; i++)
+                        mvd += abs(j.mvc[2 * i] - j.mvc[2 * i + 2]) + abs(j.mvc[2 * i + 1] - j.mvc[2 * i + 3]);
+                }
+                const int sad_ctx = THRESH(1000) ? 0 : THRESH(2000) ? 1 : THRESH(4000) ? 2 : 3;
+                const int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
+                merange = (merange * k_range_mul[mvd_ctx][sad_ctx]) >> 2;
+            }
+            cr_start = cross_start;
+            cr_xmax = merange;
+            cr_ymax = merange >> 1;
+            cr_i = s16(cr_start);
+            cr_phase = 0;
+            cr_next = ST_U5;
+            st = ST_CROSS;
+            break;
+        }
+#undef THRESH
+
+        case ST_U5:
+            push_f(wv, ox - 2, oy - 2);
+            push_f(wv, ox - 2, oy + 2);
+            push_f(wv, ox + 2, oy - 2);
+            push_f(wv, ox + 2, oy + 2);
+            flush = FL_BEST;
+            st = ST_U5B;
+            break;
+
+        case ST_U5B:
+        case ST_URING:
+        {
+            // hexagon-grid rings i = 1 .. merange/4 around the new centre (motion.cpp:802-881).  Inside
+            // the window the reference adds the two table entries as ints (no uint16 truncation) and
+            // moves once per ring; near the border it falls back to guarded scalar candidates.
+            if (st == ST_U5B)
+            {
+                ox = bx;
+                oy = by;
+                ring = 1;
+            }
+            else
+            {
+                if (ring_raw)
+                {
+                    int dx = 0, dy = 0;
+                    bool moved = false;
+                    for (int k = 0; k < 16; k++)
+                    {
+                        const int cost = q_cost(wv, k);
+                        if (cost < bcost)
+                        {
+                            bcost = cost;
+                            dx = k_hex4[k][0];
+                            dy = k_hex4[k][1];
+                            moved = true;
+                        }
+                    }
+                    wv.nq = 0;
+                    if (moved)
+                    {
+                        bx = s16(ox + ring * dx);
+                        by = s16(oy + ring * dy);
+                    }
+                }
+                ring = (ring + 1) & 0xffff; // uint16_t counter in the reference
+                if (!(ring <= merange >> 2))
+                {
+                    st = IN_RANGE(bx, by) ? ST_HEX_BEGIN : ST_POST; // "goto me_hex2" (:882-883)
+                    break;
+                }
+            }
+            const int room = min(min(hix - ox, ox - lox), min(hiy - oy, oy - loy));
+            ring_raw = !(4 * ring > room);
+            if (ring_raw)
+            {
+                for (int k = 0; k < 16; k++)
+                    q_push(wv, (ox + k_hex4[k][0] * ring) * 4, (oy + k_hex4[k][1] * ring) * 4, MV_RAW);
+            }
+            else
+            {
+                for (int k = 0; k < 16; k++)
+                {
+                    const int mx = s16(ox + s16(k_hex4[k][0] * s16(ring))), my = s16(oy + s16(k_hex4[k][1] * s16(ring)));
+                    if (IN_RANGE(mx, my))
+                        push_f(wv, mx, my);
+                }
+                flush = FL_BEST;
+            }
+            st = ST_URING;
+            break;
+        }
+
+        // ---- STAR (motion.cpp:887-995; StarPatternSearch :284-524).  The reference's sad_x4 fast path
+        // and its guarded scalar path visit the same points in the same order: the guarded form is used.
+        case ST_STAR_BEGIN:
+        case ST_STAR_RING:
+        {
+            if (st == ST_STAR_BEGIN)
+            {
+                ox = bx;
+                oy = by;
+                rounds = 0;
+                sd = 1;
+            }
+            else
+            {
+                bool cont = true;
+                if (bcost < saved)
+                    rounds = 0;
+                else if (++rounds >= early)
+                    cont = false;
+                if (cont)
+                {
+                    sd <<= 1;
+                    if (sd >= 16 && sd > s16(merange))
+                        cont = false;
+                }
+                if (!cont)
+                {
+                    st = ST_STAR_END;
+                    break;
+                }
+            }
+            saved = bcost;
+            if (sd <= 8)
+            {
+                const int half = sd >> 1;
+                const int top = s16(oy - sd), bottom = s16(oy + sd), left = s16(ox - sd), right = s16(ox + sd);
+                const int top2 = s16(oy - half), bottom2 = s16(oy + half), left2 = s16(ox - half), right2 = s16(ox + half);
+                // visiting order 2,1,3,4,5,6,8,7; points 1,3,6,8 exist only for dist >= 2
+                if (top >= loy)
+                    push_f(wv, ox, top, 2, sd);
+                if (sd > 1 && top2 >= loy)
+                {
+                    if (left2 >= lox)
+                        push_f(wv, left2, top2, 1, half);
+                    if (right2 <= hix)
+                        push_f(wv, right2, top2, 3, half);
+                }
+                if (left >= lox)
+                    push_f(wv, left, oy, 4, sd);
+                if (right <= hix)
+                    push_f(wv, right, oy, 5, sd);
+                if (sd > 1 && bottom2 <= hiy)
+                {
+                    if (left2 >= lox)
+                        push_f(wv, left2, bottom2, 6, half);
+                    if (right2 <= hix)
+                        push_f(wv, right2, bottom2, 8, half);
+                }
+                if (bottom <= hiy)
+                    push_f(wv, ox, bottom, 7, sd);
+            }
+            else
+            {
+                const int q = sd >> 2;
+                const int top = s16(oy - sd), bottom = s16(oy + sd), left = s16(ox - sd), right = s16(ox + sd);
+                if (top >= loy)
+                    push_f(wv, ox, top, 0, sd);
+                if (left >= lox)
+                    push_f(wv, left, oy, 0, sd);
+                if (right <= hix)
+                    push_f(wv, right, oy, 0, sd);
+                if (bottom <= hiy)
+                    push_f(wv, ox, bottom, 0, sd);
+                for (int idx = 1; idx < 4; idx++)
+                {
+                    const int yt = s16(top + q * idx), yb = s16(bottom - q * idx);
+                    const int xl = s16(ox - q * idx), xr = s16(ox + q * idx);
+                    if (yt >= loy)
+                    {
+                        if (xl >= lox)
+                            push_f(wv, xl, yt, 0, sd);
+                        if (xr <= hix)
+                            push_f(wv, xr, yt, 0, sd);
+                    }
+                    if (yb <= hiy)
+                    {
+                        if (xl >= lox)
+                            push_f(wv, xl, yb, 0, sd);
+                        if (xr <= hix)
+                            push_f(wv, xr, yb, 0, sd);
+                    }
+                }
+            }
+            flush = FL_STAR;
+            st = ST_STAR_RING;
+            break;
+        }
+
+        case ST_STAR_END:
+        {
+            const bool two = dist == 1 && point;
+            if (two)
+            {
+                // nearest two outer points of the winning direction (offsets[], motion.cpp:139-149)
+                const int x1 = s16(bx + k_twopoint[(point - 1) * 2][0]), y1 = s16(by + k_twopoint[(point - 1) * 2][1]);
+                const int x2 = s16(bx + k_twopoint[(point - 1) * 2 + 1][0]), y2 = s16(by + k_twopoint[(point - 1) * 2 + 1][1]);
+                if (IN_RANGE(x1, y1))
+                    push_f(wv, x1, y1);
+                if (IN_RANGE(x2, y2))
+                    push_f(wv, x2, y2);
+                flush = FL_BEST; // COST_MV: point / distance are not touched
+                saved = bcost;
+            }
+            if (star_phase == 0)
+                st = two ? ST_STAR_TPA : (dist == 1 ? ST_POST : ST_STAR_AFTER_A);
+            else
+                st = two ? ST_STAR_TPB : (dist == 1 ? ST_POST : ST_STAR_LOOP);
+            break;
+        }
+
+        case ST_STAR_TPA:
+            st = bcost == saved ? ST_POST : ST_STAR_AFTER_A;
+            break;
+
+        case ST_STAR_AFTER_A:
+            if (dist > 5) // raster refinement if the first pass went far (RasterDistance = 5)
+            {
+                ras_step = 5;
+                ras_quirk = true;
+                ras_next = ST_STAR_LOOP;
+                st = ST_RASTER;
+            }
+            else
+                st = ST_STAR_LOOP;
+            break;
+
+        case ST_STAR_LOOP:
+            if (dist > 0)
+            {
+                dist = 0;
+                point = 0;
+                star_phase = 1;
+                early = 32;
+                st = ST_STAR_BEGIN;
+            }
+            else
+                st = ST_POST;
+            break;
+
+        case ST_STAR_TPB:
+            st = ST_POST;
+            break;
+
+        // ---- raster scan of (lox + step*ix, loy + step*iy), row-major, first minimum wins: FULL
+        // (motion.cpp:997-1032, step 1) and the STAR raster (:924-958, step 5).  One position per lane.
+        // In the STAR form every fourth point of a complete group of four is charged mvcost(mv << 3),
+        // a quirk of the reference (:951) that is reproduced.
+        case ST_RASTER:
+        {
+            st = ras_next;
+            if (hix < lox || hiy < loy)
+                break;
+            const int nx = (hix - lox) / ras_step + 1, ny = (hiy - loy) / ras_step + 1;
+            const int groups = (hix - lox - 3 * ras_step >= 0) ? (hix - lox - 3 * ras_step) / (4 * ras_step) + 1 : 0;
+            const int total = nx * ny;
+            for (int base = 0; base < total; base += 64)
+            {
+                const int idx = base + wv.lane;
+                int cost = 0x7fffffff;
+                if (idx < total)
+                {
+                    const int iy = idx / nx, ix = idx - iy * nx;
+                    const int mx = lox + ix * ras_step, my = loy + iy * ras_step;
+                    const int sh = (ras_quirk && ix < 4 * groups && (ix & 3) == 3) ? 3 : 2;
+                    cost = lane_sad(wv, mx, my) + mvcost_q(wv.tab, wv.mvpx, wv.mvpy, s16(mx << sh), s16(my << sh));
+                }
+                const int m = uniform(wave_min_i32(cost));
+                if (m < bcost)
+                {
+                    const unsigned long long hit = __ballot(cost == m);
+                    const int first = base + (int)__builtin_ctzll(hit);
+                    const int iy = first / nx, ix = first - iy * nx;
+                    bcost = m;
+                    bx = lox + ix * ras_step;
+                    by = loy + iy * ras_step;
+                }
+            }
+            break;
+        }
+
+        // ---- after the integer stage (motion.cpp:1039-1119)
+        case ST_POST:
+            if (bprecost < bcost) // pre-test winner bypasses the integer result
+            {
+                bx = bpx;
+                by = bpy;
+                bcost = bprecost;
+            }
+            else
+            {
+                bx = s16(bx << 2);
+                by = s16(by << 2);
+            }
+            if (!bcost)
+            {
+                bcost = uniform(mvcost_q(wv.tab, wv.mvpx, wv.mvpy, bx, by)); // zero residual: rate only (:1049-1054)
+                st = ST_DONE;
+                break;
+            }
+            sub_it = 0;
+            metric = hsatd;
+            // with hpel_satd the SATD re-measure of the centre does not depend on the ring: same group
+            if (hsatd)
+                q_push(wv, bx, by, MV_COST);
+            for (int i = 1; i <= hpel_dirs; i++)
+                q_push(wv, s16(bx + k_square1[i][0] * 2), s16(by + k_square1[i][1] * 2), MV_COST);
+            st = ST_HPEL;
+            break;
+
+        case ST_HPEL:
+        {
+            int k = 0;
+            if (hsatd && sub_it == 0)
+                bcost = q_cost(wv, k++);
+            int bdir = 0;
+            for (int i = 1; i <= hpel_dirs; i++, k++)
+            {
+                const int cost = q_cost(wv, k);
+                if (cost < bcost)
+                {
+                    bcost = cost;
+                    bdir = i;
+                }
+            }
+            wv.nq = 0;
+            bx = s16(bx + k_square1[bdir][0] * 2);
+            by = s16(by + k_square1[bdir][1] * 2);
+            if (++sub_it < hpel_iters)
+            {
+                for (int i = 1; i <= hpel_dirs; i++)
+                    q_push(wv, s16(bx + k_square1[i][0] * 2), s16(by + k_square1[i][1] * 2), MV_COST);
+            }
+            else if (!hsatd)
+            {
+                metric = X265_HIP_SATD; // half-pel used SAD: re-measure with SATD before quarter-pel (:1103-1105)
+                q_push(wv, bx, by, MV_COST);
+                st = ST_REM;
+            }
+            else
+                st = ST_QPEL_BEGIN;
+            break;
+        }
+
+        case ST_REM:
+            bcost = q_cost(wv, 0);
+            wv.nq = 0;
+            st = ST_QPEL_BEGIN;
+            break;
+
+        case ST_QPEL_BEGIN:
+            sub_it = 0;
+            metric = X265_HIP_SATD;
+            if (qpel_iters > 0)
+            {
+                for (int i = 1; i <= qpel_dirs; i++)
+                    q_push(wv, s16(bx + k_square1[i][0]), s16(by + k_square1[i][1]), MV_COST);
+                st = ST_QPEL;
+            }
+            else
+                st = ST_DONE;
+            break;
+
+        case ST_QPEL:
+        {
+            int bdir = 0;
+            for (int i = 1; i <= qpel_dirs; i++)
+            {
+                const int cost = q_cost(wv, i - 1);
+                if (cost < bcost)
+                {
+                    bcost = cost;
+                    bdir = i;
+                }
+            }
+            wv.nq = 0;
+            bx = s16(bx + k_square1[bdir][0]);
+            by = s16(by + k_square1[bdir][1]);
+            if (++sub_it < qpel_iters)
+            {
+                for (int i = 1; i <= qpel_dirs; i++)
+                    q_push(wv, s16(bx + k_square1[i][0]), s16(by + k_square1[i][1]), MV_COST);
+            }
+            else
+                st = ST_DONE;
+            break;
+        }
+
+        default:
+            st = ST_DONE;
+            break;
+        }
+    }
+#undef IN_RANGE
+    if (wv.lane == 0)
+    {
+        out->cost = bcost;
+        out->mvx = (int16_t)bx;
+        out->mvy = (int16_t)by;
+    }
+}
+
+__global__ __launch_bounds__(64) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
+                                                x265_hip_me_result *out)
+{
+    __shared__ WaveLds lds;
+    const int id = blockIdx.x;
+    if (id >= n)
+        return;
+    const x265_hip_me_job &j = jobs[id];
+    Wave wv;
+    wave_init(wv, &lds, j.pu_w, j.pu_h);
+    const PlaneDesc fp = tabs->planes[j.fenc_plane], rp = tabs->planes[j.ref_plane];
+    wv.stride = rp.stride;
+    wv.ref = rp.origin + (long)j.pu_y * rp.stride + j.pu_x;
+    wv.tab = tabs->costtab[j.qp];
+    wv.mvpx = j.qmvp_x;
+    wv.mvpy = j.qmvp_y;
+    load_fenc(wv, fp.origin + (long)j.pu_y * fp.stride + j.pu_x, fp.stride);
+    motion_estimate(wv, j, &out[id]);
+}
+
+__global__ __launch_bounds__(64) void cost_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
+                                                  int32_t *out)
+{
+    __shared__ WaveLds lds;
+    const int id = blockIdx.x;
+    if (id >= n)
+        return;
+    const x265_hip_cost_req &r = reqs[id];
+    Wave wv;
+    wave_init(wv, &lds, r.pu_w, r.pu_h);
+    const PlaneDesc fp = tabs->planes[r.fenc_plane], rp = tabs->planes[r.ref_plane];
+    wv.stride = rp.stride;
+    wv.ref = rp.origin + (long)r.pu_y * rp.stride + r.pu_x;
+    load_fenc(wv, fp.origin + (long)r.pu_y * fp.stride + r.pu_x, fp.stride);
+    q_push(wv, r.qmv_x, r.qmv_y, MV_NONE);
+    q_eval(wv, r.metric);
+    if (wv.lane == 0)
+        out[id] = wv.vc;
+}
+
+void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st)
+{
+    if (n > 0)
+        hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, st, tabs, jobs, n, out);
+}
+
+void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, hipStream_t st)
+{
+    if (n > 0)
+        hipLaunchKernelGGL(cost_kernel, dim3(n), dim3(64), 0, st, tabs, reqs, n, out);
+}
+
+} // namespace x265hip

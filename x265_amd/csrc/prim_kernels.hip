@@ -1,0 +1,86 @@
+// prim_kernels.hip -- single primitive calls on raw device pointers (gfx950): the kernels behind the
+// function-pointer table (sad / sad_x3 / sad_x4 / satd, luma_hpp / vpp / hps / vsp).
+#include "kernels.h"
+#include "me_device.h"
+
+namespace x265hip {
+
+// ---------------------------------------------------------------------------------------------
+// primitive-level kernels: one call of sad / sad_x3 / sad_x4 / satd on raw device pointers
+
+__global__ __launch_bounds__(64) void prim_cmp_kernel(PrimCmpArgs a, int32_t *out)
+{
+    __shared__ int acc[4];
+    const int lane = threadIdx.x;
+    if (lane < 4)
+        acc[lane] = 0;
+    wave_sync();
+    const int ntx = a.w >> 2, nt = ntx * (a.h >> 2);
+    const int total = a.nref * nt;
+    for (int i = lane; i < total; i += 64)
+    {
+        int c = i / nt, t = i - c * nt;
+        int ty = t / ntx, tx = t - ty * ntx;
+        int pix[4][4];
+        ref_tile(a.fref[c] + (long)(4 * ty) * a.rstride + 4 * tx, a.rstride, 0, 0, pix);
+        int v = tile_metric(a.fenc + (long)(4 * ty) * a.fstride + 4 * tx, a.fstride, pix, a.metric);
+        atomicAdd(&acc[c], v);
+    }
+    wave_sync();
+    if (lane < a.nref)
+        out[lane] = acc[lane];
+}
+
+// luma_hpp / luma_vpp / luma_hps / luma_vsp on raw device pointers, one thread per output sample
+__global__ __launch_bounds__(256) void prim_filter_kernel(PrimFilterArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.w * a.rows)
+        return;
+    const int y = idx / a.w, x = idx - y * a.w;
+    int c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        c[k] = k_taps[a.coeff][k];
+    int acc = 0;
+    if (a.kind == PRIM_HPP || a.kind == PRIM_HPS)
+    {
+        const uint8_t *p = (const uint8_t *)a.src + (long)y * a.sstride + x - 3;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            acc += p[k] * c[k];
+        if (a.kind == PRIM_HPP)
+            ((uint8_t *)a.dst)[(long)y * a.dstride + x] = (uint8_t)clip_pixel((acc + 32) >> 6);
+        else
+            ((int16_t *)a.dst)[(long)y * a.dstride + x] = (int16_t)(acc - 8192);
+    }
+    else if (a.kind == PRIM_VPP)
+    {
+        const uint8_t *p = (const uint8_t *)a.src + (long)(y - 3) * a.sstride + x;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            acc += p[(long)k * a.sstride] * c[k];
+        ((uint8_t *)a.dst)[(long)y * a.dstride + x] = (uint8_t)clip_pixel((acc + 32) >> 6);
+    }
+    else // PRIM_VSP
+    {
+        const int16_t *p = (const int16_t *)a.src + (long)(y - 3) * a.sstride + x;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            acc += p[(long)k * a.sstride] * c[k];
+        ((uint8_t *)a.dst)[(long)y * a.dstride + x] = (uint8_t)clip_pixel((acc + 2048 + (8192 << 6)) >> 12);
+    }
+}
+
+void launch_prim_cmp(const PrimCmpArgs &a, int32_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(prim_cmp_kernel, dim3(1), dim3(64), 0, st, a, out);
+}
+
+void launch_prim_filter(const PrimFilterArgs &a, hipStream_t st)
+{
+    const int total = a.w * a.rows;
+    hipLaunchKernelGGL(prim_filter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
+}
+
+} // namespace x265hip
