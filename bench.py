@@ -214,6 +214,11 @@ def main():
                   "sample": f"{mp} pass(es) over one picture's {len(mj)} motionEstimate calls, {mdt:.1f} s"}
 
     if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, raw)
+            t = json.load(open(tpath))["fullsearch2_kernel"]
+            traffic = (t["fetch_kib"] + t["write_kib"]) * 1024
         total_units = units * world
         k_ms = ev_fs / args.steps
         px_ops = positions / args.steps * 4096  # 64x64 pixel-ops per position per CTU with full 8x8 reuse
@@ -234,7 +239,8 @@ def main():
                          "kernel_ms_per_frame": ev_me / args.steps},
             "roofline": {"bound": "valu", "achieved": px_ops / (k_ms * 1e-3) / 1e12, "peak": PX_PEAK / 1e12,
                          "unit": "Tpixel-op/s", "frac": px_ops / (k_ms * 1e-3) / PX_PEAK,
-                         "kernel": "fullsearch_kernel", "kernel_ms": k_ms, "traffic": None,
+                         "kernel": "fullsearch2_kernel", "kernel_ms": k_ms, "traffic": traffic,
+                         "algorithmic_bytes": alg_bytes,
                          "hbm": {"achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
                                  "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK}},
         }
