@@ -53,6 +53,12 @@ __device__ __forceinline__ unsigned mad16_256(unsigned packed, unsigned add)
 }
 
 template <int CTRL>
+__device__ __forceinline__ unsigned dpp_get(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+template <int CTRL>
 __device__ __forceinline__ unsigned dpp_add(unsigned v)
 {
     return v + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
@@ -138,11 +144,17 @@ __global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTab
         for (int i = 0; i < 4; i++)
             cx[i] = tab_at(tab, j.qmvp_x, fs_s16((j.mvmin_x + 4 * gc + i) << 2));
 
-        unsigned best8[4][4], best16[4], best32[4], best64[4];
+        // 32x32 and 64x64 sums are reduce-scattered over the quad: lane keeps x position (lane & 3)
+        const int xl = lane & 3;
+        const unsigned sh_keep = (xl & 1) * 16, sh_send = 16 - sh_keep;
+        const bool keep_b = (xl & 2) != 0;
+        const unsigned cxl = cx[xl];
+
+        unsigned best8[4][4], best16[4], best32 = 0xffffffffu, best64 = 0xffffffffu;
 #pragma unroll
         for (int i = 0; i < 4; i++)
         {
-            best16[i] = best32[i] = best64[i] = 0xffffffffu;
+            best16[i] = 0xffffffffu;
 #pragma unroll
             for (int b = 0; b < 4; b++)
                 best8[b][i] = 0xffffffffu;
@@ -210,15 +222,16 @@ __global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTab
                     best16[1] = min(best16[1], mad16_256<1>(slo, kmv[1]));
                     best16[2] = min(best16[2], mad16_256<0>(shi, kmv[2]));
                     best16[3] = min(best16[3], mad16_256<1>(shi, kmv[3]));
-                    unsigned v[4] = { slo & 0xffffu, slo >> 16, shi & 0xffffu, shi >> 16 };
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                    {
-                        unsigned s32 = dpp_add<0x4E>(dpp_add<0xB1>(v[i]));     // 4 lanes of a quad = one 32x32
-                        best32[i] = min(best32[i], (s32 << 8) + kmv[i]);
-                        unsigned s64 = dpp_add<0x128>(dpp_add<0x124>(s32));    // row_ror 4, 8: the four quads
-                        best64[i] = min(best64[i], (s64 << 8) + kmv[i]);
-                    }
+                    // the four lanes of a quad hold the four 16x16 blocks of one 32x32.  Exchange with
+                    // lane ^ 1 (each keeps two of the four x positions), then with lane ^ 2: the lane ends
+                    // with the 32x32 sum of x position (lane & 3); row_ror 4 and 8 add the four quads.
+                    const unsigned pa = __builtin_amdgcn_ubfe(slo, sh_keep, 16) + dpp_get<0xB1>(__builtin_amdgcn_ubfe(slo, sh_send, 16));
+                    const unsigned pb = __builtin_amdgcn_ubfe(shi, sh_keep, 16) + dpp_get<0xB1>(__builtin_amdgcn_ubfe(shi, sh_send, 16));
+                    const unsigned s32 = (keep_b ? pb : pa) + dpp_get<0x4E>(keep_b ? pa : pb);
+                    const unsigned kmvl = (((cxl + cyv) & 0xffffu) << 8) | (unsigned)y;
+                    best32 = min(best32, (s32 << 8) + kmvl);
+                    const unsigned s64 = dpp_add<0x128>(dpp_add<0x124>(s32));
+                    best64 = min(best64, (s64 << 8) + kmvl);
                 }
             }
         }
@@ -240,10 +253,9 @@ __global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTab
                 atomicMin(&L.best[21 + (y8 >> 3) * 8 + (x8 >> 3)], fold(best8[b]));
             }
             atomicMin(&L.best[5 + (by16 >> 4) * 4 + (bx16 >> 4)], fold(best16));
-            if (sub == 0)
-                atomicMin(&L.best[1 + q32], fold(best32));
-            if (q == 0)
-                atomicMin(&L.best[0], fold(best64));
+            atomicMin(&L.best[1 + q32], ((unsigned long long)best32 << 8) | (unsigned)(4 * g + xl));
+            if (q < 4)
+                atomicMin(&L.best[0], ((unsigned long long)best64 << 8) | (unsigned)(4 * g + xl));
         }
     }
     __syncthreads();
