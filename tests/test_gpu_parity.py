@@ -71,6 +71,35 @@ def test_fullsearch_ctu(gpu_ctx, oracle, small_seq, costtabs):
         assert len(bad) == 0, f"ctu {k}: pu {bad[0]} got {got[k][bad[0]]} want {want[bad[0]]}"
 
 
+def test_fullsearch_window_shapes(gpu_ctx, oracle, small_seq, costtabs):
+    """window widths around the multiples of four (the extra-column pass), narrow and tall windows,
+    the largest window the kernel takes (132 x 132), and a flat reference where every position ties on SAD"""
+    from x265_amd import lib, synth
+    shapes = [(nx, ny) for nx in (1, 2, 3, 4, 5, 6, 7, 8, 9, 127, 128, 129, 130, 131, 132) for ny in (1, 2, 31, 32, 33, 129)]
+    shapes += [(129, ny) for ny in (63, 64, 65, 96, 97, 128, 130, 131, 132)] + [(132, 132)]
+    rng = np.random.default_rng(77)
+    flat = synth.Plane(np.full((240, 416), 93, np.uint8))
+    gpu_ctx.plane_upload(5, flat.buf, flat.stride, flat.origin)
+    pl = _planes(small_seq) + [None, None, flat.as_tuple()]
+    jobs = np.zeros(len(shapes) + 6, lib.CTU_JOB)
+    for k, j in enumerate(jobs):
+        nx, ny = shapes[k] if k < len(shapes) else (129, 129)
+        j["fenc_plane"], j["ref_plane"] = 1, (0 if k < len(shapes) else 5)
+        j["ctu_x"], j["ctu_y"] = 64 * int(rng.integers(1, 5)), 64 * int(rng.integers(1, 2))
+        lox, loy = -int(rng.integers(0, nx)) if nx < 66 else -(nx // 2), -int(rng.integers(0, ny)) if ny < 66 else -(ny // 2)
+        j["mvmin_x"], j["mvmin_y"], j["mvmax_x"], j["mvmax_y"] = lox, loy, lox + nx - 1, loy + ny - 1
+        j["qmvp_x"], j["qmvp_y"] = int(rng.integers(-60, 60)), int(rng.integers(-60, 60))
+        j["qp"] = int(rng.integers(20, 45))
+    got = gpu_ctx.fullsearch(jobs)
+    for k, j in enumerate(jobs):
+        want = oracle.ctu_fullsearch(pl[1], pl[int(j["ref_plane"])], costtabs[int(j["qp"])], int(j["ctu_x"]), int(j["ctu_y"]),
+                                     (int(j["mvmin_x"]), int(j["mvmin_y"])), (int(j["mvmax_x"]), int(j["mvmax_y"])),
+                                     (int(j["qmvp_x"]), int(j["qmvp_y"])))
+        bad = np.nonzero(got[k] != want)[0]
+        assert len(bad) == 0, f"ctu {k} {j}: pu {bad[0]} got {got[k][bad[0]]} want {want[bad[0]]}"
+    gpu_ctx.plane_release(5)
+
+
 def test_primitive_table(oracle):
     """the function-pointer table (host pointers), inputs shaped like the reference's TestBench:
     random / all-0 / all-255 buffers, fref stride 64 and FENC_STRIDE-5, offsets stepping by 32

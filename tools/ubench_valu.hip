@@ -44,6 +44,50 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
             asm volatile("v_pk_min_u16 %0, %0, %4\n v_pk_min_u16 %1, %1, %4\n v_pk_min_u16 %2, %2, %4\n v_pk_min_u16 %3, %3, %4"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(f));
         }
+#define ASM4(OPC, TAIL)                                                                                          \
+    asm volatile(OPC " %0, %0, " TAIL "\n " OPC " %1, %1, " TAIL "\n " OPC " %2, %2, " TAIL "\n " OPC " %3, %3, " TAIL  \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)                                                         \
+                 : "v"(f), "s"(1024u))
+        else if (OP == 6)
+            ASM4("v_mad_u32_u16", "%5, %4");
+        else if (OP == 7)
+            ASM4("v_lshl_add_u32", "10, %4");
+        else if (OP == 8)
+            ASM4("v_min3_u32", "%4, %4");
+        else if (OP == 9)
+            ASM4("v_min_u32", "%4");
+        else if (OP == 10)
+            ASM4("v_bfe_u32", "%4, 16");
+        else if (OP == 11)
+            ASM4("v_add3_u32", "%4, %4");
+        else if (OP == 12)
+            ASM4("v_mad_u32_u24", "%5, %4");
+        else if (OP == 13)
+            ASM4("v_and_or_b32", "%4, %4");
+        else if (OP == 14)
+            ASM4("v_perm_b32", "%4, %4");
+        else if (OP == 15)
+        {
+            asm volatile("v_add_u32_dpp %0, %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                         "v_add_u32_dpp %1, %1, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                         "v_add_u32_dpp %2, %2, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                         "v_add_u32_dpp %3, %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(f));
+        }
+        else if (OP == 16)
+        {
+            asm volatile("v_add_u32_sdwa %0, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                         "v_add_u32_sdwa %1, %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                         "v_add_u32_sdwa %2, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+                         "v_add_u32_sdwa %3, %3, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(f));
+        }
+        else if (OP == 17)
+            ASM4("v_mul_lo_u32", "%4");
+        else if (OP == 18)
+            ASM4("v_pk_mad_u16", "%4, %4");
+        else if (OP == 19)
+            ASM4("v_dot4_u32_u8", "%4, %0");
         else if (OP == 5)
         {
             q0 = __builtin_amdgcn_mqsad_pk_u16_u8(r, f, q0);
@@ -85,6 +129,20 @@ int main()
     run<5>("v_mqsad_pk_u16_u8", d);
     run<2>("v_pk_add_u16", d);
     run<4>("v_pk_min_u16", d);
+    run<6>("v_mad_u32_u16", d);
+    run<12>("v_mad_u32_u24", d);
+    run<7>("v_lshl_add_u32", d);
+    run<8>("v_min3_u32", d);
+    run<9>("v_min_u32", d);
+    run<10>("v_bfe_u32", d);
+    run<11>("v_add3_u32", d);
+    run<13>("v_and_or_b32", d);
+    run<14>("v_perm_b32", d);
+    run<15>("v_add_u32_dpp", d);
+    run<16>("v_add_u32_sdwa", d);
+    run<17>("v_mul_lo_u32", d);
+    run<18>("v_pk_mad_u16", d);
+    run<19>("v_dot4_u32_u8", d);
     hipFree(d);
     return 0;
 }

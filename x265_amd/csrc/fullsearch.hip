@@ -12,13 +12,17 @@
 //     four SADs of 4 pixels at four consecutive x positions, accumulated as 4 x u16.  Eight
 //     positions (y .. y+7) are in flight per lane in a rotating set of accumulators; one completes
 //     per step.
-//   * A wave's 16-lane DPP row holds the 16 blocks of one x group, so 32x32 and 64x64 sums are two
-//     quad_perm and two row_ror additions; 16x16 sums are plain 32-bit adds of the packed pairs
-//     (16x16 SAD <= 65280, no carry between halves).
-//   * Per PU and x position a lane keeps min((cost << 8) | y); ascending y and the packed y make the
-//     first minimum win.  At the end (cost, y, x) keys meet in LDS through 64-bit atomic minima.
-//   * x positions beyond a multiple of four (the 129th column of a +-64 window) go through a small
-//     tail pass that evaluates one position per thread with v_sad_u8.
+//   * A wave's 16-lane DPP row holds the 16 blocks of one x group.  16x16 sums are plain 32-bit adds of
+//     the packed pairs (16x16 SAD <= 65280, no carry between halves).  32x32 sums are reduce-scattered
+//     over the quad (two quad_perm exchanges; lane keeps x position lane & 3), 64x64 sums add the four
+//     quads with row_ror 4 and 8.
+//   * Per PU a lane keeps min((cost << 10) | (y << 2) | (x & 3)) over its four x positions and all y
+//     (v_mad_u32_u16 builds a key from a packed u16 SAD, v_min3_u32 folds two keys per instruction);
+//     the unsigned minimum is the first minimum in raster order.  At the end the keys are widened to
+//     (cost, y, x) and meet in LDS through 64-bit atomic minima.
+//   * Columns beyond a multiple of four (the 129th of a +-64 window) are a second pass through the same
+//     loop: all 32 lane rows take those columns and 1/32 of the window rows each.
+//   * Windows narrower than four columns go through a one-position-per-thread v_sad_u8 loop.
 #include "kernels.h"
 #include "me_device.h"
 
@@ -28,6 +32,7 @@ namespace x265hip {
 #define FS_WS 200 // window row pitch in bytes (>= 64 + 132 - 1 + 3, multiple of 4)
 #define FS_WROWS (64 + FS_MAXPOS - 1 + 8)
 #define FS_THREADS 512
+#define FS_STAGE 5 // 16-byte pieces of the window per thread: ceil(195 * 13 / 512)
 
 struct Fs2Lds
 {
@@ -35,20 +40,39 @@ struct Fs2Lds
     uint8_t fenc[64 * 64];
     unsigned long long best[X265_HIP_PUS_PER_CTU]; // (cost << 16) | (y << 8) | x
     unsigned pass_best[X265_HIP_PUS_PER_CTU];
-    unsigned cy[FS_MAXPOS];
+    unsigned cy[FS_MAXPOS + 24]; // entry y + 8; read one step ahead, so y runs from -7 to ny + 8
 };
+
+__device__ __forceinline__ uint4 ld16u(const uint8_t *p)
+{
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
 
 __device__ __forceinline__ int fs_s16(int v) { return (int)(int16_t)v; }
 
-// (half of `packed`) * 256 + add in one instruction
+// Search keys: (cost << 10) | (y << 2) | (x & 3).  cost < 2^21 (64x64 SAD + mvcost), y < 256, so a key
+// fits 32 bits and the unsigned minimum is the first minimum in raster order among the four x
+// positions of a lane.
+#define FS_KSHIFT 10
+
+// (half of `packed`) * 1024 + add in one instruction
 template <int HI>
-__device__ __forceinline__ unsigned mad16_256(unsigned packed, unsigned add)
+__device__ __forceinline__ unsigned mad16_key(unsigned packed, unsigned add)
 {
     unsigned r;
     if (HI)
-        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(packed), "s"(256u), "v"(add));
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(packed), "s"(1u << FS_KSHIFT), "v"(add));
     else
-        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(packed), "s"(256u), "v"(add));
+        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(packed), "s"(1u << FS_KSHIFT), "v"(add));
+    return r;
+}
+
+__device__ __forceinline__ unsigned min3u(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 
@@ -94,21 +118,40 @@ __global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTab
 
     // ---- stage source CTU, reference window, per-row cost, result keys --------------------------
     {
+        // 16-byte pieces, every load of a thread issued before its first LDS store.  A window row is at
+        // most 195 bytes: 13 pieces, the 13th stored as 8 bytes (row pitch 200).  Loads run up to 12 bytes
+        // past the window inside the plane row (planes carry 64 bytes of slack after the last row).
         const uint8_t *fsrc = fp.origin + (long)j.ctu_y * fp.stride + j.ctu_x;
-        for (int i = tid; i < 64 * 16; i += FS_THREADS)
-        {
-            int y = i >> 4, x = i & 15;
-            *(uint32_t *)(L.fenc + y * 64 + 4 * x) = ld4u(fsrc + (long)y * fp.stride + 4 * x);
-        }
         const uint8_t *rsrc = rp.origin + (long)(j.ctu_y + j.mvmin_y) * rp.stride + j.ctu_x + j.mvmin_x;
-        const int wdw = (ww + 3) >> 2;
-        for (int i = tid; i < wh * wdw; i += FS_THREADS)
+        const int w16 = (ww + 15) >> 4, npiece = wh * w16; // <= 195 * 13 <= FS_STAGE * FS_THREADS
+        uint4 fv = {}, wv[FS_STAGE];
+        int wo[FS_STAGE];
+        if (tid < 256)
+            fv = ld16u(fsrc + (long)(tid >> 2) * fp.stride + 16 * (tid & 3));
+#pragma unroll
+        for (int k = 0; k < FS_STAGE; k++)
         {
-            int y = i / wdw, x = i - y * wdw;
-            *(uint32_t *)(L.win + y * FS_WS + 4 * x) = ld4u(rsrc + (long)y * rp.stride + 4 * x);
+            const int i = tid + k * FS_THREADS;
+            wo[k] = -1;
+            if (i < npiece)
+            {
+                const int y = i / w16, c = i - y * w16;
+                wv[k] = ld16u(rsrc + (long)y * rp.stride + 16 * c);
+                wo[k] = y * FS_WS + 16 * c;
+            }
         }
-        if (tid < ny)
-            L.cy[tid] = tab_at(tab, j.qmvp_y, fs_s16((j.mvmin_y + tid) << 2));
+        if (tid < 256)
+            *(uint4 *)(L.fenc + 16 * tid) = fv;
+#pragma unroll
+        for (int k = 0; k < FS_STAGE; k++)
+            if (wo[k] >= 0)
+            {
+                *(uint2 *)(L.win + wo[k]) = make_uint2(wv[k].x, wv[k].y);
+                if (wo[k] % FS_WS < 192)
+                    *(uint2 *)(L.win + wo[k] + 8) = make_uint2(wv[k].z, wv[k].w);
+            }
+        if (tid < ny) // y part of the key: (cost_y << 10) | (y << 2)
+            L.cy[tid + 8] = ((unsigned)tab_at(tab, j.qmvp_y, fs_s16((j.mvmin_y + tid) << 2)) << FS_KSHIFT) | ((unsigned)tid << 2);
         if (tid < X265_HIP_PUS_PER_CTU)
         {
             L.best[tid] = ~0ull;
@@ -117,15 +160,18 @@ __global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTab
     }
     __syncthreads();
 
-    // ---- main pass: x positions [0, 4G) --------------------------------------------------------
+    // ---- qsad passes ---------------------------------------------------------------------------
+    // pass 0: x positions [0, 4G), one group of four per 16-lane row, all ny rows.
+    // pass 1: the remaining columns [4G, nx) (the 129th of a +-64 window): every 16-lane row takes the
+    //         same four columns and a slice of ceil(ny / 32) rows (slices may overlap: a position
+    //         evaluated twice yields the same key twice).
     const int G = min(32, nx >> 2);
+    const int npass = G == 0 ? 0 : (nx > 4 * G ? 2 : 1);
     if (G > 0)
     {
         const int lane = tid & 63, wave = tid >> 6;
         const int q = lane & 15;                 // 16x16 block, z-order: bits 3:2 = 32x32 quadrant
-        const int g = wave * 4 + (lane >> 4);    // x group
-        const bool active = g < G;
-        const int gc = active ? g : G - 1;
+        const int g = wave * 4 + (lane >> 4);    // 16-lane row
         const int q32 = q >> 2, sub = q & 3;
         const int bx16 = (q32 & 1) * 32 + (sub & 1) * 16, by16 = (q32 >> 1) * 32 + (sub >> 1) * 16;
 
@@ -139,26 +185,10 @@ __global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTab
             f[r][2] = v.z;
             f[r][3] = v.w;
         }
-        unsigned cx[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            cx[i] = tab_at(tab, j.qmvp_x, fs_s16((j.mvmin_x + 4 * gc + i) << 2));
-
         // 32x32 and 64x64 sums are reduce-scattered over the quad: lane keeps x position (lane & 3)
         const int xl = lane & 3;
         const unsigned sh_keep = (xl & 1) * 16, sh_send = 16 - sh_keep;
         const bool keep_b = (xl & 2) != 0;
-        const unsigned cxl = cx[xl];
-
-        unsigned best8[4][4], best16[4], best32 = 0xffffffffu, best64 = 0xffffffffu;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-        {
-            best16[i] = 0xffffffffu;
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-                best8[b][i] = 0xffffffffu;
-        }
 
         uint64_t acc[8][4]; // [slot][TL, TR, BL, BR], 4 x u16 each
 #pragma unroll
@@ -167,18 +197,72 @@ __global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTab
             for (int b = 0; b < 4; b++)
                 acc[k][b] = 0;
 
-        const uint32_t *wtop = (const uint32_t *)(L.win + by16 * FS_WS + bx16 + 4 * gc);
-        const int S = ny + 7;
+#pragma clang loop unroll(disable)
+        for (int pass = 0; pass < npass; pass++)
+        {
+        int xbase, ybase, npos;
+        bool active;
+        if (pass == 0)
+        {
+            active = g < G;
+            xbase = 4 * (active ? g : G - 1);
+            ybase = 0;
+            npos = ny;
+        }
+        else
+        {
+            npos = (ny + 31) >> 5;
+            active = true;
+            xbase = 4 * G;
+            ybase = min(g * npos, ny - npos);
+        }
+        unsigned cx[4];  // x part of the key: (cost_x << 10) | i
+        unsigned inv[4]; // top bit set for columns outside the window: such keys never win
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            cx[i] = ((unsigned)tab_at(tab, j.qmvp_x, fs_s16((j.mvmin_x + xbase + i) << 2)) << FS_KSHIFT) | (unsigned)i;
+            inv[i] = xbase + i < nx ? 0u : 0x80000000u;
+        }
+        const unsigned cxl = cx[xl], invl = inv[xl]; // cxl carries i = xl in its low bits
+
+        unsigned best8[4], best16 = 0xffffffffu, best32 = 0xffffffffu, best64 = 0xffffffffu;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            best8[b] = 0xffffffffu;
+
+        const uint32_t *wtop = (const uint32_t *)(L.win + (by16 + ybase) * FS_WS + bx16 + xbase);
+        const unsigned *cyp = L.cy + ybase;
+        const int S = npos + 7;
+        // the rows of step s + 1 are fetched from LDS while step s computes
+        uint32_t nt[5], nb[5];
+        unsigned ncy = cyp[1];
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+        {
+            nt[c] = wtop[c];
+            nb[c] = wtop[8 * (FS_WS / 4) + c];
+        }
         for (int s0 = 0; s0 < S; s0 += 8)
         {
 #pragma unroll
             for (int jj = 0; jj < 8; jj++)
             {
                 const int s = s0 + jj;
-                const uint32_t *pt = wtop + s * (FS_WS / 4);
-                const uint32_t *pb = pt + 8 * (FS_WS / 4);
-                const uint32_t t0 = pt[0], t1 = pt[1], t2 = pt[2], t3 = pt[3], t4 = pt[4];
-                const uint32_t b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3], b4 = pb[4];
+                const uint32_t t0 = nt[0], t1 = nt[1], t2 = nt[2], t3 = nt[3], t4 = nt[4];
+                const uint32_t b0 = nb[0], b1 = nb[1], b2 = nb[2], b3 = nb[3], b4 = nb[4];
+                const unsigned cyv = ncy; // cyp[(s - 7) + 8]
+                {
+                    ncy = cyp[s + 2];
+                    const uint32_t *pt = wtop + (s + 1) * (FS_WS / 4); // row <= 48 + 144 + 8 < FS_WROWS
+                    const uint32_t *pb = pt + 8 * (FS_WS / 4);
+#pragma unroll
+                    for (int c = 0; c < 5; c++)
+                    {
+                        nt[c] = pt[c];
+                        nb[c] = pb[c];
+                    }
+                }
                 const uint64_t t01 = ((uint64_t)t1 << 32) | t0, t12 = ((uint64_t)t2 << 32) | t1;
                 const uint64_t t23 = ((uint64_t)t3 << 32) | t2, t34 = ((uint64_t)t4 << 32) | t3;
                 const uint64_t b01 = ((uint64_t)b1 << 32) | b0, b12 = ((uint64_t)b2 << 32) | b1;
@@ -197,71 +281,64 @@ __global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTab
                 }
                 // position y = s - 7 is complete in slot (jj + 1) & 7
                 const int y = s - 7;
-                if (y >= 0 && y < ny)
+                if (y >= 0 && y < npos)
                 {
                     const int k = (jj + 1) & 7;
-                    const unsigned cyv = L.cy[y];
+                    const unsigned kmask = (1u << (16 + FS_KSHIFT)) - 1; // mvcost() wraps at 16 bits
                     unsigned kmv[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        kmv[i] = (((cx[i] + cyv) & 0xffffu) << 8) | (unsigned)y; // mvcost() wraps at 16 bits
+                        kmv[i] = ((cx[i] + cyv) & kmask) | inv[i]; // v_and_or_b32
                     unsigned lo[4], hi[4];
 #pragma unroll
                     for (int b = 0; b < 4; b++)
                     {
                         lo[b] = (unsigned)acc[k][b];
                         hi[b] = (unsigned)(acc[k][b] >> 32);
-                        best8[b][0] = min(best8[b][0], mad16_256<0>(lo[b], kmv[0]));
-                        best8[b][1] = min(best8[b][1], mad16_256<1>(lo[b], kmv[1]));
-                        best8[b][2] = min(best8[b][2], mad16_256<0>(hi[b], kmv[2]));
-                        best8[b][3] = min(best8[b][3], mad16_256<1>(hi[b], kmv[3]));
+                        best8[b] = min3u(best8[b], mad16_key<0>(lo[b], kmv[0]), mad16_key<1>(lo[b], kmv[1]));
+                        best8[b] = min3u(best8[b], mad16_key<0>(hi[b], kmv[2]), mad16_key<1>(hi[b], kmv[3]));
                     }
                     // 16x16: the packed pairs add without carry (4 * 16320 < 65536)
                     const unsigned slo = lo[0] + lo[1] + lo[2] + lo[3], shi = hi[0] + hi[1] + hi[2] + hi[3];
-                    best16[0] = min(best16[0], mad16_256<0>(slo, kmv[0]));
-                    best16[1] = min(best16[1], mad16_256<1>(slo, kmv[1]));
-                    best16[2] = min(best16[2], mad16_256<0>(shi, kmv[2]));
-                    best16[3] = min(best16[3], mad16_256<1>(shi, kmv[3]));
+                    best16 = min3u(best16, mad16_key<0>(slo, kmv[0]), mad16_key<1>(slo, kmv[1]));
+                    best16 = min3u(best16, mad16_key<0>(shi, kmv[2]), mad16_key<1>(shi, kmv[3]));
                     // the four lanes of a quad hold the four 16x16 blocks of one 32x32.  Exchange with
                     // lane ^ 1 (each keeps two of the four x positions), then with lane ^ 2: the lane ends
                     // with the 32x32 sum of x position (lane & 3); row_ror 4 and 8 add the four quads.
                     const unsigned pa = __builtin_amdgcn_ubfe(slo, sh_keep, 16) + dpp_get<0xB1>(__builtin_amdgcn_ubfe(slo, sh_send, 16));
                     const unsigned pb = __builtin_amdgcn_ubfe(shi, sh_keep, 16) + dpp_get<0xB1>(__builtin_amdgcn_ubfe(shi, sh_send, 16));
                     const unsigned s32 = (keep_b ? pb : pa) + dpp_get<0x4E>(keep_b ? pa : pb);
-                    const unsigned kmvl = (((cxl + cyv) & 0xffffu) << 8) | (unsigned)y;
-                    best32 = min(best32, (s32 << 8) + kmvl);
+                    const unsigned kmvl = ((cxl + cyv) & kmask) | invl;
+                    best32 = min(best32, (s32 << FS_KSHIFT) + kmvl);
                     const unsigned s64 = dpp_add<0x128>(dpp_add<0x124>(s32));
-                    best64 = min(best64, (s64 << 8) + kmvl);
+                    best64 = min(best64, (s64 << FS_KSHIFT) + kmvl);
                 }
             }
         }
 
         if (active)
         {
-            // fold the four x positions (lowest x wins ties), then meet the other lanes in LDS
-            auto fold = [&](const unsigned *b4) {
-                unsigned long long r = ~0ull;
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    r = u64min(r, ((unsigned long long)b4[i] << 8) | (unsigned)(4 * g + i));
-                return r;
+            // widen to (cost << 16) | (y << 8) | x and meet the other lanes in LDS
+            auto widen = [&](unsigned k) {
+                return ((unsigned long long)(k >> FS_KSHIFT) << 16) | (((k >> 2) & 255u) << 8) | (unsigned)(xbase + (k & 3u));
             };
 #pragma unroll
             for (int b = 0; b < 4; b++)
             {
                 const int x8 = bx16 + (b & 1) * 8, y8 = by16 + (b >> 1) * 8;
-                atomicMin(&L.best[21 + (y8 >> 3) * 8 + (x8 >> 3)], fold(best8[b]));
+                atomicMin(&L.best[21 + (y8 >> 3) * 8 + (x8 >> 3)], widen(best8[b]));
             }
-            atomicMin(&L.best[5 + (by16 >> 4) * 4 + (bx16 >> 4)], fold(best16));
-            atomicMin(&L.best[1 + q32], ((unsigned long long)best32 << 8) | (unsigned)(4 * g + xl));
+            atomicMin(&L.best[5 + (by16 >> 4) * 4 + (bx16 >> 4)], widen(best16));
+            atomicMin(&L.best[1 + q32], widen(best32));
             if (q < 4)
-                atomicMin(&L.best[0], ((unsigned long long)best64 << 8) | (unsigned)(4 * g + xl));
+                atomicMin(&L.best[0], widen(best64));
         }
+        } // pass
     }
     __syncthreads();
 
-    // ---- tail pass: x positions [4G, nx), one position per thread, raster order = thread order --
-    const int ntail = nx - 4 * G;
+    // ---- windows narrower than four columns: one position per thread, raster order = thread order --
+    const int ntail = G == 0 ? nx : 0;
     const int total = ntail * ny;
     for (int base = 0; base < total; base += FS_THREADS)
     {
