@@ -75,175 +75,202 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // ---- one 4x4 tile ---------------------------------------------------------------------------
+//
+// Pixels travel as packed pairs: P[row][0] = (x0, x1), P[row][1] = (x2, x3), 16 bits each, values 0..255.
+// The filters run on v_dot4_i32_i8: pixels are biased to signed bytes (p ^ 0x80 = p - 128), so a dot
+// product with the signed taps gives sum - 128 * 64 = sum - 8192 (every tap row sums to 64), which is
+// exactly luma_hps's intermediate; the pp filters fold + 8192 and the rounding into the accumulator seed.
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+#define X265HIP_PK8(a, b, c, d) \
+    ((uint32_t)((a) & 0xff) | ((uint32_t)((b) & 0xff) << 8) | ((uint32_t)((c) & 0xff) << 16) | ((uint32_t)((d) & 0xff) << 24))
+__device__ __constant__ const uint32_t k_taps_s8[4][2] = {
+    { X265HIP_PK8(0, 0, 0, 64), X265HIP_PK8(0, 0, 0, 0) },
+    { X265HIP_PK8(-1, 4, -10, 58), X265HIP_PK8(17, -5, 1, 0) },
+    { X265HIP_PK8(-1, 4, -11, 40), X265HIP_PK8(40, -11, 4, -1) },
+    { X265HIP_PK8(0, 1, -5, 17), X265HIP_PK8(58, -10, 4, -1) },
+};
+
+// out[x] = seed + sum_k (byte[x + k] of the 12 signed bytes d0:d1:d2) * tap[k], x = 0..3
+__device__ __forceinline__ void tap8x4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t tlo, uint32_t thi, int seed, int out[4])
+{
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+    {
+        const uint32_t lo = x ? __builtin_amdgcn_alignbyte(d1, d0, x) : d0;
+        const uint32_t hi = x ? __builtin_amdgcn_alignbyte(d2, d1, x) : d1;
+        out[x] = __builtin_amdgcn_sdot4((int)lo, (int)tlo, __builtin_amdgcn_sdot4((int)hi, (int)thi, seed, false), false);
+    }
+}
+
+__device__ __forceinline__ uint32_t pack2(int lo, int hi) { return (uint32_t)lo | ((uint32_t)hi << 16); } // v_lshl_or_b32
 
 // Fetch (or interpolate) the 4x4 reference tile whose top-left full-pel sample is `r`, for the
-// quarter-pel fraction (xf, yf).  Output pix[row][col] in 0..255.  All work stays in registers.
-__device__ __forceinline__ void ref_tile(const uint8_t *r_, int stride, int xf, int yf, int pix[4][4])
+// quarter-pel fraction (xf, yf).  All work stays in registers.
+__device__ __forceinline__ void ref_tile(const uint8_t *r_, int stride, int xf, int yf, uint32_t P[4][2])
 {
+    const uint32_t bias = 0x80808080u;
     if ((xf | yf) == 0)
     {
 #pragma unroll
         for (int y = 0; y < 4; y++)
         {
-            uint32_t d = ld4u(r_ + y * stride);
-#pragma unroll
-            for (int x = 0; x < 4; x++)
-                pix[y][x] = byte_of(d, x);
+            const uint32_t d = ld4u(r_ + y * stride);
+            P[y][0] = __builtin_amdgcn_perm(0, d, 0x0c010c00);
+            P[y][1] = __builtin_amdgcn_perm(0, d, 0x0c030c02);
         }
     }
     else if (yf == 0)
     {
         // luma_hpp: dst = clip((sum_k src[x-3+k]*c[k] + 32) >> 6)
-        int c[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            c[k] = k_taps[xf][k];
+        const uint32_t tlo = k_taps_s8[xf][0], thi = k_taps_s8[xf][1];
 #pragma unroll
         for (int y = 0; y < 4; y++)
         {
             const uint8_t *p = r_ + y * stride - 3;
-            uint32_t d0 = ld4u(p), d1 = ld4u(p + 4), d2 = ld4u(p + 8);
-            int s[11];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-            {
-                s[i] = byte_of(d0, i);
-                s[4 + i] = byte_of(d1, i);
-            }
-            s[8] = byte_of(d2, 0);
-            s[9] = byte_of(d2, 1);
-            s[10] = byte_of(d2, 2);
+            int h[4];
+            tap8x4(ld4u(p) ^ bias, ld4u(p + 4) ^ bias, ld4u(p + 8) ^ bias, tlo, thi, 8192 + 32, h);
 #pragma unroll
             for (int x = 0; x < 4; x++)
-            {
-                int acc = 0;
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    acc += s[x + k] * c[k];
-                pix[y][x] = clip_pixel((acc + 32) >> 6);
-            }
+                h[x] = clip_pixel(h[x] >> 6);
+            P[y][0] = pack2(h[0], h[1]);
+            P[y][1] = pack2(h[2], h[3]);
         }
     }
     else if (xf == 0)
     {
-        // luma_vpp: same rounding, taps run down the column.  Source rows stream through once and
-        // are scattered into the 16 running sums (row r feeds output row y with tap r - y).
-        int c[8];
+        // luma_vpp: same rounding, taps run down the column.  The 11 source rows are transposed
+        // (v_perm_b32) into four 12-byte column vectors, which then go through the same tap8x4.
+        const uint32_t tlo = k_taps_s8[yf][0], thi = k_taps_s8[yf][1];
+        uint32_t c[4][3];
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            c[k] = k_taps[yf][k];
-        int acc[4][4] = {};
-#pragma unroll
-        for (int r = 0; r < 11; r++)
+        for (int b = 0; b < 3; b++)
         {
-            uint32_t d = ld4u(r_ + (r - 3) * stride);
+            uint32_t d[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                d[i] = 4 * b + i < 11 ? ld4u(r_ + (4 * b + i - 3) * stride) ^ bias : 0u;
+            const uint32_t t0 = __builtin_amdgcn_perm(d[1], d[0], 0x05010400), t1 = __builtin_amdgcn_perm(d[1], d[0], 0x07030602);
+            const uint32_t t2 = __builtin_amdgcn_perm(d[3], d[2], 0x05010400), t3 = __builtin_amdgcn_perm(d[3], d[2], 0x07030602);
+            c[0][b] = __builtin_amdgcn_perm(t2, t0, 0x05040100);
+            c[1][b] = __builtin_amdgcn_perm(t2, t0, 0x07060302);
+            c[2][b] = __builtin_amdgcn_perm(t3, t1, 0x05040100);
+            c[3][b] = __builtin_amdgcn_perm(t3, t1, 0x07060302);
+        }
+        int v[4][4]; // [x][y]
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+        {
+            tap8x4(c[x][0], c[x][1], c[x][2], tlo, thi, 8192 + 32, v[x]);
 #pragma unroll
             for (int y = 0; y < 4; y++)
-                if (r - y >= 0 && r - y < 8)
-#pragma unroll
-                    for (int x = 0; x < 4; x++)
-                        acc[y][x] += byte_of(d, x) * c[r - y];
+                v[x][y] = clip_pixel(v[x][y] >> 6);
         }
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            P[y][0] = pack2(v[0][y], v[1][y]);
+            P[y][1] = pack2(v[2][y], v[3][y]);
+        }
+    }
+    else
+    {
+        // luma_hps (isRowExt = 1: rows -3 .. +7, value = sum - 8192, always inside int16) followed by
+        // luma_vsp: clip((sum_k im[y-3+k]*c[k] + 2048 + (8192 << 6)) >> 12), streamed row by row
+        const uint32_t tlo = k_taps_s8[xf][0], thi = k_taps_s8[xf][1];
+        const uint32_t vlo = k_taps_s8[yf][0], vhi = k_taps_s8[yf][1];
+        int cy[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            cy[k] = (int)(int8_t)(vlo >> (8 * k));
+            cy[4 + k] = (int)(int8_t)(vhi >> (8 * k));
+        }
+        int acc[4][4];
 #pragma unroll
         for (int y = 0; y < 4; y++)
 #pragma unroll
             for (int x = 0; x < 4; x++)
-                pix[y][x] = clip_pixel((acc[y][x] + 32) >> 6);
-    }
-    else
-    {
-        // luma_hps (isRowExt = 1: rows -3 .. +7, value = sum - 8192 kept as int16) followed by
-        // luma_vsp: clip((sum_k im[y-3+k]*c[k] + 2048 + (8192 << 6)) >> 12), streamed row by row
-        int cx[8], cy[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-        {
-            cx[k] = k_taps[xf][k];
-            cy[k] = k_taps[yf][k];
-        }
-        int acc[4][4] = {};
+                acc[y][x] = 2048 + (8192 << 6);
 #pragma unroll
         for (int r = 0; r < 11; r++)
         {
             const uint8_t *p = r_ + (r - 3) * stride - 3;
-            uint32_t d0 = ld4u(p), d1 = ld4u(p + 4), d2 = ld4u(p + 8);
-            int s[11];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-            {
-                s[i] = byte_of(d0, i);
-                s[4 + i] = byte_of(d1, i);
-            }
-            s[8] = byte_of(d2, 0);
-            s[9] = byte_of(d2, 1);
-            s[10] = byte_of(d2, 2);
+            int im[4];
+            tap8x4(ld4u(p) ^ bias, ld4u(p + 4) ^ bias, ld4u(p + 8) ^ bias, tlo, thi, 0, im);
 #pragma unroll
             for (int x = 0; x < 4; x++)
-            {
-                int h = 0;
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    h += s[x + k] * cx[k];
-                h = (int)(int16_t)(h - 8192);
 #pragma unroll
                 for (int y = 0; y < 4; y++)
                     if (r - y >= 0 && r - y < 8)
-                        acc[y][x] += h * cy[r - y];
-            }
+                        acc[y][x] += im[x] * cy[r - y];
         }
 #pragma unroll
         for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int x = 0; x < 4; x++)
-                pix[y][x] = clip_pixel((acc[y][x] + 2048 + (8192 << 6)) >> 12);
+        {
+            P[y][0] = pack2(clip_pixel(acc[y][0] >> 12), clip_pixel(acc[y][1] >> 12));
+            P[y][1] = pack2(clip_pixel(acc[y][2] >> 12), clip_pixel(acc[y][3] >> 12));
+        }
     }
 }
 
-__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
-
 // SAD or SATD of one 4x4 tile.  `f` walks the source block with `fstride`.
 // SATD: sum |H4 * D * H4| / 2 per tile; the per-tile sum is always even, so halving per tile is
-// exactly what the reference's 4x4 / 8x4 grouping yields (pixel.cpp:201-252).
-__device__ __forceinline__ int tile_metric(const uint8_t *f, int fstride, const int pix[4][4], int metric)
+// exactly what the reference's 4x4 / 8x4 grouping yields (pixel.cpp:201-252).  All of it runs on packed
+// 16-bit pairs (|coefficient| <= 16 * 255); the last butterfly stage is folded into
+// |a + b| + |a - b| = 2 * max(|a|, |b|), which also supplies the division by two.
+__device__ __forceinline__ int tile_metric(const uint8_t *f, int fstride, const uint32_t P[4][2], int metric)
 {
-    int d[4][4];
-#pragma unroll
-    for (int y = 0; y < 4; y++)
-    {
-        uint32_t fv = ld4u(f + y * fstride);
-#pragma unroll
-        for (int x = 0; x < 4; x++)
-            d[y][x] = byte_of(fv, x) - pix[y][x];
-    }
-    int acc = 0;
     if (metric == X265_HIP_SAD)
     {
+        uint32_t acc = 0;
 #pragma unroll
         for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int x = 0; x < 4; x++)
-                acc += iabs(d[y][x]);
-        return acc;
+            acc = __builtin_amdgcn_sad_u8(ld4u(f + y * fstride), __builtin_amdgcn_perm(P[y][1], P[y][0], 0x06040200), acc);
+        return (int)acc;
     }
-    int m[4][4];
+    s16x2 a[4], b[4];
 #pragma unroll
     for (int y = 0; y < 4; y++)
     {
-        int s01 = d[y][0] + d[y][1], t01 = d[y][0] - d[y][1];
-        int s23 = d[y][2] + d[y][3], t23 = d[y][2] - d[y][3];
-        m[y][0] = s01 + s23;
-        m[y][1] = t01 + t23;
-        m[y][2] = s01 - s23;
-        m[y][3] = t01 - t23;
+        const uint32_t fv = ld4u(f + y * fstride);
+        a[y] = as_s2(__builtin_amdgcn_perm(0, fv, 0x0c010c00)) - as_s2(P[y][0]);
+        b[y] = as_s2(__builtin_amdgcn_perm(0, fv, 0x0c030c02)) - as_s2(P[y][1]);
     }
-#pragma unroll
-    for (int x = 0; x < 4; x++)
+    // columns: 4-point Hadamard down the rows, two columns per register
+    s16x2 ra[4], rb[4];
     {
-        int s01 = m[0][x] + m[1][x], t01 = m[0][x] - m[1][x];
-        int s23 = m[2][x] + m[3][x], t23 = m[2][x] - m[3][x];
-        acc += iabs(s01 + s23) + iabs(s01 - s23) + iabs(t01 + t23) + iabs(t01 - t23);
+        const s16x2 s01 = a[0] + a[1], t01 = a[0] - a[1], s23 = a[2] + a[3], t23 = a[2] - a[3];
+        ra[0] = s01 + s23;
+        ra[1] = t01 + t23;
+        ra[2] = s01 - s23;
+        ra[3] = t01 - t23;
     }
-    return acc >> 1;
+    {
+        const s16x2 s01 = b[0] + b[1], t01 = b[0] - b[1], s23 = b[2] + b[3], t23 = b[2] - b[3];
+        rb[0] = s01 + s23;
+        rb[1] = t01 + t23;
+        rb[2] = s01 - s23;
+        rb[3] = t01 - t23;
+    }
+    // rows: (v0, v1), (v2, v3) -> s = (v0 + v2, v1 + v3), t = (v0 - v2, v1 - v3); the outputs are
+    // s.lo +- s.hi and t.lo +- t.hi, whose absolute sums are 2 max(|s.lo|, |s.hi|) + 2 max(|t.lo|, |t.hi|)
+    s16x2 sum = { 0, 0 };
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+    {
+        const uint32_t s = as_u32(ra[y] + rb[y]), t = as_u32(ra[y] - rb[y]);
+        const s16x2 u = as_s2(__builtin_amdgcn_perm(t, s, 0x05040100)); // (s.lo, t.lo)
+        const s16x2 v = as_s2(__builtin_amdgcn_perm(t, s, 0x07060302)); // (s.hi, t.hi)
+        const s16x2 mx = __builtin_elementwise_max(u, v), mn = __builtin_elementwise_min(u, v);
+        const s16x2 zero = { 0, 0 };
+        sum += __builtin_elementwise_max(mx, zero - mn);
+    }
+    const uint32_t su = as_u32(sum);
+    return (int)((su & 0xffffu) + (su >> 16));
 }
 
 // ---- mvcost -----------------------------------------------------------------------------------

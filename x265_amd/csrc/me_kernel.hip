@@ -25,6 +25,8 @@
 namespace x265hip {
 
 #define QMAX 16
+#define SPEC_SQ_TILES 4    // speculate the square refine for PUs of at most this many 4x4 tiles
+#define SPEC_QPEL_TILES 16 // same for the quarter-pel ring
 
 struct WaveLds
 {
@@ -122,9 +124,24 @@ __device__ __forceinline__ void q_eval(Wave &wv, int metric)
         const int c = (int)(((float)i + 0.5f) * inv_nt), t = i - c * wv.nt;
         const int ty = (int)(((float)t + 0.5f) * inv_ntx), tx = t - ty * wv.ntx;
         const int qx = s->qx[c], qy = s->qy[c];
-        int pix[4][4];
-        ref_tile(wv.ref + ((qy >> 2) + 4 * ty) * wv.stride + (qx >> 2) + 4 * tx, wv.stride, qx & 3, qy & 3, pix);
-        const int v = tile_metric(s->fenc + ty * 4 * 64 + tx * 4, 64, pix, metric);
+        const uint8_t *r = wv.ref + ((qy >> 2) + 4 * ty) * wv.stride + (qx >> 2) + 4 * tx;
+        const uint8_t *f = s->fenc + ty * 4 * 64 + tx * 4;
+        int v;
+        if (metric == X265_HIP_SAD && ((qx | qy) & 3) == 0)
+        {
+            // full-pel SAD, the bulk of the integer stage: four v_sad_u8 on the packed rows
+            uint32_t a = 0;
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+                a = __builtin_amdgcn_sad_u8(*(const uint32_t *)(f + y * 64), ld4u(r + y * wv.stride), a);
+            v = (int)a;
+        }
+        else
+        {
+            uint32_t pix[4][2];
+            ref_tile(r, wv.stride, qx & 3, qy & 3, pix);
+            v = tile_metric(f, 64, pix, metric);
+        }
         atomicAdd(&s->cost[c], v);
     }
     wave_sync();
@@ -250,6 +267,33 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
     int ras_step = 1, ras_next = ST_POST;
     bool ras_quirk = false;
     int sub_it = 0;
+    // Speculation: a group may carry candidates that are only needed if the step before them does not
+    // move the centre (the square refine behind a hexagon step, the quarter-pel ring behind the half-pel
+    // ring).  They are evaluated in the same pass when that costs no or little extra time, consumed in
+    // the reference's order if the centre stayed, and dropped otherwise, so results are unchanged.
+    const bool spec_sq = wv.nt <= SPEC_SQ_TILES;
+    const bool spec_qp = hsatd && hpel_iters == 1 && qpel_iters > 0 && wv.nt <= SPEC_QPEL_TILES &&
+                         1 + hpel_dirs + qpel_dirs <= QMAX;
+
+    // square refine around (bx, by) from the costs at queue offset `off` (motion.cpp:688-699)
+    auto take_square = [&](int off) {
+        int d = 0;
+        for (int k = 1; k <= 8; k++)
+        {
+            const int cost = q_cost(wv, off + k - 1);
+            if (cost < bcost)
+            {
+                bcost = cost;
+                d = k;
+            }
+        }
+        bx = s16(bx + k_square1[d][0]);
+        by = s16(by + k_square1[d][1]);
+    };
+    auto push_square = [&]() {
+        for (int k = 1; k <= 8; k++)
+            push_f(wv, bx + k_square1[k][0], by + k_square1[k][1]);
+    };
 
     for (;;)
     {
@@ -396,6 +440,8 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
         case ST_HEX_BEGIN:
             for (int k = 1; k <= 6; k++) // hex2[1..6] = (-2,0)(-1,2)(1,2)(2,0)(1,-2)(-1,-2): codes 2..7
                 push_f(wv, bx + k_hex2[k][0], by + k_hex2[k][1]);
+            if (spec_sq)
+                push_square();
             st = ST_HEX1;
             break;
 
@@ -403,6 +449,7 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
         case ST_HEXN:
         {
             bool go_on = false;
+            const int nstep = st == ST_HEX1 ? 6 : 3; // the speculated square sits behind the step's points
             if (st == ST_HEX1)
             {
                 packed = bcost << 3;
@@ -439,36 +486,32 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
                 // half hexagon, not overlapping the previous one
                 for (int k = 0; k < 3; k++)
                     push_f(wv, bx + k_hex2[dir + k][0], by + k_hex2[dir + k][1]);
+                if (spec_sq)
+                    push_square();
                 st = ST_HEXN;
             }
             else
             {
                 bcost = packed >> 3;
-                for (int k = 1; k <= 8; k++)
-                    push_f(wv, bx + k_square1[k][0], by + k_square1[k][1]);
-                st = ST_SQ;
+                if (spec_sq && !(packed & 7))
+                {
+                    take_square(nstep); // the centre stayed: the square was evaluated with this step
+                    st = ST_POST;
+                }
+                else
+                {
+                    push_square();
+                    st = ST_SQ;
+                }
             }
             break;
         }
 
         case ST_SQ:
-        {
-            int d = 0;
-            for (int k = 1; k <= 8; k++)
-            {
-                const int cost = q_cost(wv, k - 1);
-                if (cost < bcost)
-                {
-                    bcost = cost;
-                    d = k;
-                }
-            }
+            take_square(0);
             wv.nq = 0;
-            bx = s16(bx + k_square1[d][0]);
-            by = s16(by + k_square1[d][1]);
             st = ST_POST;
             break;
-        }
 
         // ---- UMH (motion.cpp:702-885)
 #define THRESH(v) (bcost < (((v) >> 4) * ((wv.h * wv.h) >> 4))) /* SAD_THRESH, size_scale (motion.cpp:60-66) */
@@ -931,6 +974,9 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
                 q_push(wv, bx, by, MV_COST);
             for (int i = 1; i <= hpel_dirs; i++)
                 q_push(wv, s16(bx + k_square1[i][0] * 2), s16(by + k_square1[i][1] * 2), MV_COST);
+            if (spec_qp)
+                for (int i = 1; i <= qpel_dirs; i++)
+                    q_push(wv, s16(bx + k_square1[i][0]), s16(by + k_square1[i][1]), MV_COST);
             st = ST_HPEL;
             break;
 
@@ -962,6 +1008,31 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
                 metric = X265_HIP_SATD; // half-pel used SAD: re-measure with SATD before quarter-pel (:1103-1105)
                 q_push(wv, bx, by, MV_COST);
                 st = ST_REM;
+            }
+            else if (spec_qp && bdir == 0)
+            {
+                // the centre stayed: the first quarter-pel ring was evaluated with the half-pel ring
+                int qdir = 0;
+                for (int i = 1; i <= qpel_dirs; i++, k++)
+                {
+                    const int cost = q_cost(wv, k);
+                    if (cost < bcost)
+                    {
+                        bcost = cost;
+                        qdir = i;
+                    }
+                }
+                bx = s16(bx + k_square1[qdir][0]);
+                by = s16(by + k_square1[qdir][1]);
+                sub_it = 1;
+                if (sub_it < qpel_iters)
+                {
+                    for (int i = 1; i <= qpel_dirs; i++)
+                        q_push(wv, s16(bx + k_square1[i][0]), s16(by + k_square1[i][1]), MV_COST);
+                    st = ST_QPEL;
+                }
+                else
+                    st = ST_DONE;
             }
             else
                 st = ST_QPEL_BEGIN;
@@ -1026,7 +1097,7 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
     }
 }
 
-__global__ __launch_bounds__(64) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
                                                 x265_hip_me_result *out)
 {
     __shared__ WaveLds lds;
