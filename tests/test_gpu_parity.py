@@ -31,6 +31,27 @@ def test_cost_batch_all_partitions_all_fractions(gpu_ctx, oracle, small_seq):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,small_only", [(1, False), (15, False), (17, True), (1013, False), (1999, True)])
+def test_cost_batch_ragged(gpu_ctx, oracle, small_seq, n, small_only):
+    """request counts that do not fill the last wave, sizes mixed inside a wave (the prefix-sum path) and
+    waves of small blocks only (the lane = 4 * request + tile path)"""
+    from x265_amd import abi
+    rng = np.random.default_rng(n)
+    W, H = small_seq[0].w, small_seq[0].h
+    parts = [p for p in range(25) if abi.PARTS[p][0] * abi.PARTS[p][1] <= 64] if small_only else list(range(25))
+    reqs = np.zeros(n, abi.COST_REQ)
+    for r in reqs:
+        w, h = abi.PARTS[int(rng.choice(parts))]
+        r["fenc_plane"], r["ref_plane"] = 1, int(rng.choice([0, 2]))
+        r["pu_x"], r["pu_y"] = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+        r["pu_w"], r["pu_h"], r["metric"] = w, h, int(rng.integers(0, 2))
+        r["qmv_x"], r["qmv_y"] = int(rng.integers(-90, 90)), int(rng.integers(-90, 90))
+    got = gpu_ctx.cost_batch(reqs)
+    want = oracle.cost_batch(_planes(small_seq), reqs)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, f"request {bad[0]}: {reqs[bad[0]]} got {got[bad[0]]} want {want[bad[0]]}"
+
+
 @pytest.mark.parametrize("method", [0, 1, 2, 3])
 def test_me_batch_methods(gpu_ctx, oracle, small_seq, costtabs, method):
     from x265_amd import abi, synth

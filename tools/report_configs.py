@@ -1,0 +1,121 @@
+"""Throughput of BASELINE configs[1..3] at 1080p and 4K on one MI355X (JSON on stdout).
+
+  configs[1]  integer-pel full search, +-64, 85 square PUs per CTU, 1 reference     (x265_hip_fullsearch)
+  configs[2]  motionEstimate replay, HEX + subme 2, merange 57, 3 references        (x265_hip_me_batch)
+  configs[3]  the same at 4K, plus the SATD-candidate rate of the sub-pel stage:     (x265_hip_cost_batch)
+              every square PU x 3 references x 16 candidates (half-pel ring + quarter-pel ring around the
+              integer vector), SATD after 8-tap interpolation
+
+Everything is resident in HBM before the timed region; times are HIP events on the context's stream.
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import bench
+from x265_amd import abi, lib, synth
+
+LANE_PEAK = 7.86e13  # 32-bit VALU lane-ops/s (MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector / 2)
+PX_PEAK = 1.34e14    # measured byte-SAD pixel rate (profiles/r01_ubench_valu.txt)
+
+
+def timed(ext, ctx, fn, reps):
+    fn()
+    ctx.sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(ext)
+    for _ in range(reps):
+        fn()
+    e1.record(ext)
+    ctx.sync()
+    return e0.elapsed_time(e1) / reps
+
+
+def subpel_requests(w, h, cur, refs, motions):
+    pus = synth.square_pus(w, h)
+    ring = [(0, -1), (0, 1), (-1, 0), (1, 0), (-1, -1), (-1, 1), (1, -1), (1, 1)]
+    offs = [(2 * x, 2 * y) for x, y in ring] + ring  # half-pel ring, quarter-pel ring
+    n = len(pus)
+    out = np.zeros(n * len(refs) * len(offs), abi.COST_REQ)
+    k = 0
+    for rp, (dx, dy) in zip(refs, motions):
+        for ox, oy in offs:
+            r = out[k:k + n]
+            k += n
+            r["fenc_plane"], r["ref_plane"] = cur, rp
+            r["pu_x"], r["pu_y"] = pus[:, 0], pus[:, 1]
+            r["pu_w"] = r["pu_h"] = pus[:, 2]
+            r["metric"] = abi.SATD
+            r["qmv_x"], r["qmv_y"] = 4 * dx + ox, 4 * dy + oy
+    return out
+
+
+def satd_lane_ops(reqs):
+    """algorithmic 32-bit lane-ops of SURVEY.md 8(d): SATD 111 per 4x4 tile; hpp / vpp 8 MAC + 3 per pixel;
+    diagonal 8 (H + 7) / H + 8 MAC + 3 per pixel"""
+    px = reqs["pu_w"].astype(np.float64) * reqs["pu_h"]
+    hgt = reqs["pu_h"].astype(np.float64)
+    fx, fy = (reqs["qmv_x"] & 3) != 0, (reqs["qmv_y"] & 3) != 0
+    per_px = 111.0 / 16 + np.where(fx & fy, 8 * (hgt + 7) / hgt + 8 + 3, np.where(fx | fy, 11.0, 0.0))
+    return float((px * per_px).sum())
+
+
+def run(w, h, tag):
+    dev = torch.device("cuda", 0)
+    seq = synth.Sequence(w, h, seed=0x265)
+    planes = [synth.Plane(seq.frame(i)) for i in range(4)]
+    ctx = lib.Context(0)
+    ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    for i, p in enumerate(planes):
+        ctx.plane_upload(i, p.buf, p.stride, p.origin)
+    for q in range(28, 40):
+        ctx.set_qp(q)
+    res = {"picture": f"{w}x{h}"}
+
+    bench.W, bench.H = w, h
+    fj = bench.build_ctu_jobs(seq, 3, 2, 3, 2)
+    vp = bench.valid_pus_per_ctu()
+    npos = (fj["mvmax_x"].astype(np.int64) - fj["mvmin_x"] + 1) * (fj["mvmax_y"].astype(np.int64) - fj["mvmin_y"] + 1)
+    d = torch.from_numpy(fj.view(np.uint8).copy()).to(dev)
+    o = torch.empty(len(fj) * lib.PUS_PER_CTU * 8, dtype=torch.uint8, device=dev)
+    ms = timed(ext, ctx, lambda: ctx.fullsearch_device(d.data_ptr(), len(fj), o.data_ptr()), 20)
+    res["fullsearch"] = {"ctus": len(fj), "ms_per_picture_per_ref": ms, "candidates_per_s": float((npos * vp).sum()) / ms * 1e3,
+                         "pixel_ops_per_s": float(npos.sum()) * 4096 / ms * 1e3,
+                         "frac_of_sad_roof": float(npos.sum()) * 4096 / ms * 1e3 / PX_PEAK}
+
+    refs = [2, 1, 0]
+    mot = [seq.global_motion(3, r) for r in refs]
+    for name, method, subme in (("hex_subme2", abi.HEX, 2), ("umh_subme5", abi.UMH, 5), ("star_subme7", abi.STAR, 7)):
+        mj = synth.me_jobs(w, h, 3, refs, mot, method=method, subme=subme, merange=57)
+        d = torch.from_numpy(mj.view(np.uint8).copy()).to(dev)
+        o = torch.empty(len(mj) * 8, dtype=torch.uint8, device=dev)
+        ms = timed(ext, ctx, lambda: ctx.me_batch_device(d.data_ptr(), len(mj), o.data_ptr()), 10)
+        res["me_stage_" + name] = {"calls": len(mj), "references": 3, "ms_per_picture": ms, "pictures_per_s": 1e3 / ms,
+                                   "calls_per_s": len(mj) / ms * 1e3}
+
+    rq = subpel_requests(w, h, 3, refs, mot)
+    d = torch.from_numpy(rq.view(np.uint8).copy()).to(dev)
+    o = torch.empty(len(rq), dtype=torch.int32, device=dev)
+    ms = timed(ext, ctx, lambda: ctx.cost_batch_device(d.data_ptr(), len(rq), o.data_ptr()), 5)
+    ops = satd_lane_ops(rq)
+    res["satd_candidates"] = {"requests": len(rq), "ms": ms, "candidates_per_s": len(rq) / ms * 1e3,
+                              "pixels_per_s": float((rq["pu_w"].astype(np.int64) * rq["pu_h"]).sum()) / ms * 1e3,
+                              "algorithmic_lane_ops_per_s": ops / ms * 1e3, "frac_of_valu_peak": ops / ms * 1e3 / LANE_PEAK}
+    for size in (8, 16, 32, 64):
+        sel = rq[rq["pu_w"] == size]
+        d = torch.from_numpy(sel.view(np.uint8).copy()).to(dev)
+        ms = timed(ext, ctx, lambda: ctx.cost_batch_device(d.data_ptr(), len(sel), o.data_ptr()), 5)
+        ops = satd_lane_ops(sel)
+        res["satd_candidates"][f"{size}x{size}"] = {"requests": len(sel), "ms": ms, "candidates_per_s": len(sel) / ms * 1e3,
+                                                    "frac_of_valu_peak": ops / ms * 1e3 / LANE_PEAK}
+    ctx.close()
+    return res
+
+
+if __name__ == "__main__":
+    out = {"1080p": run(1920, 1080, "1080p"), "4k": run(3840, 2160, "4k")}
+    print(json.dumps(out, indent=1))

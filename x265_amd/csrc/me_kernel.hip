@@ -1097,7 +1097,7 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
     }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
                                                 x265_hip_me_result *out)
 {
     __shared__ WaveLds lds;
@@ -1117,24 +1117,88 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void me
     motion_estimate(wv, j, &out[id]);
 }
 
-__global__ __launch_bounds__(64) void cost_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
-                                                  int32_t *out)
+// Cost requests, sixteen per wave.  Work items are (request, 4x4 tile) pairs dealt round-robin to the 64
+// lanes, so requests of different sizes in one wave do not wait for each other: a prefix sum of the tile
+// counts sits in LDS and a lane finds its request by binary search (waves whose requests all have at most
+// four tiles skip the search: lane = 4 * request + tile).  Lanes read source and reference tiles straight
+// from the planes (a request is a single candidate, nothing is reused); partial sums meet in LDS atomics.
+#define COST_PER_WAVE 16
+
+struct CostLds
 {
-    __shared__ WaveLds lds;
-    const int id = blockIdx.x;
-    if (id >= n)
+    int pre[COST_PER_WAVE + 1]; // exclusive prefix of tile counts
+    int cost[COST_PER_WAVE];
+    // per request, resolved once by lane k: block origins, strides, ntx | xf << 8 | yf << 10 | metric << 12
+    const uint8_t *fenc[COST_PER_WAVE];
+    const uint8_t *ref[COST_PER_WAVE];
+    int fstride[COST_PER_WAVE], rstride[COST_PER_WAVE], info[COST_PER_WAVE];
+};
+
+__global__ __launch_bounds__(256) void cost_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
+                                                   int32_t *out)
+{
+    __shared__ CostLds lds[4];
+    CostLds &L = lds[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const int wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * COST_PER_WAVE;
+    if (wbase >= n)
         return;
-    const x265_hip_cost_req &r = reqs[id];
-    Wave wv;
-    wave_init(wv, &lds, r.pu_w, r.pu_h);
-    const PlaneDesc fp = tabs->planes[r.fenc_plane], rp = tabs->planes[r.ref_plane];
-    wv.stride = rp.stride;
-    wv.ref = rp.origin + (long)r.pu_y * rp.stride + r.pu_x;
-    load_fenc(wv, fp.origin + (long)r.pu_y * fp.stride + r.pu_x, fp.stride);
-    q_push(wv, r.qmv_x, r.qmv_y, MV_NONE);
-    q_eval(wv, r.metric);
-    if (wv.lane == 0)
-        out[id] = wv.vc;
+    int nt = 0;
+    if (lane < COST_PER_WAVE && wbase + lane < n)
+    {
+        const x265_hip_cost_req r = reqs[wbase + lane];
+        const PlaneDesc fp = tabs->planes[r.fenc_plane], rp = tabs->planes[r.ref_plane];
+        nt = (r.pu_w >> 2) * (r.pu_h >> 2);
+        L.fenc[lane] = fp.origin + (long)r.pu_y * fp.stride + r.pu_x;
+        L.ref[lane] = rp.origin + (long)(r.pu_y + (r.qmv_y >> 2)) * rp.stride + r.pu_x + (r.qmv_x >> 2);
+        L.fstride[lane] = fp.stride;
+        L.rstride[lane] = rp.stride;
+        L.info[lane] = (r.pu_w >> 2) | ((r.qmv_x & 3) << 8) | ((r.qmv_y & 3) << 10) | (r.metric << 12);
+    }
+    const bool small = __ballot(nt > 4) == 0;
+    if (lane < COST_PER_WAVE)
+    {
+        // inclusive scan over the 16-lane row: row_shr 1, 2, 4, 8 (lanes shifted in read 0)
+        int inc = nt;
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+        L.pre[lane + 1] = inc;
+        L.cost[lane] = 0;
+        if (lane == 0)
+            L.pre[0] = 0;
+    }
+    wave_sync();
+    const int total = small ? 64 : L.pre[COST_PER_WAVE];
+    for (int i = lane; i < total; i += 64)
+    {
+        int k, t;
+        if (small)
+        {
+            k = i >> 2;
+            t = i & 3;
+        }
+        else
+        {
+            k = 0;
+#pragma unroll
+            for (int step = 8; step > 0; step >>= 1)
+                if (L.pre[k + step] <= i)
+                    k += step;
+            t = i - L.pre[k];
+        }
+        if (t >= L.pre[k + 1] - L.pre[k]) // also skips requests past n (no tiles)
+            continue;
+        const int info = L.info[k], ntx = info & 255, fstride = L.fstride[k], rstride = L.rstride[k];
+        const int ty = (int)(((float)t + 0.5f) * (1.0f / (float)ntx)), tx = t - ty * ntx; // exact for t < 256, ntx <= 16
+        uint32_t pix[4][2];
+        ref_tile(L.ref[k] + 4 * ty * rstride + 4 * tx, rstride, (info >> 8) & 3, (info >> 10) & 3, pix);
+        atomicAdd(&L.cost[k], tile_metric(L.fenc[k] + 4 * ty * fstride + 4 * tx, fstride, pix, info >> 12));
+    }
+    wave_sync();
+    if (lane < COST_PER_WAVE && wbase + lane < n)
+        out[wbase + lane] = L.cost[lane];
 }
 
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st)
@@ -1146,7 +1210,7 @@ void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x26
 void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, hipStream_t st)
 {
     if (n > 0)
-        hipLaunchKernelGGL(cost_kernel, dim3(n), dim3(64), 0, st, tabs, reqs, n, out);
+        hipLaunchKernelGGL(cost_kernel, dim3((n + 4 * COST_PER_WAVE - 1) / (4 * COST_PER_WAVE)), dim3(256), 0, st, tabs, reqs, n, out);
 }
 
 } // namespace x265hip
