@@ -8,8 +8,9 @@ One step = one picture searched against one reference: every 64x64 CTU, every sq
 (64/32/16/8) wholly inside the picture, every integer position of the window that
 xSetSearchRange gives around the CTU's predictor, SAD + mvcost, first minimum in raster order.
 `value` counts (PU, position) cost evaluations per second with planes, job lists and results resident
-in HBM.  A second timed leg (reported in extra keys) runs the full motionEstimate replay
-(HEX, subme 2, merange 57, 3 references: configs[2]) on the same pictures.
+in HBM.  Two more timed legs (reported in extra keys) run on the same pictures: the full motionEstimate
+replay (HEX, subme 2, merange 57, 3 references: configs[2]) and the SATD sub-pel candidate set (every
+square PU x 3 references x 16 half-/quarter-pel candidates through 8-tap interpolation + SATD).
 
 For N > 1 the driver launches one rank per GPU; ranks take disjoint GOP segments of the
 sequence (no collective on the data path) and the job-wide rate is units / max-over-ranks time.
@@ -28,7 +29,7 @@ sys.path.insert(0, ROOT)
 W, H = 1920, 1080
 RANGE = 64
 PX_PEAK = 1.34e14     # measured v_qsad_pk_u16_u8 / v_sad_u8 pixel rate, profiles/r01_ubench_valu.txt
-LANE_PEAK = 7.86e13   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector / 2)
+LANE_PEAK = 3.93e13   # integer VALU lane-ops/s: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (measured 3.65e13)
 HBM_PEAK = 8000.0     # GB/s
 
 
@@ -125,6 +126,16 @@ def main():
         me_jobs.append(torch.from_numpy(j.view(np.uint8).copy()).to(dev))
     me_out = torch.empty(max(me_n) * 8, dtype=torch.uint8, device=dev)
 
+    sp_reqs, sp_n, sp_ops = [], [], []
+    for i in range(nfr):
+        cur = 3 + i
+        refs = [cur - 1, cur - 2, cur - 3]
+        rq = synth.subpel_requests(W, H, cur, refs, [seq.global_motion(first + cur, first + r) for r in refs])
+        sp_n.append(len(rq))
+        sp_ops.append(synth.satd_lane_ops(rq))
+        sp_reqs.append(torch.from_numpy(rq.view(np.uint8).copy()).to(dev))
+    sp_out = torch.empty(max(sp_n), dtype=torch.int32, device=dev)
+
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
 
     def barrier():
@@ -143,6 +154,11 @@ def main():
         i = step % nfr
         ctx.me_batch_device(me_jobs[i].data_ptr(), me_n[i], me_out.data_ptr())
         return me_n[i]
+
+    def run_sp(step):
+        i = step % nfr
+        ctx.cost_batch_device(sp_reqs[i].data_ptr(), sp_n[i], sp_out.data_ptr())
+        return sp_n[i], sp_ops[i]
 
     def timed(fn, steps, warmup):
         for s in range(warmup):
@@ -169,6 +185,9 @@ def main():
     positions = sum(a[1] for a in acc_fs)
     dt_me, ev_me, acc_me = timed(run_me, args.steps, args.warmup)
     me_calls = sum(acc_me)
+    dt_sp, ev_sp, acc_sp = timed(run_sp, args.steps, args.warmup)
+    sp_cands = sum(a[0] for a in acc_sp)
+    sp_lane_ops = sum(a[1] for a in acc_sp)
 
     # ---- CPU baseline: the reference's own C primitives (oracle/_ref) when present, else the port ----
     cpu = None
@@ -215,10 +234,10 @@ def main():
 
     if rank == 0:
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, raw)
+        tpath = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE)
             t = json.load(open(tpath))["fullsearch2_kernel"]
-            traffic = (t["fetch_kib"] + t["write_kib"]) * 1024
+            traffic = (t["fetch_kib_corrected"] + t["write_kib"]) * 1024
         total_units = units * world
         k_ms = ev_fs / args.steps
         px_ops = positions / args.steps * 4096  # 64x64 pixel-ops per position per CTU with full 8x8 reuse
@@ -235,8 +254,13 @@ def main():
             "me_stage": {"workload": "configs[2]: motionEstimate replay, HEX, subme 2, merange 57, 3 references, "
                                      "square PUs 64..8",
                          "frames_per_s": args.steps * world / dt_me, "me_calls_per_s": me_calls * world / dt_me,
-                         "satd_candidates_per_s": me_calls * world * 9 / dt_me, "ms_per_frame": dt_me / args.steps * 1e3,
-                         "kernel_ms_per_frame": ev_me / args.steps},
+                         "ms_per_frame": dt_me / args.steps * 1e3, "kernel_ms_per_frame": ev_me / args.steps},
+            "satd_candidates": {"workload": "sub-pel stage of the same pictures: square PUs 64..8 x 3 references x 16 half-/"
+                                            "quarter-pel candidates, 8-tap interpolation + SATD (x265_hip_cost_batch)",
+                                "candidates_per_s": sp_cands * world / dt_sp, "ms_per_frame": dt_sp / args.steps * 1e3,
+                                "roofline": {"bound": "valu", "achieved": sp_lane_ops / (ev_sp * 1e-3) / 1e12,
+                                             "peak": LANE_PEAK / 1e12, "unit": "Tlane-op/s",
+                                             "frac": sp_lane_ops / (ev_sp * 1e-3) / LANE_PEAK, "kernel": "cost_kernel"}},
             "roofline": {"bound": "valu", "achieved": px_ops / (k_ms * 1e-3) / 1e12, "peak": PX_PEAK / 1e12,
                          "unit": "Tpixel-op/s", "frac": px_ops / (k_ms * 1e-3) / PX_PEAK,
                          "kernel": "fullsearch2_kernel", "kernel_ms": k_ms, "traffic": traffic,

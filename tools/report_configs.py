@@ -19,7 +19,7 @@ import torch
 import bench
 from x265_amd import abi, lib, synth
 
-LANE_PEAK = 7.86e13  # 32-bit VALU lane-ops/s (MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector / 2)
+LANE_PEAK = 3.93e13  # 32-bit integer VALU lane-ops/s: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (measured 3.65e13)
 PX_PEAK = 1.34e14    # measured byte-SAD pixel rate (profiles/r01_ubench_valu.txt)
 
 
@@ -33,35 +33,6 @@ def timed(ext, ctx, fn, reps):
     e1.record(ext)
     ctx.sync()
     return e0.elapsed_time(e1) / reps
-
-
-def subpel_requests(w, h, cur, refs, motions):
-    pus = synth.square_pus(w, h)
-    ring = [(0, -1), (0, 1), (-1, 0), (1, 0), (-1, -1), (-1, 1), (1, -1), (1, 1)]
-    offs = [(2 * x, 2 * y) for x, y in ring] + ring  # half-pel ring, quarter-pel ring
-    n = len(pus)
-    out = np.zeros(n * len(refs) * len(offs), abi.COST_REQ)
-    k = 0
-    for rp, (dx, dy) in zip(refs, motions):
-        for ox, oy in offs:
-            r = out[k:k + n]
-            k += n
-            r["fenc_plane"], r["ref_plane"] = cur, rp
-            r["pu_x"], r["pu_y"] = pus[:, 0], pus[:, 1]
-            r["pu_w"] = r["pu_h"] = pus[:, 2]
-            r["metric"] = abi.SATD
-            r["qmv_x"], r["qmv_y"] = 4 * dx + ox, 4 * dy + oy
-    return out
-
-
-def satd_lane_ops(reqs):
-    """algorithmic 32-bit lane-ops of SURVEY.md 8(d): SATD 111 per 4x4 tile; hpp / vpp 8 MAC + 3 per pixel;
-    diagonal 8 (H + 7) / H + 8 MAC + 3 per pixel"""
-    px = reqs["pu_w"].astype(np.float64) * reqs["pu_h"]
-    hgt = reqs["pu_h"].astype(np.float64)
-    fx, fy = (reqs["qmv_x"] & 3) != 0, (reqs["qmv_y"] & 3) != 0
-    per_px = 111.0 / 16 + np.where(fx & fy, 8 * (hgt + 7) / hgt + 8 + 3, np.where(fx | fy, 11.0, 0.0))
-    return float((px * per_px).sum())
 
 
 def run(w, h, tag):
@@ -97,11 +68,11 @@ def run(w, h, tag):
         res["me_stage_" + name] = {"calls": len(mj), "references": 3, "ms_per_picture": ms, "pictures_per_s": 1e3 / ms,
                                    "calls_per_s": len(mj) / ms * 1e3}
 
-    rq = subpel_requests(w, h, 3, refs, mot)
+    rq = synth.subpel_requests(w, h, 3, refs, mot)
     d = torch.from_numpy(rq.view(np.uint8).copy()).to(dev)
     o = torch.empty(len(rq), dtype=torch.int32, device=dev)
     ms = timed(ext, ctx, lambda: ctx.cost_batch_device(d.data_ptr(), len(rq), o.data_ptr()), 5)
-    ops = satd_lane_ops(rq)
+    ops = synth.satd_lane_ops(rq)
     res["satd_candidates"] = {"requests": len(rq), "ms": ms, "candidates_per_s": len(rq) / ms * 1e3,
                               "pixels_per_s": float((rq["pu_w"].astype(np.int64) * rq["pu_h"]).sum()) / ms * 1e3,
                               "algorithmic_lane_ops_per_s": ops / ms * 1e3, "frac_of_valu_peak": ops / ms * 1e3 / LANE_PEAK}
@@ -109,7 +80,7 @@ def run(w, h, tag):
         sel = rq[rq["pu_w"] == size]
         d = torch.from_numpy(sel.view(np.uint8).copy()).to(dev)
         ms = timed(ext, ctx, lambda: ctx.cost_batch_device(d.data_ptr(), len(sel), o.data_ptr()), 5)
-        ops = satd_lane_ops(sel)
+        ops = synth.satd_lane_ops(sel)
         res["satd_candidates"][f"{size}x{size}"] = {"requests": len(sel), "ms": ms, "candidates_per_s": len(sel) / ms * 1e3,
                                                     "frac_of_valu_peak": ops / ms * 1e3 / LANE_PEAK}
     ctx.close()

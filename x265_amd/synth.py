@@ -10,7 +10,7 @@ Nothing here is timed; bench.py uploads the result once and keeps it resident in
 """
 import numpy as np
 
-from .abi import ME_JOB, MAX_MVC
+from .abi import COST_REQ, ME_JOB, MAX_MVC, SATD
 
 MARGIN_X = 96
 MARGIN_Y = 80
@@ -196,3 +196,35 @@ def me_jobs(w, h, fenc_plane, ref_planes, motions, method=1, subme=2, merange=57
             j["mvc"][:, 2 * c] = 4 * dx + hx
             j["mvc"][:, 2 * c + 1] = 4 * dy + hy
     return jobs
+
+
+def subpel_requests(w, h, cur, refs, motions):
+    """Cost requests of the sub-pel stage of one picture: every square PU x every reference x 16 candidates
+    (half-pel ring, then quarter-pel ring, around the integer vector `motions[i]`), SATD after interpolation.
+    Ordered reference-major, then candidate, then PU, so neighbouring requests share their fraction."""
+    pus = square_pus(w, h)
+    ring = [(0, -1), (0, 1), (-1, 0), (1, 0), (-1, -1), (-1, 1), (1, -1), (1, 1)]
+    offs = [(2 * x, 2 * y) for x, y in ring] + ring
+    n = len(pus)
+    out = np.zeros(n * len(refs) * len(offs), COST_REQ)
+    k = 0
+    for rp, (dx, dy) in zip(refs, motions):
+        for ox, oy in offs:
+            r = out[k:k + n]
+            k += n
+            r["fenc_plane"], r["ref_plane"] = cur, rp
+            r["pu_x"], r["pu_y"] = pus[:, 0], pus[:, 1]
+            r["pu_w"] = r["pu_h"] = pus[:, 2]
+            r["metric"] = SATD
+            r["qmv_x"], r["qmv_y"] = 4 * dx + ox, 4 * dy + oy
+    return out
+
+
+def satd_lane_ops(reqs):
+    """Algorithmic 32-bit lane-ops of a request list: SATD 111 per 4x4 tile; hpp / vpp
+    8 MAC + 3 per pixel; diagonal 8 (H + 7) / H + 8 MAC + 3 per pixel."""
+    px = reqs["pu_w"].astype(np.float64) * reqs["pu_h"]
+    hgt = reqs["pu_h"].astype(np.float64)
+    fx, fy = (reqs["qmv_x"] & 3) != 0, (reqs["qmv_y"] & 3) != 0
+    per_px = 111.0 / 16 + np.where(fx & fy, 8 * (hgt + 7) / hgt + 8 + 3, np.where(fx | fy, 11.0, 0.0))
+    return float((px * per_px).sum())
