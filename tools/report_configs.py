@@ -68,6 +68,23 @@ def run(w, h, tag):
         res["me_stage_" + name] = {"calls": len(mj), "references": 3, "ms_per_picture": ms, "pictures_per_s": 1e3 / ms,
                                    "calls_per_s": len(mj) / ms * 1e3}
 
+    # host-array entry points (job upload, kernel, result download, all synchronous): the PCIe-inclusive rate
+    import time
+    mj = synth.me_jobs(w, h, 3, refs, mot, method=abi.HEX, subme=2, merange=57)
+    ctx.me_batch(mj)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.me_batch(mj)
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    res["host_array_me_batch"] = {"calls": len(mj), "ms_per_picture": ms, "pictures_per_s": 1e3 / ms}
+    ctx.fullsearch(fj)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.fullsearch(fj)
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    res["host_array_fullsearch"] = {"ctus": len(fj), "ms_per_picture_per_ref": ms,
+                                    "candidates_per_s": float((npos * vp).sum()) / ms * 1e3}
+
     rq = synth.subpel_requests(w, h, 3, refs, mot)
     d = torch.from_numpy(rq.view(np.uint8).copy()).to(dev)
     o = torch.empty(len(rq), dtype=torch.int32, device=dev)
