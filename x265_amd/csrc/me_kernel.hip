@@ -25,6 +25,9 @@
 namespace x265hip {
 
 #define QMAX 16
+#define PAT_HEX 0
+#define PAT_SQ 8
+#define PAT_N 17
 #define SPEC_SQ_TILES 4    // speculate the square refine for PUs of at most this many 4x4 tiles
 #define SPEC_QPEL_TILES 16 // same for the quarter-pel ring
 
@@ -35,6 +38,7 @@ struct WaveLds
     int qy[QMAX];
     int cost[QMAX];
     int aux[QMAX];         // (tag << 2) | mv-rate mode
+    int pat[PAT_N];        // search patterns, (dy << 16) | (dx & 0xffff): hex2[0..7], then square1[0..8]
 };
 
 // how the evaluation seeds a candidate's cost with its motion-vector rate
@@ -58,7 +62,17 @@ struct Wave
     int lane;
     int nq;
     int vc, vx, vy, va; // after an evaluation: lane k holds candidate k's cost / position / aux word
+    int patv;           // lane k holds pattern entry k (same words as WaveLds::pat), for scalar reads
 };
+
+#define PAT(dx, dy) (int)(((uint32_t)(uint16_t)(dy) << 16) | (uint16_t)(dx))
+// hex2 (motion.cpp:68-70) and square1 (motion.cpp:71-73)
+__device__ __constant__ const int k_pat[PAT_N] = {
+    PAT(-1, -2), PAT(-2, 0), PAT(-1, 2), PAT(1, 2), PAT(2, 0), PAT(1, -2), PAT(-1, -2), PAT(-2, 0),
+    PAT(0, 0), PAT(0, -1), PAT(0, 1), PAT(-1, 0), PAT(1, 0), PAT(-1, -1), PAT(-1, 1), PAT(1, -1), PAT(1, 1),
+};
+__device__ __forceinline__ int pat_dx(int p) { return (int)(int16_t)p; }
+__device__ __forceinline__ int pat_dy(int p) { return p >> 16; }
 
 __device__ __forceinline__ void wave_init(Wave &wv, WaveLds *s, int w, int h)
 {
@@ -72,6 +86,9 @@ __device__ __forceinline__ void wave_init(Wave &wv, WaveLds *s, int w, int h)
     wv.tab = nullptr;
     wv.mvpx = wv.mvpy = 0;
     wv.vc = wv.vx = wv.vy = wv.va = 0;
+    wv.patv = wv.lane < PAT_N ? k_pat[wv.lane] : 0;
+    if (wv.lane < PAT_N)
+        s->pat[wv.lane] = wv.patv; // made visible by load_fenc's wave_sync
 }
 
 __device__ __forceinline__ void load_fenc(Wave &wv, const uint8_t *src, int sstride)
@@ -166,9 +183,37 @@ __device__ __forceinline__ void push_f(Wave &wv, int mx, int my, int point = 0, 
     q_push(wv, s16(s16(mx) << 2), s16(s16(my) << 2), MV_COST, (point << 16) | dist);
 }
 
-__device__ __constant__ const int8_t k_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
-__device__ __constant__ const uint8_t k_mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
-__device__ __constant__ const int8_t k_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+// Queue `count` pattern points in one go: lane k computes centre + pat[first + k] * mul, in quarter-pel
+// after << sh (int16 wrap as in the reference's MV arithmetic), and writes its own queue slot.
+__device__ __forceinline__ void push_pat(Wave &wv, int cx, int cy, int first, int count, int mul, int sh, int mvmode)
+{
+    if (wv.lane < count)
+    {
+        const int p = wv.s->pat[first + wv.lane];
+        const int slot = wv.nq + wv.lane;
+        wv.s->qx[slot] = s16(s16(cx + pat_dx(p) * mul) << sh);
+        wv.s->qy[slot] = s16(s16(cy + pat_dy(p) * mul) << sh);
+        wv.s->aux[slot] = mvmode;
+    }
+    wv.nq += count;
+}
+
+// pattern entry k as a wave-uniform value (k uniform)
+__device__ __forceinline__ int pat_at(const Wave &wv, int k) { return __builtin_amdgcn_readlane(wv.patv, k); }
+
+// First minimum among the evaluated candidates [off, off + count) (count >= 1, all inside lanes 0..15):
+// returns (cost << 4) | (k - off).  Sequential strict-less updates in push order pick exactly this one.
+__device__ __forceinline__ int q_argmin(const Wave &wv, int off, int count)
+{
+    const int k = wv.lane - off;
+    int key = (k >= 0 && k < count) ? (wv.vc << 4) | k : 0x7fffffff;
+    key = min(key, __builtin_amdgcn_update_dpp(0x7fffffff, key, 0xB1, 0xf, 0xf, false));  // quad_perm 1,0,3,2
+    key = min(key, __builtin_amdgcn_update_dpp(0x7fffffff, key, 0x4E, 0xf, 0xf, false));  // quad_perm 2,3,0,1
+    key = min(key, __builtin_amdgcn_update_dpp(0x7fffffff, key, 0x141, 0xf, 0xf, false)); // row_half_mirror
+    key = min(key, __builtin_amdgcn_update_dpp(0x7fffffff, key, 0x140, 0xf, 0xf, false)); // row_mirror
+    return __builtin_amdgcn_readlane(key, 0);
+}
+
 __device__ __constant__ const int8_t k_hex4[16][2] = { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 },
                                                       { -4, 0 }, { 4, 0 }, { -4, 1 }, { 4, 1 }, { -4, 2 }, { 4, 2 }, { -2, 3 }, { 2, 3 } };
 __device__ __constant__ const int8_t k_twopoint[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
@@ -258,7 +303,7 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
 
     int st = ST_PRE, metric = X265_HIP_SAD, flush = FL_NONE;
     // per-method scratch (uniform)
-    int cnt = 0, dir = 0, packed = 0;                 // DIA / HEX iteration count, hexagon direction, packed best
+    int cnt = 0, dir = 0;                             // DIA / HEX iteration count, hexagon direction
     int ox = 0, oy = 0;                               // pattern origin
     int ucost1 = 0, ucost2 = 0, cross_start = 1, urange = 0, ring = 1;
     bool ring_raw = false;
@@ -276,24 +321,23 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
                          1 + hpel_dirs + qpel_dirs <= QMAX;
 
     // square refine around (bx, by) from the costs at queue offset `off` (motion.cpp:688-699)
-    auto take_square = [&](int off) {
-        int d = 0;
-        for (int k = 1; k <= 8; k++)
+    // ring of `count` square1 points (x mul) around (bx, by) whose costs sit at queue offset `off`:
+    // strict-less in push order, i.e. the first minimum if it beats bcost; moves (bx, by) there
+    auto take_ring = [&](int off, int count, int mul) {
+        const int key = q_argmin(wv, off, count);
+        if ((key >> 4) < bcost)
         {
-            const int cost = q_cost(wv, off + k - 1);
-            if (cost < bcost)
-            {
-                bcost = cost;
-                d = k;
-            }
+            bcost = key >> 4;
+            const int p = pat_at(wv, PAT_SQ + 1 + (key & 15));
+            bx = s16(bx + pat_dx(p) * mul);
+            by = s16(by + pat_dy(p) * mul);
+            return true;
         }
-        bx = s16(bx + k_square1[d][0]);
-        by = s16(by + k_square1[d][1]);
+        return false;
     };
-    auto push_square = [&]() {
-        for (int k = 1; k <= 8; k++)
-            push_f(wv, bx + k_square1[k][0], by + k_square1[k][1]);
-    };
+    // square refine (motion.cpp:688-699)
+    auto take_square = [&](int off) { take_ring(off, 8, 1); };
+    auto push_square = [&]() { push_pat(wv, bx, by, PAT_SQ + 1, 8, 1, 2, MV_COST); };
 
     for (;;)
     {
@@ -301,12 +345,13 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
             q_eval(wv, metric);
         if (flush != FL_NONE)
         {
-            for (int k = 0; k < wv.nq; k++)
+            if (wv.nq)
             {
-                const int cost = q_cost(wv, k);
-                if (cost < bcost)
+                const int key = q_argmin(wv, 0, wv.nq);
+                if ((key >> 4) < bcost)
                 {
-                    bcost = cost;
+                    const int k = key & 15;
+                    bcost = key >> 4;
                     bx = q_x(wv, k) >> 2;
                     by = q_y(wv, k) >> 2;
                     if (flush == FL_STAR)
@@ -365,10 +410,7 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
             if (method == X265_HIP_DIA)
             {
                 cnt = merange;
-                push_f(wv, bx, by - 1);
-                push_f(wv, bx, by + 1);
-                push_f(wv, bx - 1, by);
-                push_f(wv, bx + 1, by);
+                push_pat(wv, bx, by, PAT_SQ + 1, 4, 1, 2, MV_COST); // (0,-1) (0,1) (-1,0) (1,0)
                 st = ST_DIA;
             }
             else if (method == X265_HIP_HEX)
@@ -410,27 +452,16 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
         // ---- DIA: radius-1 diamond, packed (cost << 4) + code, centre wins ties (motion.cpp:605-626)
         case ST_DIA:
         {
-            int best = bcost << 4;
-            best = min(best, (q_cost(wv, 0) << 4) + 1);
-            best = min(best, (q_cost(wv, 1) << 4) + 3);
-            best = min(best, (q_cost(wv, 2) << 4) + 4);
-            best = min(best, (q_cost(wv, 3) << 4) + 12);
+            // the reference packs (cost << 4) + code with codes 1, 3, 4, 12 in visiting order and takes the
+            // minimum against bcost << 4: the first minimum, if strictly better than the centre
             wv.nq = 0;
-            if (!(best & 15))
+            if (!take_ring(0, 4, 1))
             {
                 st = ST_POST;
                 break;
             }
-            bx = s16(bx - (((int)((unsigned)best << 28)) >> 30));
-            by = s16(by - (((int)((unsigned)best << 30)) >> 30));
-            bcost = best >> 4;
             if (--cnt && IN_RANGE(bx, by))
-            {
-                push_f(wv, bx, by - 1);
-                push_f(wv, bx, by + 1);
-                push_f(wv, bx - 1, by);
-                push_f(wv, bx + 1, by);
-            }
+                push_pat(wv, bx, by, PAT_SQ + 1, 4, 1, 2, MV_COST);
             else
                 st = ST_POST;
             break;
@@ -438,8 +469,7 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
 
         // ---- HEX: radius-2 hexagon then square refine (motion.cpp:628-700)
         case ST_HEX_BEGIN:
-            for (int k = 1; k <= 6; k++) // hex2[1..6] = (-2,0)(-1,2)(1,2)(2,0)(1,-2)(-1,-2): codes 2..7
-                push_f(wv, bx + k_hex2[k][0], by + k_hex2[k][1]);
+            push_pat(wv, bx, by, PAT_HEX + 1, 6, 1, 2, MV_COST); // hex2[1..6]: directions 0..5
             if (spec_sq)
                 push_square();
             st = ST_HEX1;
@@ -448,52 +478,43 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
         case ST_HEX1:
         case ST_HEXN:
         {
-            bool go_on = false;
+            bool go_on = false, moved = false;
             const int nstep = st == ST_HEX1 ? 6 : 3; // the speculated square sits behind the step's points
-            if (st == ST_HEX1)
+            // the reference's packed minimum ((cost << 3) + code against bcost << 3): first minimum of the
+            // step if strictly better than the centre
+            const int key = q_argmin(wv, 0, nstep);
+            wv.nq = 0;
+            if ((key >> 4) < bcost)
             {
-                packed = bcost << 3;
-                for (int k = 0; k < 6; k++)
-                    packed = min(packed, (q_cost(wv, k) << 3) + (k + 2));
-                wv.nq = 0;
-                if (packed & 7)
+                moved = true;
+                bcost = key >> 4;
+                if (st == ST_HEX1)
                 {
-                    dir = (packed & 7) - 2;
-                    bx = s16(bx + k_hex2[dir + 1][0]);
-                    by = s16(by + k_hex2[dir + 1][1]);
+                    dir = key & 15;
                     cnt = (merange >> 1) - 1;
-                    go_on = cnt > 0 && IN_RANGE(bx, by);
                 }
-            }
-            else
-            {
-                packed &= ~7;
-                for (int k = 0; k < 3; k++)
-                    packed = min(packed, (q_cost(wv, k) << 3) + (k + 1));
-                wv.nq = 0;
-                if (packed & 7)
+                else
                 {
-                    dir += (packed & 7) - 2;
-                    dir = k_mod6m1[dir + 1];
-                    bx = s16(bx + k_hex2[dir + 1][0]);
-                    by = s16(by + k_hex2[dir + 1][1]);
+                    dir += (key & 15) - 1;
+                    dir = dir < 0 ? dir + 6 : (dir >= 6 ? dir - 6 : dir); // mod6m1
                     cnt--;
-                    go_on = cnt > 0 && IN_RANGE(bx, by);
                 }
+                const int p = pat_at(wv, PAT_HEX + dir + 1);
+                bx = s16(bx + pat_dx(p));
+                by = s16(by + pat_dy(p));
+                go_on = cnt > 0 && IN_RANGE(bx, by);
             }
             if (go_on)
             {
                 // half hexagon, not overlapping the previous one
-                for (int k = 0; k < 3; k++)
-                    push_f(wv, bx + k_hex2[dir + k][0], by + k_hex2[dir + k][1]);
+                push_pat(wv, bx, by, PAT_HEX + dir, 3, 1, 2, MV_COST);
                 if (spec_sq)
                     push_square();
                 st = ST_HEXN;
             }
             else
             {
-                bcost = packed >> 3;
-                if (spec_sq && !(packed & 7))
+                if (spec_sq && !moved)
                 {
                     take_square(nstep); // the centre stayed: the square was evaluated with this step
                     st = ST_POST;
@@ -972,11 +993,9 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
             // with hpel_satd the SATD re-measure of the centre does not depend on the ring: same group
             if (hsatd)
                 q_push(wv, bx, by, MV_COST);
-            for (int i = 1; i <= hpel_dirs; i++)
-                q_push(wv, s16(bx + k_square1[i][0] * 2), s16(by + k_square1[i][1] * 2), MV_COST);
+            push_pat(wv, bx, by, PAT_SQ + 1, hpel_dirs, 2, 0, MV_COST);
             if (spec_qp)
-                for (int i = 1; i <= qpel_dirs; i++)
-                    q_push(wv, s16(bx + k_square1[i][0]), s16(by + k_square1[i][1]), MV_COST);
+                push_pat(wv, bx, by, PAT_SQ + 1, qpel_dirs, 1, 0, MV_COST);
             st = ST_HPEL;
             break;
 
@@ -985,50 +1004,25 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
             int k = 0;
             if (hsatd && sub_it == 0)
                 bcost = q_cost(wv, k++);
-            int bdir = 0;
-            for (int i = 1; i <= hpel_dirs; i++, k++)
-            {
-                const int cost = q_cost(wv, k);
-                if (cost < bcost)
-                {
-                    bcost = cost;
-                    bdir = i;
-                }
-            }
+            const bool moved = take_ring(k, hpel_dirs, 2);
+            k += hpel_dirs;
             wv.nq = 0;
-            bx = s16(bx + k_square1[bdir][0] * 2);
-            by = s16(by + k_square1[bdir][1] * 2);
             if (++sub_it < hpel_iters)
-            {
-                for (int i = 1; i <= hpel_dirs; i++)
-                    q_push(wv, s16(bx + k_square1[i][0] * 2), s16(by + k_square1[i][1] * 2), MV_COST);
-            }
+                push_pat(wv, bx, by, PAT_SQ + 1, hpel_dirs, 2, 0, MV_COST);
             else if (!hsatd)
             {
                 metric = X265_HIP_SATD; // half-pel used SAD: re-measure with SATD before quarter-pel (:1103-1105)
                 q_push(wv, bx, by, MV_COST);
                 st = ST_REM;
             }
-            else if (spec_qp && bdir == 0)
+            else if (spec_qp && !moved)
             {
                 // the centre stayed: the first quarter-pel ring was evaluated with the half-pel ring
-                int qdir = 0;
-                for (int i = 1; i <= qpel_dirs; i++, k++)
-                {
-                    const int cost = q_cost(wv, k);
-                    if (cost < bcost)
-                    {
-                        bcost = cost;
-                        qdir = i;
-                    }
-                }
-                bx = s16(bx + k_square1[qdir][0]);
-                by = s16(by + k_square1[qdir][1]);
+                take_ring(k, qpel_dirs, 1);
                 sub_it = 1;
                 if (sub_it < qpel_iters)
                 {
-                    for (int i = 1; i <= qpel_dirs; i++)
-                        q_push(wv, s16(bx + k_square1[i][0]), s16(by + k_square1[i][1]), MV_COST);
+                    push_pat(wv, bx, by, PAT_SQ + 1, qpel_dirs, 1, 0, MV_COST);
                     st = ST_QPEL;
                 }
                 else
@@ -1050,8 +1044,7 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
             metric = X265_HIP_SATD;
             if (qpel_iters > 0)
             {
-                for (int i = 1; i <= qpel_dirs; i++)
-                    q_push(wv, s16(bx + k_square1[i][0]), s16(by + k_square1[i][1]), MV_COST);
+                push_pat(wv, bx, by, PAT_SQ + 1, qpel_dirs, 1, 0, MV_COST);
                 st = ST_QPEL;
             }
             else
@@ -1059,29 +1052,13 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
             break;
 
         case ST_QPEL:
-        {
-            int bdir = 0;
-            for (int i = 1; i <= qpel_dirs; i++)
-            {
-                const int cost = q_cost(wv, i - 1);
-                if (cost < bcost)
-                {
-                    bcost = cost;
-                    bdir = i;
-                }
-            }
+            take_ring(0, qpel_dirs, 1);
             wv.nq = 0;
-            bx = s16(bx + k_square1[bdir][0]);
-            by = s16(by + k_square1[bdir][1]);
             if (++sub_it < qpel_iters)
-            {
-                for (int i = 1; i <= qpel_dirs; i++)
-                    q_push(wv, s16(bx + k_square1[i][0]), s16(by + k_square1[i][1]), MV_COST);
-            }
+                push_pat(wv, bx, by, PAT_SQ + 1, qpel_dirs, 1, 0, MV_COST);
             else
                 st = ST_DONE;
             break;
-        }
 
         default:
             st = ST_DONE;
