@@ -49,6 +49,28 @@ __device__ __forceinline__ uint32_t ld4u(const uint8_t *p)
     return v;
 }
 
+// the same from plane memory: a global_load instead of a flat_load (which also queues on the LDS path)
+typedef const __attribute__((address_space(1))) uint8_t *gptr_t;
+__device__ __forceinline__ gptr_t as_global(const uint8_t *p) { return (gptr_t)p; }
+__device__ __forceinline__ uint32_t ld4g(gptr_t p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// 12 bytes from any byte address as three dwords, fetched as one dword-aligned 16-byte load and shifted
+// into place (the texture-address unit splits unaligned multi-dword loads; the aligned form is one pass)
+__device__ __forceinline__ void ld12g(gptr_t p, uint32_t &d0, uint32_t &d1, uint32_t &d2)
+{
+    const unsigned s = (unsigned)(uintptr_t)p & 3u;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 w = *(const __attribute__((address_space(1))) u32x4 *)(p - s);
+    d0 = __builtin_amdgcn_alignbyte(w.y, w.x, s);
+    d1 = __builtin_amdgcn_alignbyte(w.z, w.y, s);
+    d2 = __builtin_amdgcn_alignbyte(w.w, w.z, s);
+}
+
 __device__ __forceinline__ int byte_of(uint32_t v, int i)
 {
     return (int)((v >> (8 * i)) & 0xffu);
@@ -59,11 +81,12 @@ __device__ __forceinline__ int uniform(int v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-// narrowing to int16 before the clamp is what the reference does (ipfilter.cpp:105-109)
+// The reference narrows to int16 before the clamp (ipfilter.cpp:105-109).  For 8-bit input the value is
+// always inside int16 (|sum| <= 255 * 88 + offset before the shift of the pp filters, at most
+// (14248 * 88 + 526336) >> 12 for vsp), so the narrowing never changes it and a plain clamp is exact.
 __device__ __forceinline__ int clip_pixel(int v)
 {
-    int s = (int)(int16_t)v;
-    return s < 0 ? 0 : (s > 255 ? 255 : s);
+    return min(max(v, 0), 255); // v_med3_i32
 }
 
 // make LDS traffic of this wave visible to its other lanes (single-wave scope)
@@ -94,15 +117,56 @@ __device__ __constant__ const uint32_t k_taps_s8[4][2] = {
     { X265HIP_PK8(0, 1, -5, 17), X265HIP_PK8(58, -10, 4, -1) },
 };
 
-// out[x] = seed + sum_k (byte[x + k] of the 12 signed bytes d0:d1:d2) * tap[k], x = 0..3
-__device__ __forceinline__ void tap8x4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t tlo, uint32_t thi, int seed, int out[4])
+// the same vertical taps as 16-bit pairs for v_dot2_i32_i16 over row pairs (2j, 2j + 1): entries 0..3 serve
+// output rows that start on an even row, (c0,c1) (c2,c3) (c4,c5) (c6,c7); entries 4..8 serve rows that start
+// on an odd row, (0,c0) (c1,c2) (c3,c4) (c5,c6) (c7,0)
+#define X265HIP_PK16(a, b) ((uint32_t)((a) & 0xffff) | ((uint32_t)((b) & 0xffff) << 16))
+#define X265HIP_VTAPS(c0, c1, c2, c3, c4, c5, c6, c7)                                                        \
+    { X265HIP_PK16(c0, c1), X265HIP_PK16(c2, c3), X265HIP_PK16(c4, c5), X265HIP_PK16(c6, c7), X265HIP_PK16(0, c0), \
+      X265HIP_PK16(c1, c2), X265HIP_PK16(c3, c4), X265HIP_PK16(c5, c6), X265HIP_PK16(c7, 0), 0, 0, 0 }
+__device__ __constant__ __attribute__((aligned(16))) const uint32_t k_vtaps_s16[4][12] = {
+    X265HIP_VTAPS(0, 0, 0, 64, 0, 0, 0, 0),
+    X265HIP_VTAPS(-1, 4, -10, 58, 17, -5, 1, 0),
+    X265HIP_VTAPS(-1, 4, -11, 40, 40, -11, 4, -1),
+    X265HIP_VTAPS(0, 1, -5, 17, 58, -10, 4, -1),
+};
+
+// first link of a dot-product chain with the seed as a direct operand (the compiler's accumulate-in-place
+// form would spend a v_mov per chain on it)
+template <int SEED>
+__device__ __forceinline__ int sdot4_first(uint32_t a, uint32_t b)
+{
+    int r;
+    if (SEED == 0)
+        asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    else
+        asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(SEED));
+    return r;
+}
+
+template <int SEED>
+__device__ __forceinline__ int sdot2_first(uint32_t a, uint32_t b)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(SEED));
+    return r;
+}
+
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(as_s2(a), as_s2(b), c, false);
+}
+
+// out[x] = SEED + sum_k (byte[x + k] of the 12 signed bytes d0:d1:d2) * tap[k], x = 0..3
+template <int SEED>
+__device__ __forceinline__ void tap8x4(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t tlo, uint32_t thi, int out[4])
 {
 #pragma unroll
     for (int x = 0; x < 4; x++)
     {
         const uint32_t lo = x ? __builtin_amdgcn_alignbyte(d1, d0, x) : d0;
         const uint32_t hi = x ? __builtin_amdgcn_alignbyte(d2, d1, x) : d1;
-        out[x] = __builtin_amdgcn_sdot4((int)lo, (int)tlo, __builtin_amdgcn_sdot4((int)hi, (int)thi, seed, false), false);
+        out[x] = __builtin_amdgcn_sdot4((int)lo, (int)tlo, sdot4_first<SEED>(hi, thi), false);
     }
 }
 
@@ -110,15 +174,16 @@ __device__ __forceinline__ uint32_t pack2(int lo, int hi) { return (uint32_t)lo 
 
 // Fetch (or interpolate) the 4x4 reference tile whose top-left full-pel sample is `r`, for the
 // quarter-pel fraction (xf, yf).  All work stays in registers.
-__device__ __forceinline__ void ref_tile(const uint8_t *r_, int stride, int xf, int yf, uint32_t P[4][2])
+__device__ __forceinline__ void ref_tile(const uint8_t *ref, int stride, int xf, int yf, uint32_t P[4][2])
 {
     const uint32_t bias = 0x80808080u;
+    const gptr_t r_ = as_global(ref);
     if ((xf | yf) == 0)
     {
 #pragma unroll
         for (int y = 0; y < 4; y++)
         {
-            const uint32_t d = ld4u(r_ + y * stride);
+            const uint32_t d = ld4g(r_ + y * stride);
             P[y][0] = __builtin_amdgcn_perm(0, d, 0x0c010c00);
             P[y][1] = __builtin_amdgcn_perm(0, d, 0x0c030c02);
         }
@@ -130,9 +195,11 @@ __device__ __forceinline__ void ref_tile(const uint8_t *r_, int stride, int xf, 
 #pragma unroll
         for (int y = 0; y < 4; y++)
         {
-            const uint8_t *p = r_ + y * stride - 3;
+            gptr_t p = r_ + y * stride - 3;
             int h[4];
-            tap8x4(ld4u(p) ^ bias, ld4u(p + 4) ^ bias, ld4u(p + 8) ^ bias, tlo, thi, 8192 + 32, h);
+            uint32_t d0, d1, d2;
+            ld12g(p, d0, d1, d2);
+            tap8x4<8192 + 32>(d0 ^ bias, d1 ^ bias, d2 ^ bias, tlo, thi, h);
 #pragma unroll
             for (int x = 0; x < 4; x++)
                 h[x] = clip_pixel(h[x] >> 6);
@@ -152,7 +219,7 @@ __device__ __forceinline__ void ref_tile(const uint8_t *r_, int stride, int xf, 
             uint32_t d[4];
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                d[i] = 4 * b + i < 11 ? ld4u(r_ + (4 * b + i - 3) * stride) ^ bias : 0u;
+                d[i] = 4 * b + i < 11 ? ld4g(r_ + (4 * b + i - 3) * stride) ^ bias : 0u;
             const uint32_t t0 = __builtin_amdgcn_perm(d[1], d[0], 0x05010400), t1 = __builtin_amdgcn_perm(d[1], d[0], 0x07030602);
             const uint32_t t2 = __builtin_amdgcn_perm(d[3], d[2], 0x05010400), t3 = __builtin_amdgcn_perm(d[3], d[2], 0x07030602);
             c[0][b] = __builtin_amdgcn_perm(t2, t0, 0x05040100);
@@ -164,7 +231,7 @@ __device__ __forceinline__ void ref_tile(const uint8_t *r_, int stride, int xf, 
 #pragma unroll
         for (int x = 0; x < 4; x++)
         {
-            tap8x4(c[x][0], c[x][1], c[x][2], tlo, thi, 8192 + 32, v[x]);
+            tap8x4<8192 + 32>(c[x][0], c[x][1], c[x][2], tlo, thi, v[x]);
 #pragma unroll
             for (int y = 0; y < 4; y++)
                 v[x][y] = clip_pixel(v[x][y] >> 6);
@@ -179,40 +246,46 @@ __device__ __forceinline__ void ref_tile(const uint8_t *r_, int stride, int xf, 
     else
     {
         // luma_hps (isRowExt = 1: rows -3 .. +7, value = sum - 8192, always inside int16) followed by
-        // luma_vsp: clip((sum_k im[y-3+k]*c[k] + 2048 + (8192 << 6)) >> 12), streamed row by row
+        // luma_vsp: clip((sum_k im[y-3+k]*c[k] + 2048 + (8192 << 6)) >> 12).  The 11 intermediate rows are
+        // packed in pairs (2j, 2j + 1) and the vertical taps run on v_dot2_i32_i16.
         const uint32_t tlo = k_taps_s8[xf][0], thi = k_taps_s8[xf][1];
-        const uint32_t vlo = k_taps_s8[yf][0], vhi = k_taps_s8[yf][1];
-        int cy[8];
+        const uint4 ve = *(const uint4 *)&k_vtaps_s16[yf][0], vo = *(const uint4 *)&k_vtaps_s16[yf][4];
+        const uint32_t vo4 = k_vtaps_s16[yf][8];
+        gptr_t p = r_ - 3 * stride - 3;
+        uint32_t q[6][4];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int j = 0; j < 6; j++)
         {
-            cy[k] = (int)(int8_t)(vlo >> (8 * k));
-            cy[4 + k] = (int)(int8_t)(vhi >> (8 * k));
-        }
-        int acc[4][4];
-#pragma unroll
-        for (int y = 0; y < 4; y++)
+            int a[4], b[4] = { 0, 0, 0, 0 };
+            uint32_t d0, d1, d2;
+            ld12g(p, d0, d1, d2);
+            tap8x4<0>(d0 ^ bias, d1 ^ bias, d2 ^ bias, tlo, thi, a);
+            p += stride;
+            if (j < 5)
+            {
+                ld12g(p, d0, d1, d2);
+                tap8x4<0>(d0 ^ bias, d1 ^ bias, d2 ^ bias, tlo, thi, b);
+                p += stride;
+            }
 #pragma unroll
             for (int x = 0; x < 4; x++)
-                acc[y][x] = 2048 + (8192 << 6);
+                q[j][x] = j < 5 ? __builtin_amdgcn_perm((uint32_t)b[x], (uint32_t)a[x], 0x05040100) : ((uint32_t)a[x] & 0xffffu);
+        }
+        const int seed = 2048 + (8192 << 6);
+        int o[4][4];
 #pragma unroll
-        for (int r = 0; r < 11; r++)
+        for (int x = 0; x < 4; x++)
         {
-            const uint8_t *p = r_ + (r - 3) * stride - 3;
-            int im[4];
-            tap8x4(ld4u(p) ^ bias, ld4u(p + 4) ^ bias, ld4u(p + 8) ^ bias, tlo, thi, 0, im);
-#pragma unroll
-            for (int x = 0; x < 4; x++)
-#pragma unroll
-                for (int y = 0; y < 4; y++)
-                    if (r - y >= 0 && r - y < 8)
-                        acc[y][x] += im[x] * cy[r - y];
+            o[0][x] = sdot2(q[3][x], ve.w, sdot2(q[2][x], ve.z, sdot2(q[1][x], ve.y, sdot2_first<seed>(q[0][x], ve.x))));
+            o[2][x] = sdot2(q[4][x], ve.w, sdot2(q[3][x], ve.z, sdot2(q[2][x], ve.y, sdot2_first<seed>(q[1][x], ve.x))));
+            o[1][x] = sdot2(q[4][x], vo4, sdot2(q[3][x], vo.w, sdot2(q[2][x], vo.z, sdot2(q[1][x], vo.y, sdot2_first<seed>(q[0][x], vo.x)))));
+            o[3][x] = sdot2(q[5][x], vo4, sdot2(q[4][x], vo.w, sdot2(q[3][x], vo.z, sdot2(q[2][x], vo.y, sdot2_first<seed>(q[1][x], vo.x)))));
         }
 #pragma unroll
         for (int y = 0; y < 4; y++)
         {
-            P[y][0] = pack2(clip_pixel(acc[y][0] >> 12), clip_pixel(acc[y][1] >> 12));
-            P[y][1] = pack2(clip_pixel(acc[y][2] >> 12), clip_pixel(acc[y][3] >> 12));
+            P[y][0] = pack2(clip_pixel(o[y][0] >> 12), clip_pixel(o[y][1] >> 12));
+            P[y][1] = pack2(clip_pixel(o[y][2] >> 12), clip_pixel(o[y][3] >> 12));
         }
     }
 }
@@ -222,21 +295,23 @@ __device__ __forceinline__ void ref_tile(const uint8_t *r_, int stride, int xf, 
 // exactly what the reference's 4x4 / 8x4 grouping yields (pixel.cpp:201-252).  All of it runs on packed
 // 16-bit pairs (|coefficient| <= 16 * 255); the last butterfly stage is folded into
 // |a + b| + |a - b| = 2 * max(|a|, |b|), which also supplies the division by two.
+template <bool F_GLOBAL = false> // source block in plane memory (true) or wherever `f` points, e.g. LDS (false)
 __device__ __forceinline__ int tile_metric(const uint8_t *f, int fstride, const uint32_t P[4][2], int metric)
 {
+    auto ldf = [&](int y) { return F_GLOBAL ? ld4g(as_global(f) + y * fstride) : ld4u(f + y * fstride); };
     if (metric == X265_HIP_SAD)
     {
         uint32_t acc = 0;
 #pragma unroll
         for (int y = 0; y < 4; y++)
-            acc = __builtin_amdgcn_sad_u8(ld4u(f + y * fstride), __builtin_amdgcn_perm(P[y][1], P[y][0], 0x06040200), acc);
+            acc = __builtin_amdgcn_sad_u8(ldf(y), __builtin_amdgcn_perm(P[y][1], P[y][0], 0x06040200), acc);
         return (int)acc;
     }
     s16x2 a[4], b[4];
 #pragma unroll
     for (int y = 0; y < 4; y++)
     {
-        const uint32_t fv = ld4u(f + y * fstride);
+        const uint32_t fv = ldf(y);
         a[y] = as_s2(__builtin_amdgcn_perm(0, fv, 0x0c010c00)) - as_s2(P[y][0]);
         b[y] = as_s2(__builtin_amdgcn_perm(0, fv, 0x0c030c02)) - as_s2(P[y][1]);
     }

@@ -97,7 +97,7 @@ __device__ __forceinline__ void load_fenc(Wave &wv, const uint8_t *src, int sstr
     for (int i = wv.lane; i < ndw; i += 64)
     {
         int y = i / wv.ntx, x = i - y * wv.ntx;
-        *(uint32_t *)(wv.s->fenc + y * 64 + 4 * x) = ld4u(src + y * sstride + 4 * x);
+        *(uint32_t *)(wv.s->fenc + y * 64 + 4 * x) = ld4g(as_global(src) + y * sstride + 4 * x);
     }
     wave_sync();
 }
@@ -150,7 +150,7 @@ __device__ __forceinline__ void q_eval(Wave &wv, int metric)
             uint32_t a = 0;
 #pragma unroll
             for (int y = 0; y < 4; y++)
-                a = __builtin_amdgcn_sad_u8(*(const uint32_t *)(f + y * 64), ld4u(r + y * wv.stride), a);
+                a = __builtin_amdgcn_sad_u8(*(const uint32_t *)(f + y * 64), ld4g(as_global(r) + y * wv.stride), a);
             v = (int)a;
         }
         else
@@ -235,7 +235,7 @@ __device__ __forceinline__ int lane_sad(const Wave &wv, int mx, int my)
         const uint8_t *rr = r + y * wv.stride;
         const uint8_t *ff = wv.s->fenc + y * 64;
         for (int x = 0; x < wv.ntx; x++)
-            acc = __builtin_amdgcn_sad_u8(*(const uint32_t *)(ff + 4 * x), ld4u(rr + 4 * x), acc);
+            acc = __builtin_amdgcn_sad_u8(*(const uint32_t *)(ff + 4 * x), ld4g(as_global(rr) + 4 * x), acc);
     }
     return (int)acc;
 }
@@ -1094,88 +1094,111 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void me
     motion_estimate(wv, j, &out[id]);
 }
 
-// Cost requests, sixteen per wave.  Work items are (request, 4x4 tile) pairs dealt round-robin to the 64
-// lanes, so requests of different sizes in one wave do not wait for each other: a prefix sum of the tile
-// counts sits in LDS and a lane finds its request by binary search (waves whose requests all have at most
-// four tiles skip the search: lane = 4 * request + tile).  Lanes read source and reference tiles straight
-// from the planes (a request is a single candidate, nothing is reused); partial sums meet in LDS atomics.
-#define COST_PER_WAVE 16
+// Cost requests in batches of sixteen per wave; a wave walks batches wave, wave + nwaves, ... and fetches the
+// next batch's request records while it computes the current one (the plane directory sits in LDS), so the
+// only memory latency in front of a batch's arithmetic is that of its pixel loads.
+// Work items are (request, 4x4 tile) pairs dealt round-robin to the 64 lanes, so requests of different
+// sizes in one batch do not wait for each other: a prefix sum of the tile counts sits in LDS and a lane
+// finds its request by binary search (batches whose requests all have at most four tiles skip the search:
+// lane = 4 * request + tile).  Lanes read source and reference tiles straight from the planes (a request
+// is a single candidate, nothing is reused); partial sums meet in LDS atomics.
+#define COST_BATCH 16
+#define COST_MAX_BLOCKS (256 * 6)
 
 struct CostLds
 {
-    int pre[COST_PER_WAVE + 1]; // exclusive prefix of tile counts
-    int cost[COST_PER_WAVE];
+    int pre[COST_BATCH + 1]; // exclusive prefix of tile counts
+    int cost[COST_BATCH];
     // per request, resolved once by lane k: block origins, strides, ntx | xf << 8 | yf << 10 | metric << 12
-    const uint8_t *fenc[COST_PER_WAVE];
-    const uint8_t *ref[COST_PER_WAVE];
-    int fstride[COST_PER_WAVE], rstride[COST_PER_WAVE], info[COST_PER_WAVE];
+    const uint8_t *fenc[COST_BATCH];
+    const uint8_t *ref[COST_BATCH];
+    int fstride[COST_BATCH], rstride[COST_BATCH], info[COST_BATCH];
 };
 
 __global__ __launch_bounds__(256) void cost_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
                                                    int32_t *out)
 {
     __shared__ CostLds lds[4];
+    __shared__ PlaneDesc planes[X265_HIP_MAX_PLANES];
+    static_assert(sizeof(PlaneDesc) == 16 && X265_HIP_MAX_PLANES * 4 <= 256, "plane directory copy below");
+    if (threadIdx.x < X265_HIP_MAX_PLANES * 4)
+        ((uint32_t *)planes)[threadIdx.x] = ((const uint32_t *)tabs->planes)[threadIdx.x];
+    __syncthreads();
+
     CostLds &L = lds[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
-    const int wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * COST_PER_WAVE;
-    if (wbase >= n)
-        return;
-    int nt = 0;
-    if (lane < COST_PER_WAVE && wbase + lane < n)
+    const int nbatch = (n + COST_BATCH - 1) / COST_BATCH, nwaves = gridDim.x * 4;
+    int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    x265_hip_cost_req cur = {};
+    if (lane < COST_BATCH && b * COST_BATCH + lane < n)
+        cur = reqs[b * COST_BATCH + lane];
+    for (; b < nbatch; b += nwaves)
     {
-        const x265_hip_cost_req r = reqs[wbase + lane];
-        const PlaneDesc fp = tabs->planes[r.fenc_plane], rp = tabs->planes[r.ref_plane];
-        nt = (r.pu_w >> 2) * (r.pu_h >> 2);
-        L.fenc[lane] = fp.origin + (long)r.pu_y * fp.stride + r.pu_x;
-        L.ref[lane] = rp.origin + (long)(r.pu_y + (r.qmv_y >> 2)) * rp.stride + r.pu_x + (r.qmv_x >> 2);
-        L.fstride[lane] = fp.stride;
-        L.rstride[lane] = rp.stride;
-        L.info[lane] = (r.pu_w >> 2) | ((r.qmv_x & 3) << 8) | ((r.qmv_y & 3) << 10) | (r.metric << 12);
-    }
-    const bool small = __ballot(nt > 4) == 0;
-    if (lane < COST_PER_WAVE)
-    {
-        // inclusive scan over the 16-lane row: row_shr 1, 2, 4, 8 (lanes shifted in read 0)
-        int inc = nt;
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
-        inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
-        L.pre[lane + 1] = inc;
-        L.cost[lane] = 0;
-        if (lane == 0)
-            L.pre[0] = 0;
-    }
-    wave_sync();
-    const int total = small ? 64 : L.pre[COST_PER_WAVE];
-    for (int i = lane; i < total; i += 64)
-    {
-        int k, t;
-        if (small)
+        const int base = b * COST_BATCH;
+        const bool have = lane < COST_BATCH && base + lane < n;
+        int nt = 0;
+        if (have)
         {
-            k = i >> 2;
-            t = i & 3;
+            const PlaneDesc fp = planes[cur.fenc_plane], rp = planes[cur.ref_plane];
+            nt = (cur.pu_w >> 2) * (cur.pu_h >> 2);
+            L.fenc[lane] = fp.origin + (long)cur.pu_y * fp.stride + cur.pu_x;
+            L.ref[lane] = rp.origin + (long)(cur.pu_y + (cur.qmv_y >> 2)) * rp.stride + cur.pu_x + (cur.qmv_x >> 2);
+            L.fstride[lane] = fp.stride;
+            L.rstride[lane] = rp.stride;
+            L.info[lane] = (cur.pu_w >> 2) | ((cur.qmv_x & 3) << 8) | ((cur.qmv_y & 3) << 10) | (cur.metric << 12);
         }
-        else
+        const bool small = __ballot(nt > 4) == 0;
+        if (lane < COST_BATCH)
         {
-            k = 0;
+            // inclusive scan over the 16-lane row: row_shr 1, 2, 4, 8 (lanes shifted in read 0)
+            int inc = nt;
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+            L.pre[lane + 1] = inc;
+            L.cost[lane] = 0;
+            if (lane == 0)
+                L.pre[0] = 0;
+        }
+        // next batch's records: in flight during this batch's arithmetic
+        {
+            const int nid = (b + nwaves) * COST_BATCH + lane;
+            if (lane < COST_BATCH && b + nwaves < nbatch && nid < n)
+                cur = reqs[nid];
+        }
+        wave_sync();
+        const int total = small ? 64 : L.pre[COST_BATCH];
+        for (int i = lane; i < total; i += 64)
+        {
+            int k, t;
+            if (small)
+            {
+                k = i >> 2;
+                t = i & 3;
+            }
+            else
+            {
+                k = 0;
 #pragma unroll
-            for (int step = 8; step > 0; step >>= 1)
-                if (L.pre[k + step] <= i)
-                    k += step;
-            t = i - L.pre[k];
+                for (int step = 8; step > 0; step >>= 1)
+                    if (L.pre[k + step] <= i)
+                        k += step;
+                t = i - L.pre[k];
+            }
+            if (t >= L.pre[k + 1] - L.pre[k]) // also skips requests past n (no tiles)
+                continue;
+            const int info = L.info[k], ntx = info & 255, fstride = L.fstride[k], rstride = L.rstride[k];
+            const int ty = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)ntx)), tx = t - ty * ntx; // exact: t < 256, ntx <= 16
+            uint32_t pix[4][2];
+            ref_tile(L.ref[k] + 4 * ty * rstride + 4 * tx, rstride, (info >> 8) & 3, (info >> 10) & 3, pix);
+            atomicAdd(&L.cost[k], tile_metric<true>(L.fenc[k] + 4 * ty * fstride + 4 * tx, fstride, pix, info >> 12));
         }
-        if (t >= L.pre[k + 1] - L.pre[k]) // also skips requests past n (no tiles)
-            continue;
-        const int info = L.info[k], ntx = info & 255, fstride = L.fstride[k], rstride = L.rstride[k];
-        const int ty = (int)(((float)t + 0.5f) * (1.0f / (float)ntx)), tx = t - ty * ntx; // exact for t < 256, ntx <= 16
-        uint32_t pix[4][2];
-        ref_tile(L.ref[k] + 4 * ty * rstride + 4 * tx, rstride, (info >> 8) & 3, (info >> 10) & 3, pix);
-        atomicAdd(&L.cost[k], tile_metric(L.fenc[k] + 4 * ty * fstride + 4 * tx, fstride, pix, info >> 12));
+        wave_sync();
+        if (have)
+            out[base + lane] = L.cost[lane];
+        wave_sync(); // the next batch rewrites this wave's LDS record
     }
-    wave_sync();
-    if (lane < COST_PER_WAVE && wbase + lane < n)
-        out[wbase + lane] = L.cost[lane];
 }
 
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st)
@@ -1187,7 +1210,10 @@ void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x26
 void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, hipStream_t st)
 {
     if (n > 0)
-        hipLaunchKernelGGL(cost_kernel, dim3((n + 4 * COST_PER_WAVE - 1) / (4 * COST_PER_WAVE)), dim3(256), 0, st, tabs, reqs, n, out);
+    {
+        const int blocks = ((n + COST_BATCH - 1) / COST_BATCH + 3) / 4;
+        hipLaunchKernelGGL(cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out);
+    }
 }
 
 } // namespace x265hip

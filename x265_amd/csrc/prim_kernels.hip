@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64) void prim_cmp_kernel(PrimCmpArgs a, int32_t *ou
         int ty = t / ntx, tx = t - ty * ntx;
         uint32_t pix[4][2];
         ref_tile(a.fref[c] + (long)(4 * ty) * a.rstride + 4 * tx, a.rstride, 0, 0, pix);
-        int v = tile_metric(a.fenc + (long)(4 * ty) * a.fstride + 4 * tx, a.fstride, pix, a.metric);
+        int v = tile_metric<true>(a.fenc + (long)(4 * ty) * a.fstride + 4 * tx, a.fstride, pix, a.metric);
         atomicAdd(&acc[c], v);
     }
     wave_sync();
