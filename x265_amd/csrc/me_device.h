@@ -172,16 +172,19 @@ __device__ __forceinline__ void tap8x4(uint32_t d0, uint32_t d1, uint32_t d2, ui
 
 __device__ __forceinline__ uint32_t pack2(int lo, int hi) { return (uint32_t)lo | ((uint32_t)hi << 16); } // v_lshl_or_b32
 
-// Fetch (or interpolate) the 4x4 reference tile whose top-left full-pel sample is `r`, for the
-// quarter-pel fraction (xf, yf).  All work stays in registers.
-__device__ __forceinline__ void ref_tile(const uint8_t *ref, int stride, int xf, int yf, uint32_t P[4][2])
+// Fetch (or interpolate) a strip of NT vertically stacked 4x4 reference tiles whose top-left full-pel
+// sample is `ref`, for the quarter-pel fraction (xf, yf).  All work stays in registers.  A strip of two tiles
+// filters 15 source rows instead of 2 x 11 (vertical taps overlap), which is what NT = 2 is for.
+template <int NT>
+__device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf, int yf, uint32_t P[4 * NT][2])
 {
+    constexpr int R = 4 * NT;
     const uint32_t bias = 0x80808080u;
     const gptr_t r_ = as_global(ref);
     if ((xf | yf) == 0)
     {
 #pragma unroll
-        for (int y = 0; y < 4; y++)
+        for (int y = 0; y < R; y++)
         {
             const uint32_t d = ld4g(r_ + y * stride);
             P[y][0] = __builtin_amdgcn_perm(0, d, 0x0c010c00);
@@ -192,13 +195,14 @@ __device__ __forceinline__ void ref_tile(const uint8_t *ref, int stride, int xf,
     {
         // luma_hpp: dst = clip((sum_k src[x-3+k]*c[k] + 32) >> 6)
         const uint32_t tlo = k_taps_s8[xf][0], thi = k_taps_s8[xf][1];
+        gptr_t p = r_ - 3;
 #pragma unroll
-        for (int y = 0; y < 4; y++)
+        for (int y = 0; y < R; y++)
         {
-            gptr_t p = r_ + y * stride - 3;
             int h[4];
             uint32_t d0, d1, d2;
             ld12g(p, d0, d1, d2);
+            p += stride;
             tap8x4<8192 + 32>(d0 ^ bias, d1 ^ bias, d2 ^ bias, tlo, thi, h);
 #pragma unroll
             for (int x = 0; x < 4; x++)
@@ -209,17 +213,26 @@ __device__ __forceinline__ void ref_tile(const uint8_t *ref, int stride, int xf,
     }
     else if (xf == 0)
     {
-        // luma_vpp: same rounding, taps run down the column.  The 11 source rows are transposed
-        // (v_perm_b32) into four 12-byte column vectors, which then go through the same tap8x4.
+        // luma_vpp: same rounding, taps run down the column.  The R + 7 source rows are transposed
+        // (v_perm_b32) into four column vectors of 4 (NT + 2) bytes; output row y takes bytes y .. y + 7.
+        constexpr int NB = NT + 2;
         const uint32_t tlo = k_taps_s8[yf][0], thi = k_taps_s8[yf][1];
-        uint32_t c[4][3];
+        uint32_t c[4][NB];
+        gptr_t p = r_ - 3 * stride;
 #pragma unroll
-        for (int b = 0; b < 3; b++)
+        for (int b = 0; b < NB; b++)
         {
             uint32_t d[4];
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                d[i] = 4 * b + i < 11 ? ld4g(r_ + (4 * b + i - 3) * stride) ^ bias : 0u;
+            {
+                d[i] = 0u;
+                if (4 * b + i < R + 7)
+                {
+                    d[i] = ld4g(p) ^ bias;
+                    p += stride;
+                }
+            }
             const uint32_t t0 = __builtin_amdgcn_perm(d[1], d[0], 0x05010400), t1 = __builtin_amdgcn_perm(d[1], d[0], 0x07030602);
             const uint32_t t2 = __builtin_amdgcn_perm(d[3], d[2], 0x05010400), t3 = __builtin_amdgcn_perm(d[3], d[2], 0x07030602);
             c[0][b] = __builtin_amdgcn_perm(t2, t0, 0x05040100);
@@ -227,41 +240,46 @@ __device__ __forceinline__ void ref_tile(const uint8_t *ref, int stride, int xf,
             c[2][b] = __builtin_amdgcn_perm(t3, t1, 0x05040100);
             c[3][b] = __builtin_amdgcn_perm(t3, t1, 0x07060302);
         }
-        int v[4][4]; // [x][y]
 #pragma unroll
-        for (int x = 0; x < 4; x++)
+        for (int t = 0; t < NT; t++)
         {
-            tap8x4<8192 + 32>(c[x][0], c[x][1], c[x][2], tlo, thi, v[x]);
+            int v[4][4]; // [x][y]
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                tap8x4<8192 + 32>(c[x][t], c[x][t + 1], c[x][t + 2], tlo, thi, v[x]);
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                    v[x][y] = clip_pixel(v[x][y] >> 6);
+            }
 #pragma unroll
             for (int y = 0; y < 4; y++)
-                v[x][y] = clip_pixel(v[x][y] >> 6);
-        }
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-        {
-            P[y][0] = pack2(v[0][y], v[1][y]);
-            P[y][1] = pack2(v[2][y], v[3][y]);
+            {
+                P[4 * t + y][0] = pack2(v[0][y], v[1][y]);
+                P[4 * t + y][1] = pack2(v[2][y], v[3][y]);
+            }
         }
     }
     else
     {
-        // luma_hps (isRowExt = 1: rows -3 .. +7, value = sum - 8192, always inside int16) followed by
-        // luma_vsp: clip((sum_k im[y-3+k]*c[k] + 2048 + (8192 << 6)) >> 12).  The 11 intermediate rows are
+        // luma_hps (isRowExt = 1: rows -3 .. R + 3, value = sum - 8192, always inside int16) followed by
+        // luma_vsp: clip((sum_k im[y-3+k]*c[k] + 2048 + (8192 << 6)) >> 12).  The R + 7 intermediate rows are
         // packed in pairs (2j, 2j + 1) and the vertical taps run on v_dot2_i32_i16.
+        constexpr int NP = R / 2 + 4; // row pairs; the last one holds a single row
         const uint32_t tlo = k_taps_s8[xf][0], thi = k_taps_s8[xf][1];
         const uint4 ve = *(const uint4 *)&k_vtaps_s16[yf][0], vo = *(const uint4 *)&k_vtaps_s16[yf][4];
         const uint32_t vo4 = k_vtaps_s16[yf][8];
         gptr_t p = r_ - 3 * stride - 3;
-        uint32_t q[6][4];
+        uint32_t q[NP][4];
 #pragma unroll
-        for (int j = 0; j < 6; j++)
+        for (int j = 0; j < NP; j++)
         {
             int a[4], b[4] = { 0, 0, 0, 0 };
             uint32_t d0, d1, d2;
             ld12g(p, d0, d1, d2);
             tap8x4<0>(d0 ^ bias, d1 ^ bias, d2 ^ bias, tlo, thi, a);
             p += stride;
-            if (j < 5)
+            if (j < NP - 1)
             {
                 ld12g(p, d0, d1, d2);
                 tap8x4<0>(d0 ^ bias, d1 ^ bias, d2 ^ bias, tlo, thi, b);
@@ -269,25 +287,32 @@ __device__ __forceinline__ void ref_tile(const uint8_t *ref, int stride, int xf,
             }
 #pragma unroll
             for (int x = 0; x < 4; x++)
-                q[j][x] = j < 5 ? __builtin_amdgcn_perm((uint32_t)b[x], (uint32_t)a[x], 0x05040100) : ((uint32_t)a[x] & 0xffffu);
+                q[j][x] = j < NP - 1 ? __builtin_amdgcn_perm((uint32_t)b[x], (uint32_t)a[x], 0x05040100) : ((uint32_t)a[x] & 0xffffu);
         }
         const int seed = 2048 + (8192 << 6);
-        int o[4][4];
 #pragma unroll
-        for (int x = 0; x < 4; x++)
+        for (int y = 0; y < R; y += 2)
         {
-            o[0][x] = sdot2(q[3][x], ve.w, sdot2(q[2][x], ve.z, sdot2(q[1][x], ve.y, sdot2_first<seed>(q[0][x], ve.x))));
-            o[2][x] = sdot2(q[4][x], ve.w, sdot2(q[3][x], ve.z, sdot2(q[2][x], ve.y, sdot2_first<seed>(q[1][x], ve.x))));
-            o[1][x] = sdot2(q[4][x], vo4, sdot2(q[3][x], vo.w, sdot2(q[2][x], vo.z, sdot2(q[1][x], vo.y, sdot2_first<seed>(q[0][x], vo.x)))));
-            o[3][x] = sdot2(q[5][x], vo4, sdot2(q[4][x], vo.w, sdot2(q[3][x], vo.z, sdot2(q[2][x], vo.y, sdot2_first<seed>(q[1][x], vo.x)))));
-        }
+            const int j = y >> 1; // output row y starts on source row y = pair j; row y + 1 in the middle of pair j
+            int e[4], o[4];
 #pragma unroll
-        for (int y = 0; y < 4; y++)
-        {
-            P[y][0] = pack2(clip_pixel(o[y][0] >> 12), clip_pixel(o[y][1] >> 12));
-            P[y][1] = pack2(clip_pixel(o[y][2] >> 12), clip_pixel(o[y][3] >> 12));
+            for (int x = 0; x < 4; x++)
+            {
+                e[x] = sdot2(q[j + 3][x], ve.w, sdot2(q[j + 2][x], ve.z, sdot2(q[j + 1][x], ve.y, sdot2_first<seed>(q[j][x], ve.x))));
+                o[x] = sdot2(q[j + 4][x], vo4, sdot2(q[j + 3][x], vo.w, sdot2(q[j + 2][x], vo.z, sdot2(q[j + 1][x], vo.y, sdot2_first<seed>(q[j][x], vo.x)))));
+            }
+            P[y][0] = pack2(clip_pixel(e[0] >> 12), clip_pixel(e[1] >> 12));
+            P[y][1] = pack2(clip_pixel(e[2] >> 12), clip_pixel(e[3] >> 12));
+            P[y + 1][0] = pack2(clip_pixel(o[0] >> 12), clip_pixel(o[1] >> 12));
+            P[y + 1][1] = pack2(clip_pixel(o[2] >> 12), clip_pixel(o[3] >> 12));
         }
     }
+}
+
+// one 4x4 tile
+__device__ __forceinline__ void ref_tile(const uint8_t *ref, int stride, int xf, int yf, uint32_t P[4][2])
+{
+    ref_strip<1>(ref, stride, xf, yf, P);
 }
 
 // SAD or SATD of one 4x4 tile.  `f` walks the source block with `fstride`.

@@ -1094,22 +1094,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void me
     motion_estimate(wv, j, &out[id]);
 }
 
-// Cost requests in batches of sixteen per wave; a wave walks batches wave, wave + nwaves, ... and fetches the
+// Cost requests in batches of 32 per wave; a wave walks batches wave, wave + nwaves, ... and fetches the
 // next batch's request records while it computes the current one (the plane directory sits in LDS), so the
 // only memory latency in front of a batch's arithmetic is that of its pixel loads.
-// Work items are (request, 4x4 tile) pairs dealt round-robin to the 64 lanes, so requests of different
-// sizes in one batch do not wait for each other: a prefix sum of the tile counts sits in LDS and a lane
-// finds its request by binary search (batches whose requests all have at most four tiles skip the search:
-// lane = 4 * request + tile).  Lanes read source and reference tiles straight from the planes (a request
-// is a single candidate, nothing is reused); partial sums meet in LDS atomics.
-#define COST_BATCH 16
+// Work items are (request, strip) pairs dealt round-robin to the 64 lanes, a strip being 4 pixels wide and 8
+// tall (4 tall for block heights that are not multiples of 8), so requests of different sizes in one batch do
+// not wait for each other: a prefix sum of the item counts sits in LDS and a lane finds its request by binary
+// search (batches whose requests all have at most two items skip the search: lane = 2 * request + item).
+// Lanes read source and reference pixels straight from the planes (a request is a single candidate, nothing
+// is reused); partial sums meet in LDS atomics.
+#define COST_BATCH 32
 #define COST_MAX_BLOCKS (256 * 6)
 
 struct CostLds
 {
-    int pre[COST_BATCH + 1]; // exclusive prefix of tile counts
+    int pre[COST_BATCH + 1]; // exclusive prefix of item counts
     int cost[COST_BATCH];
-    // per request, resolved once by lane k: block origins, strides, ntx | xf << 8 | yf << 10 | metric << 12
+    // per request, resolved once by lane k: block origins, strides,
+    // ntx | xf << 8 | yf << 10 | metric << 12 | (8-row strips) << 13
     const uint8_t *fenc[COST_BATCH];
     const uint8_t *ref[COST_BATCH];
     int fstride[COST_BATCH], rstride[COST_BATCH], info[COST_BATCH];
@@ -1136,26 +1138,31 @@ __global__ __launch_bounds__(256) void cost_kernel(const DeviceTables *tabs, con
     {
         const int base = b * COST_BATCH;
         const bool have = lane < COST_BATCH && base + lane < n;
-        int nt = 0;
+        int ni = 0;
         if (have)
         {
             const PlaneDesc fp = planes[cur.fenc_plane], rp = planes[cur.ref_plane];
-            nt = (cur.pu_w >> 2) * (cur.pu_h >> 2);
+            const int tall = (cur.pu_h & 7) == 0;
+            ni = (cur.pu_w >> 2) * (cur.pu_h >> (2 + tall));
             L.fenc[lane] = fp.origin + (long)cur.pu_y * fp.stride + cur.pu_x;
             L.ref[lane] = rp.origin + (long)(cur.pu_y + (cur.qmv_y >> 2)) * rp.stride + cur.pu_x + (cur.qmv_x >> 2);
             L.fstride[lane] = fp.stride;
             L.rstride[lane] = rp.stride;
-            L.info[lane] = (cur.pu_w >> 2) | ((cur.qmv_x & 3) << 8) | ((cur.qmv_y & 3) << 10) | (cur.metric << 12);
+            L.info[lane] = (cur.pu_w >> 2) | ((cur.qmv_x & 3) << 8) | ((cur.qmv_y & 3) << 10) | (cur.metric << 12) | (tall << 13);
         }
-        const bool small = __ballot(nt > 4) == 0;
+        const bool small = __ballot(ni > 2) == 0;
         if (lane < COST_BATCH)
         {
-            // inclusive scan over the 16-lane row: row_shr 1, 2, 4, 8 (lanes shifted in read 0)
-            int inc = nt;
+            // inclusive scan: row_shr 1, 2, 4, 8 inside each 16-lane row (lanes shifted in read 0), then the
+            // first row's total onto the second row
+            int inc = ni;
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+            const int row0 = __builtin_amdgcn_readlane(inc, 15);
+            if (lane >= 16)
+                inc += row0;
             L.pre[lane + 1] = inc;
             L.cost[lane] = 0;
             if (lane == 0)
@@ -1174,25 +1181,38 @@ __global__ __launch_bounds__(256) void cost_kernel(const DeviceTables *tabs, con
             int k, t;
             if (small)
             {
-                k = i >> 2;
-                t = i & 3;
+                k = i >> 1;
+                t = i & 1;
             }
             else
             {
                 k = 0;
 #pragma unroll
-                for (int step = 8; step > 0; step >>= 1)
+                for (int step = 16; step > 0; step >>= 1)
                     if (L.pre[k + step] <= i)
                         k += step;
                 t = i - L.pre[k];
             }
-            if (t >= L.pre[k + 1] - L.pre[k]) // also skips requests past n (no tiles)
+            if (t >= L.pre[k + 1] - L.pre[k]) // also skips requests past n (no items)
                 continue;
             const int info = L.info[k], ntx = info & 255, fstride = L.fstride[k], rstride = L.rstride[k];
+            const int xf = (info >> 8) & 3, yf = (info >> 10) & 3, metric = (info >> 12) & 1;
             const int ty = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)ntx)), tx = t - ty * ntx; // exact: t < 256, ntx <= 16
-            uint32_t pix[4][2];
-            ref_tile(L.ref[k] + 4 * ty * rstride + 4 * tx, rstride, (info >> 8) & 3, (info >> 10) & 3, pix);
-            atomicAdd(&L.cost[k], tile_metric<true>(L.fenc[k] + 4 * ty * fstride + 4 * tx, fstride, pix, info >> 12));
+            int v;
+            if (info >> 13)
+            {
+                const uint8_t *f = L.fenc[k] + 8 * ty * fstride + 4 * tx;
+                uint32_t pix[8][2];
+                ref_strip<2>(L.ref[k] + 8 * ty * rstride + 4 * tx, rstride, xf, yf, pix);
+                v = tile_metric<true>(f, fstride, pix, metric) + tile_metric<true>(f + 4 * fstride, fstride, pix + 4, metric);
+            }
+            else
+            {
+                uint32_t pix[4][2];
+                ref_strip<1>(L.ref[k] + 4 * ty * rstride + 4 * tx, rstride, xf, yf, pix);
+                v = tile_metric<true>(L.fenc[k] + 4 * ty * fstride + 4 * tx, fstride, pix, metric);
+            }
+            atomicAdd(&L.cost[k], v);
         }
         wave_sync();
         if (have)
