@@ -52,6 +52,10 @@ enum
 /* search methods, values of the reference's X265_*_SEARCH (source/x265.h:143-147) */
 enum { X265_HIP_DIA = 0, X265_HIP_HEX = 1, X265_HIP_UMH = 2, X265_HIP_STAR = 3, X265_HIP_FULL = 4 };
 enum { X265_HIP_SAD = 0, X265_HIP_SATD = 1 };
+/* OR-ed into x265_hip_me_job::method: the reference is a Lowres (ReferencePlanes::isLowres, lowres.h:42):
+ * ref_plane .. ref_plane + 3 are lowresPlane[0..3] with one stride, the block must be the lookahead's 8x8 CU,
+ * and sub-pel costs come from lowresQPelCost (lowres.h:73-93) along motion.cpp:556-557, 587-588, 1055-1080 */
+#define X265_HIP_LOWRES_REF 0x80
 
 #define X265_HIP_MAX_MVC    12  /* AMVP + spatial candidates, <= 11 in the reference (TEncSearch.cpp:2311) */
 #define X265_HIP_MAX_PLANES 64
@@ -124,6 +128,26 @@ int x265_hip_plane_upload(x265_hip_ctx *ctx, int plane_id, const uint8_t *host_b
 int x265_hip_plane_bind(x265_hip_ctx *ctx, int plane_id, const void *device_buf, size_t bytes, int stride,
                         int origin_offset);
 int x265_hip_plane_release(x265_hip_ctx *ctx, int plane_id);
+/* copy a plane's buffer back to the host (synchronous; `bytes` at most the size it was created with) */
+int x265_hip_plane_download(x265_hip_ctx *ctx, int plane_id, uint8_t *host_buf, size_t bytes);
+
+/* ---- lookahead planes ---------------------------------------------------
+ * Lowres::create + Lowres::init (source/common/lowres.cpp:30-69, 164-174): the half-resolution plane and
+ * its three half-pel companions (frame_init_lowres_core, source/common/pixel.cpp:595-618), edge-extended
+ * by marginX / marginY (extendPicBorder, pixel.cpp:893-911), made on the device from plane `src_plane`
+ * (a full-resolution picture of `width` x `height` with margins of at least 2 samples right and below).
+ * Fills plane ids dst_plane0 .. dst_plane0 + 3 = lowresPlane[0..3] (owned by the context, released with
+ * x265_hip_plane_release).  Asynchronous on the context's stream. */
+typedef struct x265_hip_lowres_geometry
+{
+    int width, lines;  /* half resolution, rounded up to multiples of the 8x8 lookahead CU */
+    int stride;        /* width / 2 + 2 marginX, rounded up to a multiple of 32 (lowres.cpp:36-38) */
+    int origin_offset; /* stride * marginY + marginX */
+    size_t bytes;      /* stride * (lines + 2 marginY) */
+} x265_hip_lowres_geometry;
+int x265_hip_lowres_geometry_of(int width, int height, int margin_x, int margin_y, x265_hip_lowres_geometry *out);
+int x265_hip_lowres_init(x265_hip_ctx *ctx, int src_plane, int width, int height, int margin_x, int margin_y,
+                         int dst_plane0);
 
 /* One lambda-scaled MVD cost row as BitCost::setQP builds it (source/encoder/bitcost.cpp:31-56):
  * tab[32768 + d] = cost of difference d, d in [-32768, 32767].  The table is an input: it is made
@@ -156,7 +180,7 @@ typedef struct x265_hip_me_job
     int32_t ref_plane;  /* ReferencePlanes::fpelPlane / lumaStride (lowres.h:36-50) */
     int16_t pu_x, pu_y; /* setSourcePU offset, as picture coordinates (motion.cpp:110-126) */
     uint8_t pu_w, pu_h;
-    uint8_t method;     /* setSearchMethod: X265_HIP_DIA .. X265_HIP_FULL */
+    uint8_t method;     /* setSearchMethod: X265_HIP_DIA .. X265_HIP_FULL, optionally | X265_HIP_LOWRES_REF */
     uint8_t subme;      /* setSubpelRefine: 0..7, workload[] of motion.cpp:47-57 */
     int16_t mvmin_x, mvmin_y, mvmax_x, mvmax_y; /* full-pel, inclusive */
     int16_t qmvp_x, qmvp_y;                     /* quarter-pel predictor */

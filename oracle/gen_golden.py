@@ -8,6 +8,8 @@ been run.  The fixtures hold inputs and the reference's outputs (data, no refere
               hps / vsp output buffers for all 25 partitions (input classes of the reference's
               TestBench: random, all-0, all-255; fref strides 64 and 59)
   bitcost.npz CRC32 and probe entries of BitCost::setQP's table for qp 0..69
+  lowres.npz  CRC32s of the 12 lookahead planes (frame_init_lowres_core + extendPicBorder) of the same pictures and
+              motionEstimate call records against them (ref->isLowres)
   me.npz      motionEstimate call records (inputs) and (cost, qmv) results on a small synthetic
               sequence for every search method and sub-pel level, plus two per-CTU full searches
 
@@ -120,6 +122,22 @@ def gen_me(R):
                         plane_crc=np.array([crc(p.buf) for p in planes], np.uint32))
 
 
+def gen_lowres(R):
+    """lookahead planes (Lowres::init) of the golden sequence and motionEstimate calls against them"""
+    from conftest import random_lowres_jobs
+    planes = golden_sequence()
+    low, size = [], None
+    for p in planes:
+        four, size = R.lowres_planes(p.buf, p.origin, p.stride, p.w, p.h)
+        low += four
+    rng = np.random.default_rng(78)
+    jobs = random_lowres_jobs(rng, 400, size[0], size[1], pyoracle.ME_JOB)
+    tabs = {q: R.bitcost_table(q) for q in (12, 20, 33)}
+    res = R.me_batch(low, tabs, jobs)
+    np.savez_compressed(os.path.join(OUT, "lowres.npz"), jobs=jobs, results=res, size=np.array(size, np.int32),
+                        plane_crc=np.array([crc(b) for (b, _, _) in low], np.uint32))
+
+
 def main():
     if not pyoracle.have_ref():
         sys.exit("oracle/_ref/libx265ref.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -128,6 +146,7 @@ def main():
     gen_prims(R)
     gen_bitcost(R)
     gen_me(R)
+    gen_lowres(R)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -147,6 +147,26 @@ class Checker:
         self._f("cost_batch")(self._planes(planes), _ptr(reqs), C.c_int(len(reqs)), _ptr(out), C.c_int(nthreads))
         return out
 
+    def lowres_planes(self, src, src_origin, src_stride, width, height, margin_x=96, margin_y=80):
+        """Lowres::create + Lowres::init restated on numpy buffers (common/lowres.cpp:30-69, 164-174):
+        `width` x `height` is the full-resolution picture; returns four padded planes as
+        (buffer, origin, stride) plus the rounded lowres (width, lines).  frame_init_lowres_core and
+        extendPicBorder are the checker library's."""
+        lw, ll = width // 2, height // 2
+        stride = lw + 2 * margin_x
+        if stride & 31:
+            stride += 32 - (stride & 31)
+        lw, ll = -(-lw // 8) * 8, -(-ll // 8) * 8
+        origin = stride * margin_y + margin_x
+        bufs = [np.zeros(stride * (ll + 2 * margin_y), np.uint8) for _ in range(4)]
+        self._f("frame_init_lowres")(_ptr(src, src_origin), _ptr(bufs[0], origin), _ptr(bufs[1], origin),
+                                     _ptr(bufs[2], origin), _ptr(bufs[3], origin), C.c_ssize_t(src_stride),
+                                     C.c_ssize_t(stride), C.c_int(lw), C.c_int(ll))
+        for b in bufs:
+            self._f("extend_pic_border")(_ptr(b, origin), C.c_ssize_t(stride), C.c_int(lw), C.c_int(ll),
+                                         C.c_int(margin_x), C.c_int(margin_y))
+        return [(b, origin, stride) for b in bufs], (lw, ll)
+
     def ctu_fullsearch(self, fenc, ref, costtab, ctu_x, ctu_y, mvmin, mvmax, qmvp):
         out = np.zeros(85, ME_RESULT)
         pl = self._planes([fenc, ref])

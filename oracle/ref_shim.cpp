@@ -129,10 +129,13 @@ static void run_me(MotionEstimate &me, const x265o_plane *planes, const x265o_me
     ReferencePlanes ref;
     ref.fpelPlane = (pixel *)p.origin;
     ref.lumaStride = (int)p.stride;
-    ref.isLowres = false;
+    ref.isLowres = (j->method & X265O_LOWRES_REF) != 0;
     ref.isWeighted = false;
+    if (ref.isLowres) /* a Lowres: planes[ref_plane .. ref_plane + 3] are lowresPlane[0..3] (lowres.cpp:66-69, 174) */
+        for (int i = 0; i < 4; i++)
+            ref.lowresPlane[i] = (pixel *)planes[j->ref_plane + i].origin;
     me.setSourcePlane((pixel *)f.origin, f.stride);
-    me.setSearchMethod(j->method);
+    me.setSearchMethod(j->method & ~X265O_LOWRES_REF);
     me.setSubpelRefine(j->subme);
     me.setQP(j->qp);
     me.setSourcePU(j->pu_x + j->pu_y * (int)f.stride, j->pu_w, j->pu_h);
@@ -194,6 +197,19 @@ void x265r_me_batch(const x265o_plane *planes, const uint16_t *const *costtabs, 
         pthread_join(th[t], 0);
     delete[] sl;
     delete[] th;
+}
+
+void x265r_frame_init_lowres(const uint8_t *src0, uint8_t *dst0, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc,
+                             intptr_t src_stride, intptr_t dst_stride, int width, int height)
+{
+    init();
+    g_c.frame_init_lowres_core((pixel *)src0, dst0, dsth, dstv, dstc, src_stride, dst_stride, width, height);
+}
+
+void x265r_extend_pic_border(uint8_t *pic, intptr_t stride, int width, int height, int marginX, int marginY)
+{
+    init();
+    extendPicBorder(pic, (int)stride, width, height, marginX, marginY); /* uses primitives.extendRowBorder */
 }
 
 int x265r_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, int y, int w, int h, int qmvx,

@@ -253,6 +253,7 @@ typedef struct
     intptr_t stride;
     const uint16_t *tab;   /* 65536 entries, centre at +32768 */
     int mvpx, mvpy;        /* setMVP bias                  ref: encoder/bitcost.h:42 */
+    const uint8_t *lowres[4]; /* ReferencePlanes::lowresPlane[] at the PU origin when ref->isLowres, else NULL */
 } me_ctx;
 
 /* mvcost() sums two uint16 entries and truncates to uint16 (bitcost.h:45).  Indices are
@@ -282,9 +283,41 @@ static inline int cost_fpel(const me_ctx *c, int mx, int my)
     return sad_at(c, mx, my) + mvcost_q(c, s16(mx << 2), s16(my << 2));
 }
 
-/* ref: MotionEstimate::subpelCompare, motion.cpp:1126-1164 */
+/* ref: ReferencePlanes::lowresQPelCost, common/lowres.h:73-93; pixelavg_pp, common/pixel.cpp:546-560.
+ * The reference always averages an 8x8 block here (the lookahead's only block size). */
+static int lowres_qpel_cost(const me_ctx *c, int qx, int qy, int use_satd)
+{
+    const uint8_t *cmp;
+    intptr_t cmpstride;
+    uint8_t buf[8 * 8];
+    if ((qx | qy) & 1)
+    {
+        int hpelA = (qy & 2) | ((qx & 2) >> 1);
+        const uint8_t *a = c->lowres[hpelA] + (qx >> 2) + (qy >> 2) * c->stride;
+        int bx = s16(qx + (qx & 1) * 2), by = s16(qy + (qy & 1) * 2);
+        int hpelB = (by & 2) | ((bx & 2) >> 1);
+        const uint8_t *b = c->lowres[hpelB] + (bx >> 2) + (by >> 2) * c->stride;
+        for (int y = 0; y < 8; y++)
+            for (int x = 0; x < 8; x++)
+                buf[y * 8 + x] = (uint8_t)((a[y * c->stride + x] + b[y * c->stride + x] + 1) >> 1);
+        cmp = buf;
+        cmpstride = 8;
+    }
+    else
+    {
+        int hpel = (qy & 2) | ((qx & 2) >> 1);
+        cmp = c->lowres[hpel] + (qx >> 2) + (qy >> 2) * c->stride;
+        cmpstride = c->stride;
+    }
+    return use_satd ? x265o_satd(c->part, c->fenc, 64, cmp, cmpstride) : sad_wh(c->w, c->h, c->fenc, 64, cmp, cmpstride);
+}
+
+/* ref: MotionEstimate::subpelCompare, motion.cpp:1126-1164 (lowres references: lowresQPelCost instead,
+ * motion.cpp:556-557, 587-588, 1055-1080) */
 static int subpel_cost(const me_ctx *c, int qx, int qy, int use_satd)
 {
+    if (c->lowres[0])
+        return lowres_qpel_cost(c, qx, qy, use_satd);
     int xf = qx & 3, yf = qy & 3;
     const uint8_t *p = c->fref + (qx >> 2) + (qy >> 2) * c->stride;
     uint8_t buf[64 * 64];
@@ -496,11 +529,17 @@ static void umh_cross(srch *s, mv_t o, int start, int x_max, int y_max)
     }
 }
 
-/* ref: MotionEstimate::motionEstimate, motion.cpp:526-1124 (non-lowres branch) */
+/* ref: MotionEstimate::motionEstimate, motion.cpp:526-1124.  With X265O_LOWRES_REF set in j->method the
+ * reference is a Lowres (ref->isLowres): refpl[0..3] are lowresPlane[0..3] (same stride), the block is the
+ * lookahead's 8x8 CU and sub-pel positions come from the four half-pel planes. */
 static int motion_estimate(const x265o_plane *fencpl, const x265o_plane *refpl, const uint16_t *costtab,
                            const x265o_me_job *j, mv_t *out)
 {
     me_ctx c;
+    const int lowres = (j->method & X265O_LOWRES_REF) != 0;
+    const int method = j->method & ~X265O_LOWRES_REF;
+    for (int i = 0; i < 4; i++)
+        c.lowres[i] = lowres ? refpl[i].origin + j->pu_x + (intptr_t)j->pu_y * refpl[0].stride : 0;
     c.w = j->pu_w;
     c.h = j->pu_h;
     c.part = x265o_partition_from_sizes(c.w, c.h);
@@ -575,7 +614,7 @@ static int motion_estimate(const x265o_plane *fencpl, const x265o_plane *refpl, 
     pmv.y = s16(s16(pmv.y + 2) >> 2);
     mv_t omv = s.bmv;
 
-    switch (j->method)
+    switch (method)
     {
     case 0: /* DIA, motion.cpp:605-626: packed (cost<<4)+code, centre wins ties, lowest code next */
     {
@@ -889,6 +928,37 @@ static int motion_estimate(const x265o_plane *fencpl, const x265o_plane *refpl, 
     {
         bcost = mvcost_q(&c, bx, by); /* :1049-1054 */
     }
+    else if (lowres)
+    {
+        /* motion.cpp:1055-1080: one half-pel ring with SAD, SATD re-measure, one quarter-pel ring with SATD */
+        int bdir = 0;
+        for (int i = 1; i <= k_workload[j->subme].hpel_dirs; i++)
+        {
+            int qx = s16(bx + k_square1[i][0] * 2), qy = s16(by + k_square1[i][1] * 2);
+            int cost = subpel_cost(&c, qx, qy, 0) + mvcost_q(&c, qx, qy);
+            if (cost < bcost)
+            {
+                bcost = cost;
+                bdir = i;
+            }
+        }
+        bx = s16(bx + k_square1[bdir][0] * 2);
+        by = s16(by + k_square1[bdir][1] * 2);
+        bcost = subpel_cost(&c, bx, by, 1) + mvcost_q(&c, bx, by);
+        bdir = 0;
+        for (int i = 1; i <= k_workload[j->subme].qpel_dirs; i++)
+        {
+            int qx = s16(bx + k_square1[i][0]), qy = s16(by + k_square1[i][1]);
+            int cost = subpel_cost(&c, qx, qy, 1) + mvcost_q(&c, qx, qy);
+            if (cost < bcost)
+            {
+                bcost = cost;
+                bdir = i;
+            }
+        }
+        bx = s16(bx + k_square1[bdir][0]);
+        by = s16(by + k_square1[bdir][1]);
+    }
     else
     {
         const int hsatd = k_workload[j->subme].hpel_satd;
@@ -941,6 +1011,7 @@ int x265o_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, in
                       int qmvy, int metric)
 {
     me_ctx c;
+    c.lowres[0] = c.lowres[1] = c.lowres[2] = c.lowres[3] = 0;
     c.w = w;
     c.h = h;
     c.part = x265o_partition_from_sizes(w, h);
@@ -950,6 +1021,51 @@ int x265o_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, in
     c.mvpx = c.mvpy = 0;
     x265o_luma_copy_pp(c.part, c.fenc, 64, fenc->origin + x + (intptr_t)y * fenc->stride, fenc->stride);
     return subpel_cost(&c, qmvx, qmvy, metric);
+}
+
+/* ------------------------------------------------------------------------- */
+/* lookahead planes                                                          */
+
+/* ref: frame_init_lowres_core, common/pixel.cpp:595-618 */
+void x265o_frame_init_lowres(const uint8_t *src0, uint8_t *dst0, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc,
+                             intptr_t src_stride, intptr_t dst_stride, int width, int height)
+{
+    for (int y = 0; y < height; y++)
+    {
+        const uint8_t *src1 = src0 + src_stride, *src2 = src1 + src_stride;
+        for (int x = 0; x < width; x++)
+        {
+#define X265O_F(a, b, c, d) ((((a + b + 1) >> 1) + ((c + d + 1) >> 1) + 1) >> 1)
+            dst0[x] = (uint8_t)X265O_F(src0[2 * x], src1[2 * x], src0[2 * x + 1], src1[2 * x + 1]);
+            dsth[x] = (uint8_t)X265O_F(src0[2 * x + 1], src1[2 * x + 1], src0[2 * x + 2], src1[2 * x + 2]);
+            dstv[x] = (uint8_t)X265O_F(src1[2 * x], src2[2 * x], src1[2 * x + 1], src2[2 * x + 1]);
+            dstc[x] = (uint8_t)X265O_F(src1[2 * x + 1], src2[2 * x + 1], src1[2 * x + 2], src2[2 * x + 2]);
+#undef X265O_F
+        }
+        src0 += src_stride * 2;
+        dst0 += dst_stride;
+        dsth += dst_stride;
+        dstv += dst_stride;
+        dstc += dst_stride;
+    }
+}
+
+/* ref: extendPicBorder, common/pixel.cpp:893-911 (rows first: extendRowBorder replicates the first and last
+ * sample of every row into the margins; then whole rows of `stride` bytes are copied up and down) */
+void x265o_extend_pic_border(uint8_t *pic, intptr_t stride, int width, int height, int marginX, int marginY)
+{
+    for (int y = 0; y < height; y++)
+    {
+        uint8_t *row = pic + y * stride;
+        memset(row - marginX, row[0], marginX);
+        memset(row + width, row[width - 1], marginX);
+    }
+    uint8_t *top = pic - marginX;
+    for (int y = 0; y < marginY; y++)
+        memcpy(top - (y + 1) * stride, top, stride);
+    uint8_t *bot = pic - marginX + (height - 1) * stride;
+    for (int y = 0; y < marginY; y++)
+        memcpy(bot + (y + 1) * stride, bot, stride);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -28,6 +28,7 @@ extern "C" {
 
 #define X265O_NUM_PARTS 25
 #define X265O_MAX_MVC   12
+#define X265O_LOWRES_REF 0x80 /* OR-ed into x265o_me_job::method: the reference is a Lowres (ref->isLowres) */
 
 /* Same byte layout as x265_hip_me_job in include/x265_hip.h (declared again
  * here on purpose: the oracle shares no header with the product). */
@@ -100,6 +101,11 @@ int  x265o_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, i
 void x265o_cost_batch(const x265o_plane *planes, const x265o_cost_req *reqs, int n, int32_t *out, int nthreads);
 void x265o_me_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_me_job *jobs, int n,
                     x265o_me_result *out, int nthreads);
+
+/* lookahead planes: frame_init_lowres_core (pixel.cpp:595-618) and extendPicBorder (pixel.cpp:893-911) */
+void x265o_frame_init_lowres(const uint8_t *src0, uint8_t *dst0, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc,
+                             intptr_t src_stride, intptr_t dst_stride, int width, int height);
+void x265o_extend_pic_border(uint8_t *pic, intptr_t stride, int width, int height, int marginX, int marginY);
 
 /* Hierarchical full search used by config 2: for one 64x64 CTU at (ctu_x,ctu_y), every square PU of
  * sizes 64/32/16/8 (85 PUs, z-order within each level, levels 64,32,16,8) is searched over

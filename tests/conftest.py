@@ -81,3 +81,27 @@ def random_me_jobs(rng, n, method, subme, W, H, dtype, search_range, parts, mera
             j["mvc"][2 * c] = px + int(rng.integers(-30, 30)) if rng.integers(3) else 0
             j["mvc"][2 * c + 1] = py + int(rng.integers(-30, 30)) if rng.integers(3) else 0
     return jobs
+
+
+def random_lowres_jobs(rng, n, lw, ll, dtype, fenc_plane=4, ref_planes=(0, 8), methods=(0, 1, 2, 3), qps=(12, 20, 33)):
+    """motionEstimate calls against a Lowres reference the way the lookahead issues them (8x8 CUs, bounds of
+    slicetype.cpp:1539-1543), with every search method and sub-pel level"""
+    wcu, hcu = lw // 8, ll // 8
+    jobs = np.zeros(n, dtype)
+    for j in jobs:
+        cux, cuy = int(rng.integers(0, wcu)), int(rng.integers(0, hcu))
+        j["fenc_plane"], j["ref_plane"] = fenc_plane, int(rng.choice(ref_planes))
+        j["pu_x"], j["pu_y"], j["pu_w"], j["pu_h"] = 8 * cux, 8 * cuy, 8, 8
+        j["method"] = int(rng.choice(methods)) | 0x80
+        j["subme"] = int(rng.integers(0, 8))
+        j["mvmin_x"], j["mvmin_y"] = -cux * 8 - 8, -cuy * 8 - 8
+        j["mvmax_x"], j["mvmax_y"] = (wcu - cux - 1) * 8 + 8, (hcu - cuy - 1) * 8 + 8
+        j["qmvp_x"], j["qmvp_y"] = int(rng.integers(-24, 24)), int(rng.integers(-24, 24))
+        j["merange"] = int(rng.choice([4, 16]))
+        j["qp"] = int(rng.choice(qps))
+        nm = int(rng.integers(0, 5))
+        j["num_mvc"] = nm
+        for c in range(nm):
+            j["mvc"][2 * c] = int(rng.integers(-30, 30)) if rng.integers(3) else 0
+            j["mvc"][2 * c + 1] = int(rng.integers(-30, 30)) if rng.integers(3) else 0
+    return jobs

@@ -98,6 +98,29 @@ def test_motion_estimate_reproduces_reference_fixtures():
     ctx.close()
 
 
+def test_lookahead_planes_and_search_reproduce_reference_fixtures():
+    """lowres.npz holds the reference's own outputs: CRC32 of the 12 lookahead planes and motionEstimate
+    results against them"""
+    import zlib
+    from x265_amd import lib
+    g = np.load(os.path.join(GOLD, "lowres.npz"))
+    ctx = lib.Context(0)
+    crcs = []
+    for i, p in enumerate(golden_planes()):
+        ctx.plane_upload(20 + i, p.buf, p.stride, p.origin)
+        geo = ctx.lowres_init(20 + i, p.w, p.h, 4 * i)
+        crcs += [zlib.crc32(ctx.plane_download(4 * i + k, geo.bytes).tobytes()) & 0xffffffff for k in range(4)]
+    assert [geo.width, geo.lines] == [int(v) for v in g["size"]]
+    assert crcs == [int(v) for v in g["plane_crc"]]
+    for q in (12, 20, 33):
+        ctx.set_qp(q)
+    got = ctx.me_batch(g["jobs"])
+    want = g["results"].view(got.dtype)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, (g["jobs"][bad[0]], got[bad[0]], want[bad[0]])
+    ctx.close()
+
+
 def test_bad_arguments_are_rejected(gpu_ctx):
     from x265_amd import abi, lib
     jobs = np.zeros(1, abi.ME_JOB)

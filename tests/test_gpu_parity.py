@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import random_me_jobs
+from conftest import random_lowres_jobs, random_me_jobs
 
 pytestmark = pytest.mark.gpu
 
@@ -171,3 +171,35 @@ def test_primitive_table(oracle):
             t.luma_vsp[part](addr(s16, 2 * so), ss, addr(d1), ds, coeff)
             oracle.luma_vsp(part, s16, so, ss, d2, 0, ds, coeff)
             assert np.array_equal(d1, d2), ("vsp", part, coeff)
+
+
+def test_lowres_planes_and_search(oracle, small_seq, costtabs):
+    """x265_hip_lowres_init against the oracle's frame_init_lowres_core + extendPicBorder (every byte of the
+    four padded planes), then motionEstimate against those planes (ref->isLowres), all methods and sub-pel levels"""
+    from x265_amd import abi, lib
+    ctx = lib.Context(0)
+    low = []
+    for i, p in enumerate(small_seq):
+        ctx.plane_upload(20 + i, p.buf, p.stride, p.origin)
+        geo = ctx.lowres_init(20 + i, p.w, p.h, 4 * i)
+        want, size = oracle.lowres_planes(p.buf, p.origin, p.stride, p.w, p.h)
+        assert (geo.width, geo.lines, geo.stride, geo.origin_offset) == (size[0], size[1], want[0][2], want[0][1])
+        for k in range(4):
+            got = ctx.plane_download(4 * i + k, geo.bytes)
+            bad = np.nonzero(got != want[k][0])[0]
+            assert len(bad) == 0, f"picture {i} plane {k}: first difference at byte {bad[0]} (row {bad[0] // geo.stride}, col {bad[0] % geo.stride})"
+        low += want
+    for q in (12, 20, 33):
+        ctx.costtab_upload(q, costtabs.get(q, oracle.bitcost_table(q)))
+    rng = np.random.default_rng(6)
+    jobs = random_lowres_jobs(rng, 2000, size[0], size[1], abi.ME_JOB)
+    got = ctx.me_batch(jobs)
+    want = oracle.me_batch(low, {q: oracle.bitcost_table(q) for q in (12, 20, 33)}, jobs)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, f"job {jobs[bad[0]]} got {got[bad[0]]} want {want[bad[0]]}"
+    # a lowres job must be an 8x8 block
+    j = jobs[:1].copy()
+    j["pu_w"] = 16
+    with pytest.raises(lib.X265HipError):
+        ctx.me_batch(j)
+    ctx.close()

@@ -120,3 +120,24 @@ def test_ctu_fullsearch_cost_is_sad_plus_mvcost(oracle):
     sad = int(oracle.cost_batch(planes, req)[0])
     mvc = (int(tab[32768 + int(res[0]["mvx"])]) + int(tab[32768 + int(res[0]["mvy"])])) & 0xffff
     assert sad + mvc == int(res[0]["cost"])
+
+
+def golden_lowres(impl):
+    """the 12 lookahead planes of the golden pictures, made by `impl`: plane ids 4 p + k"""
+    low, size = [], None
+    for p in golden_planes():
+        four, size = impl.lowres_planes(p.buf, p.origin, p.stride, p.w, p.h)
+        low += four
+    return low, size
+
+
+def test_lowres_planes_and_search_match_reference_fixtures(oracle):
+    g = np.load(os.path.join(GOLD, "lowres.npz"))
+    low, size = golden_lowres(oracle)
+    assert list(size) == [int(v) for v in g["size"]]
+    assert [crc(b) for (b, _, _) in low] == [int(v) for v in g["plane_crc"]]
+    tabs = {q: oracle.bitcost_table(q) for q in (12, 20, 33)}
+    got = oracle.me_batch(low, tabs, g["jobs"])
+    want = g["results"].view(got.dtype)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, (g["jobs"][bad[0]], got[bad[0]], want[bad[0]])

@@ -3,7 +3,7 @@ Skipped where oracle/_ref/libx265ref.so is absent (it is built only where /root/
 import numpy as np
 import pytest
 
-from conftest import random_me_jobs
+from conftest import random_lowres_jobs, random_me_jobs
 from oracle import pyoracle
 
 pytestmark = pytest.mark.skipif(not pyoracle.have_ref(), reason="reference build not present")
@@ -62,3 +62,21 @@ def test_motion_estimate_flat_and_extreme_content(oracle, ref):
             jobs = random_me_jobs(rng, 60, method, int(rng.integers(0, 8)), W, H, pyoracle.ME_JOB, synth.search_range,
                                   pyoracle.PARTS, planes=(fenc, (refp,)))
             assert np.array_equal(oracle.me_batch(pl, tabs, jobs), ref.me_batch(pl, tabs, jobs))
+
+
+def test_lowres_planes_and_search(oracle, ref, small_seq):
+    """frame_init_lowres_core + extendPicBorder, and motionEstimate against a Lowres (ref->isLowres)"""
+    low_o, low_r, size = [], [], None
+    for p in small_seq:
+        a, size = oracle.lowres_planes(p.buf, p.origin, p.stride, p.w, p.h)
+        b, _ = ref.lowres_planes(p.buf, p.origin, p.stride, p.w, p.h)
+        for (x, _, _), (y, _, _) in zip(a, b):
+            assert np.array_equal(x, y)
+        low_o += a
+        low_r += b
+    rng = np.random.default_rng(5)
+    jobs = random_lowres_jobs(rng, 1500, size[0], size[1], pyoracle.ME_JOB)
+    tabs = {q: oracle.bitcost_table(q) for q in (12, 20, 33)}
+    a, b = oracle.me_batch(low_o, tabs, jobs), ref.me_batch(low_r, tabs, jobs)
+    bad = np.nonzero(a != b)[0]
+    assert len(bad) == 0, (jobs[bad[0]], a[bad[0]], b[bad[0]])

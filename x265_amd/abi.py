@@ -11,6 +11,7 @@ PARTS = [(4, 4), (8, 8), (8, 4), (4, 8), (16, 16), (16, 8), (8, 16), (16, 12), (
 
 DIA, HEX, UMH, STAR, FULL = range(5)
 SAD, SATD = 0, 1
+LOWRES_REF = 0x80  # OR-ed into ME_JOB.method: the reference is a Lowres (four half-pel planes, 8x8 blocks)
 
 ME_JOB = np.dtype([
     ("fenc_plane", "<i4"), ("ref_plane", "<i4"),

@@ -65,6 +65,7 @@ struct x265_hip_ctx
     bool tabs_dirty = true;
     void *owned_plane[X265_HIP_MAX_PLANES] = {};
     size_t plane_bytes[X265_HIP_MAX_PLANES] = {};
+    int plane_origin[X265_HIP_MAX_PLANES] = {};
     uint16_t *owned_tab[X265_HIP_MAX_QP] = {};
     Buf in, out;       // staging of the host-array batch calls
     Buf prim_a, prim_b; // staging of the primitive thunks
@@ -211,6 +212,7 @@ static int plane_set(x265_hip_ctx *c, int id, const void *dev, size_t bytes, int
     c->host_tabs.planes[id].origin = (const uint8_t *)dev + origin;
     c->host_tabs.planes[id].stride = stride;
     c->plane_bytes[id] = bytes;
+    c->plane_origin[id] = origin;
     c->tabs_dirty = true;
     return X265_HIP_OK;
 }
@@ -264,6 +266,87 @@ int x265_hip_plane_bind(x265_hip_ctx *c, int id, const void *device_buf, size_t 
         (void)hipFree(c->owned_plane[id]);
     c->owned_plane[id] = nullptr;
     return plane_set(c, id, device_buf, bytes, stride, origin);
+}
+
+int x265_hip_plane_download(x265_hip_ctx *c, int id, uint8_t *host_buf, size_t bytes)
+{
+    if (!c || !host_buf || id < 0 || id >= X265_HIP_MAX_PLANES)
+        return fail(X265_HIP_EINVAL, "plane_download: bad argument (id %d)", id);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->host_tabs.planes[id].origin || bytes > c->plane_bytes[id])
+        return fail(X265_HIP_EINVAL, "plane_download: plane %d is not set or smaller than %zu bytes", id, bytes);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(host_buf, c->host_tabs.planes[id].origin - c->plane_origin[id], bytes, hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return X265_HIP_OK;
+}
+
+int x265_hip_lowres_geometry_of(int width, int height, int margin_x, int margin_y, x265_hip_lowres_geometry *out)
+{
+    if (!out || width < 16 || height < 16 || margin_x < 0 || margin_y < 0)
+        return fail(X265_HIP_EINVAL, "lowres_geometry_of: bad argument");
+    // Lowres::create, lowres.cpp:33-48
+    int w = width / 2, l = height / 2;
+    int stride = w + 2 * margin_x;
+    if (stride & 31)
+        stride += 32 - (stride & 31);
+    w = (w + 7) / 8 * 8;
+    l = (l + 7) / 8 * 8;
+    out->width = w;
+    out->lines = l;
+    out->stride = stride;
+    out->origin_offset = stride * margin_y + margin_x;
+    out->bytes = (size_t)stride * (l + 2 * margin_y);
+    return X265_HIP_OK;
+}
+
+int x265_hip_lowres_init(x265_hip_ctx *c, int src_plane, int width, int height, int margin_x, int margin_y, int dst0)
+{
+    x265_hip_lowres_geometry g;
+    if (!c || src_plane < 0 || src_plane >= X265_HIP_MAX_PLANES || dst0 < 0 || dst0 + 3 >= X265_HIP_MAX_PLANES ||
+        (src_plane >= dst0 && src_plane <= dst0 + 3))
+        return fail(X265_HIP_EINVAL, "lowres_init: bad plane ids (src %d, dst %d..%d)", src_plane, dst0, dst0 + 3);
+    int r = x265_hip_lowres_geometry_of(width, height, margin_x, margin_y, &g);
+    if (r)
+        return r;
+    if (margin_x & 1) // padded rows are written four samples at a time
+        return fail(X265_HIP_EINVAL, "lowres_init: marginX must be even");
+    if (g.width + 2 * margin_x > g.stride)
+        return fail(X265_HIP_EINVAL, "lowres_init: rounded width %d + margins does not fit stride %d", g.width, g.stride);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->host_tabs.planes[src_plane].origin)
+        return fail(X265_HIP_EINVAL, "lowres_init: source plane %d is not set", src_plane);
+    HIP_TRY(hipSetDevice(c->device));
+    LowresArgs a;
+    a.src = c->host_tabs.planes[src_plane].origin;
+    a.src_stride = c->host_tabs.planes[src_plane].stride;
+    a.dst_stride = g.stride;
+    a.width = g.width;
+    a.lines = g.lines;
+    a.margin_x = margin_x;
+    a.margin_y = margin_y;
+    for (int k = 0; k < 4; k++)
+    {
+        const int id = dst0 + k;
+        if (!c->owned_plane[id] || c->plane_bytes[id] != g.bytes)
+        {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->owned_plane[id])
+                (void)hipFree(c->owned_plane[id]);
+            c->owned_plane[id] = nullptr;
+            HIP_TRY(hipMalloc(&c->owned_plane[id], g.bytes + 64));
+            // the reference clears the buffers (lowres.cpp:63); bytes between the padded width and the stride stay 0
+            HIP_TRY(hipMemsetAsync(c->owned_plane[id], 0, g.bytes + 64, c->stream));
+        }
+        a.dst[k] = (uint8_t *)c->owned_plane[id];
+        r = plane_set(c, id, c->owned_plane[id], g.bytes, g.stride, g.origin_offset);
+        if (r)
+            return r;
+    }
+    launch_lowres_init(a, c->stream);
+    HIP_TRY(hipGetLastError());
+    return X265_HIP_OK;
 }
 
 int x265_hip_costtab_upload(x265_hip_ctx *c, int qp, const uint16_t *tab)
@@ -345,7 +428,19 @@ static int check_jobs(const x265_hip_ctx *c, const x265_hip_me_job *jobs, int n)
         int r = check_block(c, j.fenc_plane, j.ref_plane, j.pu_w, j.pu_h, "me_job", i);
         if (r)
             return r;
-        if (j.method > X265_HIP_FULL || j.subme > 7 || j.num_mvc > X265_HIP_MAX_MVC)
+        if (j.method & X265_HIP_LOWRES_REF)
+        {
+            // a Lowres reference: the lookahead's 8x8 CU, four planes of one stride
+            if (j.pu_w != 8 || j.pu_h != 8)
+                return fail(X265_HIP_EINVAL, "me_job[%d]: a lowres reference takes 8x8 blocks only (lowres.h:83)", i);
+            if (j.ref_plane + 3 >= X265_HIP_MAX_PLANES)
+                return fail(X265_HIP_EINVAL, "me_job[%d]: lowres planes %d..%d out of range", i, j.ref_plane, j.ref_plane + 3);
+            for (int k = 1; k < 4; k++)
+                if (!c->host_tabs.planes[j.ref_plane + k].origin ||
+                    c->host_tabs.planes[j.ref_plane + k].stride != c->host_tabs.planes[j.ref_plane].stride)
+                    return fail(X265_HIP_EINVAL, "me_job[%d]: lowres plane %d missing or of another stride", i, j.ref_plane + k);
+        }
+        if ((j.method & ~X265_HIP_LOWRES_REF) > X265_HIP_FULL || j.subme > 7 || j.num_mvc > X265_HIP_MAX_MVC)
             return fail(X265_HIP_EINVAL, "me_job[%d]: method %d / subme %d / num_mvc %d out of range", i, j.method, j.subme,
                         j.num_mvc);
         if (j.qp >= X265_HIP_MAX_QP || !c->host_tabs.costtab[j.qp])

@@ -28,6 +28,16 @@ struct PrimFilterArgs
     int w, rows, coeff, kind;
 };
 
+struct LowresArgs
+{
+    const uint8_t *src;   // full-resolution picture sample (0,0)
+    uint8_t *dst[4];      // first byte of the four padded lowres buffers (lowresPlane[0..3])
+    int src_stride, dst_stride;
+    int width, lines;     // lowres picture size
+    int margin_x, margin_y;
+};
+
+void launch_lowres_init(const LowresArgs &a, hipStream_t st);
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st);
 void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, hipStream_t st);
 void launch_prim_cmp(const PrimCmpArgs &a, int32_t *out, hipStream_t st);

@@ -24,6 +24,8 @@
 
 namespace x265hip {
 
+__device__ __forceinline__ int s16(int v) { return (int)(int16_t)v; }
+
 #define QMAX 16
 #define PAT_HEX 0
 #define PAT_SQ 8
@@ -63,6 +65,10 @@ struct Wave
     int nq;
     int vc, vx, vy, va; // after an evaluation: lane k holds candidate k's cost / position / aux word
     int patv;           // lane k holds pattern entry k (same words as WaveLds::pat), for scalar reads
+    // reference is a Lowres (ReferencePlanes::isLowres): ref is lowresPlane[0], these are [1..3], all at the
+    // PU origin and of one stride
+    bool lowres;
+    const uint8_t *lref[3];
 };
 
 #define PAT(dx, dy) (int)(((uint32_t)(uint16_t)(dy) << 16) | (uint16_t)(dx))
@@ -86,6 +92,8 @@ __device__ __forceinline__ void wave_init(Wave &wv, WaveLds *s, int w, int h)
     wv.tab = nullptr;
     wv.mvpx = wv.mvpy = 0;
     wv.vc = wv.vx = wv.vy = wv.va = 0;
+    wv.lowres = false;
+    wv.lref[0] = wv.lref[1] = wv.lref[2] = nullptr;
     wv.patv = wv.lane < PAT_N ? k_pat[wv.lane] : 0;
     if (wv.lane < PAT_N)
         s->pat[wv.lane] = wv.patv; // made visible by load_fenc's wave_sync
@@ -109,6 +117,43 @@ __device__ __forceinline__ void q_push(Wave &wv, int qx, int qy, int mvmode, int
     wv.s->qy[wv.nq] = qy;
     wv.s->aux[wv.nq] = (tag << 2) | mvmode;
     wv.nq++;
+}
+
+// ReferencePlanes::lowresQPelCost's pixels for one 4x4 tile (common/lowres.h:73-93): the half-pel plane the
+// quarter-pel vector selects, or the rounded average of two of them (pixelavg_pp, common/pixel.cpp:546-560)
+// when a component is odd.  `toff` is the tile's byte offset inside the block.
+__device__ __forceinline__ void lowres_tile(const Wave &wv, int qx, int qy, int toff, uint32_t P[4][2])
+{
+    auto plane = [&](int hpel) {
+        const uint8_t *p = wv.ref;
+        p = hpel == 1 ? wv.lref[0] : p;
+        p = hpel == 2 ? wv.lref[1] : p;
+        p = hpel == 3 ? wv.lref[2] : p;
+        return as_global(p);
+    };
+    const gptr_t a = plane((qy & 2) | ((qx & 2) >> 1)) + (qx >> 2) + (qy >> 2) * wv.stride + toff;
+    uint32_t d[4];
+    if ((qx | qy) & 1)
+    {
+        const int bx = s16(qx + (qx & 1) * 2), by = s16(qy + (qy & 1) * 2);
+        const gptr_t b = plane((by & 2) | ((bx & 2) >> 1)) + (bx >> 2) + (by >> 2) * wv.stride + toff;
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            const uint32_t u = ld4g(a + y * wv.stride), v = ld4g(b + y * wv.stride);
+            d[y] = (u | v) - (((u ^ v) >> 1) & 0x7f7f7f7fu); // per byte (u + v + 1) >> 1
+        }
+    }
+    else
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+            d[y] = ld4g(a + y * wv.stride);
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+    {
+        P[y][0] = __builtin_amdgcn_perm(0, d[y], 0x0c010c00);
+        P[y][1] = __builtin_amdgcn_perm(0, d[y], 0x0c030c02);
+    }
 }
 
 // cost[c] = mv rate (per its mode) + SAD or SATD of the PU against the reference at candidate c's
@@ -156,7 +201,10 @@ __device__ __forceinline__ void q_eval(Wave &wv, int metric)
         else
         {
             uint32_t pix[4][2];
-            ref_tile(r, wv.stride, qx & 3, qy & 3, pix);
+            if (wv.lowres)
+                lowres_tile(wv, qx, qy, 4 * ty * wv.stride + 4 * tx, pix);
+            else
+                ref_tile(r, wv.stride, qx & 3, qy & 3, pix);
             v = tile_metric(f, 64, pix, metric);
         }
         atomicAdd(&s->cost[c], v);
@@ -174,7 +222,6 @@ __device__ __forceinline__ int q_x(const Wave &wv, int k) { return __builtin_amd
 __device__ __forceinline__ int q_y(const Wave &wv, int k) { return __builtin_amdgcn_readlane(wv.vy, k); }
 __device__ __forceinline__ int q_tag(const Wave &wv, int k) { return __builtin_amdgcn_readlane(wv.va, k) >> 2; }
 
-__device__ __forceinline__ int s16(int v) { return (int)(int16_t)v; }
 
 // queue a full-pel point with mvcost(mv << 2); the shift is an int16 operation in the reference
 // (mv.h:63).  tag carries (point << 16) | dist for the STAR pattern.
@@ -253,7 +300,7 @@ enum State
     ST_PRE, ST_INT_BEGIN, ST_DIA, ST_HEX_BEGIN, ST_HEX1, ST_HEXN, ST_SQ,
     ST_U0, ST_U1, ST_U2, ST_CROSS, ST_U3, ST_U3B, ST_U4, ST_U5, ST_U5B, ST_URING,
     ST_STAR_BEGIN, ST_STAR_RING, ST_STAR_END, ST_STAR_TPA, ST_STAR_AFTER_A, ST_STAR_LOOP, ST_STAR_TPB,
-    ST_RASTER, ST_POST, ST_HPEL, ST_REM, ST_QPEL_BEGIN, ST_QPEL, ST_DONE
+    ST_RASTER, ST_POST, ST_HPEL, ST_REM, ST_QPEL_BEGIN, ST_QPEL, ST_LOWRES_HPEL, ST_LOWRES_QPEL, ST_DONE
 };
 
 __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_result *out)
@@ -264,7 +311,7 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
     int point = 0, dist = 0;       // STAR bookkeeping
     const int qlox = s16(lox << 2), qloy = s16(loy << 2), qhix = s16(hix << 2), qhiy = s16(hiy << 2);
     int merange = j.merange;
-    const int method = j.method;
+    const int method = j.method & ~X265_HIP_LOWRES_REF;
     const int nmvc = j.num_mvc;
     const int subme = j.subme;
     const int hpel_iters = k_workload[subme][0], hpel_dirs = k_workload[subme][1];
@@ -988,6 +1035,15 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
                 st = ST_DONE;
                 break;
             }
+            if (wv.lowres)
+            {
+                // motion.cpp:1055-1080: one half-pel ring with SAD, then the SATD re-measure of the winner
+                // together with its quarter-pel ring; the iteration counts of workload[] are not used
+                metric = X265_HIP_SAD;
+                push_pat(wv, bx, by, PAT_SQ + 1, hpel_dirs, 2, 0, MV_COST);
+                st = ST_LOWRES_HPEL;
+                break;
+            }
             sub_it = 0;
             metric = hsatd;
             // with hpel_satd the SATD re-measure of the centre does not depend on the ring: same group
@@ -1032,6 +1088,22 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
                 st = ST_QPEL_BEGIN;
             break;
         }
+
+        case ST_LOWRES_HPEL:
+            take_ring(0, hpel_dirs, 2);
+            wv.nq = 0;
+            metric = X265_HIP_SATD;
+            q_push(wv, bx, by, MV_COST);
+            push_pat(wv, bx, by, PAT_SQ + 1, qpel_dirs, 1, 0, MV_COST);
+            st = ST_LOWRES_QPEL;
+            break;
+
+        case ST_LOWRES_QPEL:
+            bcost = q_cost(wv, 0);
+            take_ring(1, qpel_dirs, 1);
+            wv.nq = 0;
+            st = ST_DONE;
+            break;
 
         case ST_REM:
             bcost = q_cost(wv, 0);
@@ -1090,6 +1162,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void me
     wv.tab = tabs->costtab[j.qp];
     wv.mvpx = j.qmvp_x;
     wv.mvpy = j.qmvp_y;
+    if (j.method & X265_HIP_LOWRES_REF)
+    {
+        wv.lowres = true;
+        for (int k = 0; k < 3; k++)
+            wv.lref[k] = tabs->planes[j.ref_plane + 1 + k].origin + (long)j.pu_y * rp.stride + j.pu_x;
+    }
     load_fenc(wv, fp.origin + (long)j.pu_y * fp.stride + j.pu_x, fp.stride);
     motion_estimate(wv, j, &out[id]);
 }

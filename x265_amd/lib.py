@@ -31,6 +31,7 @@ EXPORTS = [
     "x265_hip_plane_bind", "x265_hip_plane_release", "x265_hip_costtab_upload", "x265_hip_cost_batch",
     "x265_hip_me_batch", "x265_hip_me_batch_device", "x265_hip_cost_batch_device", "x265_hip_fullsearch",
     "x265_hip_fullsearch_device", "x265_hip_costtab_build", "x265_hip_costtab_set_qp",
+    "x265_hip_plane_download", "x265_hip_lowres_geometry_of", "x265_hip_lowres_init",
 ]
 
 
@@ -90,6 +91,18 @@ def costtab_build(qp):
     return out
 
 
+class LowresGeometry(C.Structure):
+    _fields_ = [("width", C.c_int), ("lines", C.c_int), ("stride", C.c_int), ("origin_offset", C.c_int),
+                ("bytes", C.c_size_t)]
+
+
+def lowres_geometry(width, height, margin_x=96, margin_y=80):
+    g = LowresGeometry()
+    _check(load().x265_hip_lowres_geometry_of(C.c_int(width), C.c_int(height), C.c_int(margin_x), C.c_int(margin_y),
+                                              C.byref(g)))
+    return g
+
+
 def device_count():
     return load().x265_hip_device_count()
 
@@ -131,6 +144,17 @@ class Context:
 
     def plane_release(self, plane_id):
         _check(load().x265_hip_plane_release(self._h, C.c_int(plane_id)))
+
+    def plane_download(self, plane_id, nbytes):
+        out = np.zeros(nbytes, np.uint8)
+        _check(load().x265_hip_plane_download(self._h, C.c_int(plane_id), _p(out), C.c_size_t(nbytes)))
+        return out
+
+    def lowres_init(self, src_plane, width, height, dst_plane0, margin_x=96, margin_y=80):
+        """Lowres planes dst_plane0 .. +3 from full-resolution plane src_plane (asynchronous)."""
+        _check(load().x265_hip_lowres_init(self._h, C.c_int(src_plane), C.c_int(width), C.c_int(height),
+                                           C.c_int(margin_x), C.c_int(margin_y), C.c_int(dst_plane0)))
+        return lowres_geometry(width, height, margin_x, margin_y)
 
     def costtab_upload(self, qp, tab):
         tab = np.ascontiguousarray(tab, np.uint16)

@@ -10,7 +10,7 @@ Nothing here is timed; bench.py uploads the result once and keeps it resident in
 """
 import numpy as np
 
-from .abi import COST_REQ, ME_JOB, MAX_MVC, SATD
+from .abi import COST_REQ, LOWRES_REF, ME_JOB, MAX_MVC, SATD
 
 MARGIN_X = 96
 MARGIN_Y = 80
@@ -228,3 +228,30 @@ def satd_lane_ops(reqs):
     fx, fy = (reqs["qmv_x"] & 3) != 0, (reqs["qmv_y"] & 3) != 0
     per_px = 111.0 / 16 + np.where(fx & fy, 8 * (hgt + 7) / hgt + 8 + 3, np.where(fx | fy, 11.0, 0.0))
     return float((px * per_px).sum())
+
+
+def lookahead_jobs(lw, ll, fenc_plane, ref_plane0, motion, method=1, subme=1, merange=16, qp=12, seed=1):
+    """Job list of one lookahead pass (slicetype.cpp:1512-1584): every 8x8 CU of a `lw` x `ll` lowres picture
+    against the Lowres whose planes are ref_plane0 .. +3.  Search bounds as estimateCUCost sets them
+    (:1539-1543); predictors scatter around `motion` (half-resolution full-pel dx, dy), standing in for the
+    neighbour medians the lookahead takes from already estimated CUs.  The lookahead's own settings are HEX,
+    subme 1, merange 16 and a fixed QP of X265_LOOKAHEAD_QP = 12 (slicetype.h:73-77, common.h:151)."""
+    wcu, hcu = lw // 8, ll // 8
+    cux, cuy = np.meshgrid(np.arange(wcu), np.arange(hcu), indexing="xy")
+    cux, cuy = cux.reshape(-1), cuy.reshape(-1)
+    n = len(cux)
+    j = np.zeros(n, ME_JOB)
+    hsh = _mix(np.arange(n, dtype=np.uint64) * np.uint64(16) + np.uint64(seed * 1000003))
+    j["fenc_plane"], j["ref_plane"] = fenc_plane, ref_plane0
+    j["pu_x"], j["pu_y"], j["pu_w"], j["pu_h"] = 8 * cux, 8 * cuy, 8, 8
+    j["method"], j["subme"], j["merange"], j["qp"] = method | LOWRES_REF, subme, merange, qp
+    j["mvmin_x"], j["mvmin_y"] = -cux * 8 - 8, -cuy * 8 - 8
+    j["mvmax_x"], j["mvmax_y"] = (wcu - cux - 1) * 8 + 8, (hcu - cuy - 1) * 8 + 8
+    dx, dy = motion
+    j["qmvp_x"] = 4 * dx + ((hsh >> np.uint64(8)) % np.uint64(9)).astype(np.int64) - 4
+    j["qmvp_y"] = 4 * dy + ((hsh >> np.uint64(16)) % np.uint64(9)).astype(np.int64) - 4
+    j["num_mvc"] = 3
+    for c in range(3):
+        j["mvc"][:, 2 * c] = 4 * dx + ((hsh >> np.uint64(24 + 8 * c)) % np.uint64(13)).astype(np.int64) - 6
+        j["mvc"][:, 2 * c + 1] = 4 * dy + ((hsh >> np.uint64(28 + 8 * c)) % np.uint64(13)).astype(np.int64) - 6
+    return j
