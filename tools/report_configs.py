@@ -68,6 +68,48 @@ def run(w, h, tag):
         res["me_stage_" + name] = {"calls": len(mj), "references": 3, "ms_per_picture": ms, "pictures_per_s": 1e3 / ms,
                                    "calls_per_s": len(mj) / ms * 1e3}
 
+    # lookahead: lowres planes of four pictures, then every 8x8 CU of one picture against
+    # two Lowres references (HEX, subme 1, merange 16, QP 12: the lookahead's settings, slicetype.h:73-77)
+    ctx.set_qp(12)
+    geo = lib.lowres_geometry(w, h)
+
+    def all_lowres():
+        for i in range(4):
+            ctx.lowres_init(i, w, h, 8 + 4 * i)
+    ms = timed(ext, ctx, all_lowres, 20) / 4
+    alg = geo.width * geo.lines * 8  # 4 source bytes read and 4 plane bytes written per lowres sample
+    wrote = (geo.width + 192) * (geo.lines + 160) * 4 + geo.width * geo.lines * 4  # with the margins it also writes
+    res["lowres_init"] = {"lowres_picture": f"{geo.width}x{geo.lines}", "ms_per_picture": ms,
+                          "algorithmic_bytes": alg, "algorithmic_gb_per_s": alg / ms / 1e6, "frac_of_hbm_peak": alg / ms / 1e6 / 8000.0,
+                          "bytes_incl_margins": wrote, "gb_per_s_incl_margins": wrote / ms / 1e6}
+    lmot = [(mx // 2, my // 2) for (mx, my) in (seq.global_motion(3, 2), seq.global_motion(3, 1))]
+    lj = np.concatenate([synth.lookahead_jobs(geo.width, geo.lines, 8 + 4 * 3, 8 + 4 * r, m)
+                         for r, m in zip((2, 1), lmot)])
+    d = torch.from_numpy(lj.view(np.uint8).copy()).to(dev)
+    o = torch.empty(len(lj) * 8, dtype=torch.uint8, device=dev)
+    ms = timed(ext, ctx, lambda: ctx.me_batch_device(d.data_ptr(), len(lj), o.data_ptr()), 10)
+    res["lookahead_me"] = {"calls": len(lj), "references": 2, "ms_per_picture": ms, "pictures_per_s": 1e3 / ms,
+                           "calls_per_s": len(lj) / ms * 1e3}
+    if os.environ.get("X265_REPORT_CPU", "1") == "1":
+        import time
+        from oracle import pyoracle  # checker library, timed here as the CPU baseline only
+        chk = pyoracle.load_ref() if pyoracle.have_ref() else pyoracle.load_oracle()
+        t0 = time.perf_counter()
+        low = []
+        for p in planes:
+            low += chk.lowres_planes(p.buf, p.origin, p.stride, p.w, p.h)[0]
+        t_init = (time.perf_counter() - t0) / 4 * 1e3
+        cj = lj.copy()
+        cj["fenc_plane"] = 12
+        cj["ref_plane"] = np.where(lj["ref_plane"] == 8 + 4 * 2, 8, 4)
+        tabs = {12: lib.costtab_build(12)}
+        chk.me_batch(low, tabs, cj[:1000], nthreads=16)
+        t0 = time.perf_counter()
+        chk.me_batch(low, tabs, cj, nthreads=16)
+        t_me = (time.perf_counter() - t0) * 1e3
+        res["lookahead_cpu"] = {"kind": chk.kind, "lowres_init_ms_per_picture_1_thread": t_init, "me_ms_per_picture_16_threads": t_me,
+                                "me_pictures_per_s": 1e3 / t_me}
+
     # host-array entry points (job upload, kernel, result download, all synchronous): the PCIe-inclusive rate
     import time
     mj = synth.me_jobs(w, h, 3, refs, mot, method=abi.HEX, subme=2, merange=57)
