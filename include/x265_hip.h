@@ -149,6 +149,18 @@ int x265_hip_lowres_geometry_of(int width, int height, int margin_x, int margin_
 int x265_hip_lowres_init(x265_hip_ctx *ctx, int src_plane, int width, int height, int margin_x, int margin_y,
                          int dst_plane0);
 
+/* ---- reference-plane production ---------------------------------------------
+ * extendPicBorder (source/common/pixel.cpp:893-911) in place on a plane whose picture area (`width` x
+ * `height` at the plane's origin) has been written, e.g. a reconstructed picture bound with
+ * x265_hip_plane_bind: columns -marginX .. width + marginX - 1 of rows -marginY .. height + marginY - 1. */
+int x265_hip_plane_extend_border(x265_hip_ctx *ctx, int plane_id, int width, int height, int margin_x, int margin_y);
+/* MotionReference::init + applyWeight over a whole picture (source/encoder/reference.cpp:57-121): plane
+ * `dst_plane` (same geometry as `src_plane`, owned by the context) receives weight_pp (pixel.cpp:510-529) of
+ * the picture area with weight `w0`, `offset` and `log2_denom` as in wpScalingParam (the interpolation-depth
+ * correction of reference.cpp:95-98 is applied inside), then the border extension. */
+int x265_hip_plane_weight(x265_hip_ctx *ctx, int src_plane, int dst_plane, int width, int height, int margin_x,
+                          int margin_y, int w0, int offset, int log2_denom);
+
 /* One lambda-scaled MVD cost row as BitCost::setQP builds it (source/encoder/bitcost.cpp:31-56):
  * tab[32768 + d] = cost of difference d, d in [-32768, 32767].  The table is an input: it is made
  * with host floating point in the reference and is never recomputed on the GPU. */

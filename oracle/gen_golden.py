@@ -134,8 +134,13 @@ def gen_lowres(R):
     jobs = random_lowres_jobs(rng, 400, size[0], size[1], pyoracle.ME_JOB)
     tabs = {q: R.bitcost_table(q) for q in (12, 20, 33)}
     res = R.me_batch(low, tabs, jobs)
+    # weighted reference planes (MotionReference::applyWeight) of picture 0: (w0, offset, log2 denominator)
+    wcases = np.array([(64, 0, 6), (70, -3, 6), (37, 10, 5), (1, 0, 0), (200, -100, 7)], np.int32)
+    p = planes[0]
+    wcrc = np.array([crc(R.weighted_plane(p.buf, p.origin, p.stride, p.w, p.h, int(a), int(b), int(c))) for a, b, c in wcases],
+                    np.uint32)
     np.savez_compressed(os.path.join(OUT, "lowres.npz"), jobs=jobs, results=res, size=np.array(size, np.int32),
-                        plane_crc=np.array([crc(b) for (b, _, _) in low], np.uint32))
+                        plane_crc=np.array([crc(b) for (b, _, _) in low], np.uint32), weight_cases=wcases, weight_crc=wcrc)
 
 
 def main():

@@ -167,6 +167,20 @@ class Checker:
                                          C.c_int(margin_x), C.c_int(margin_y))
         return [(b, origin, stride) for b in bufs], (lw, ll)
 
+    def weighted_plane(self, buf, origin, stride, width, height, w0, offset, log2denom, margin_x=96, margin_y=80):
+        """MotionReference::init + applyWeight over the whole picture (encoder/reference.cpp:57-121): weight_pp
+        on the padded width with the interpolation-depth correction, then the border extension.  Returns
+        the weighted padded buffer (same geometry as the source)."""
+        out = np.zeros_like(buf)
+        rnd = (1 << (log2denom - 1)) if log2denom else 0
+        padw = (width + 15) & ~15
+        self._f("weight_pp")(_ptr(buf, origin), _ptr(out, origin), C.c_ssize_t(stride), C.c_ssize_t(stride),
+                             C.c_int(padw), C.c_int(height), C.c_int(w0), C.c_int(rnd << 6), C.c_int(log2denom + 6),
+                             C.c_int(offset))
+        self._f("extend_pic_border")(_ptr(out, origin), C.c_ssize_t(stride), C.c_int(width), C.c_int(height),
+                                     C.c_int(margin_x), C.c_int(margin_y))
+        return out
+
     def ctu_fullsearch(self, fenc, ref, costtab, ctu_x, ctu_y, mvmin, mvmax, qmvp):
         out = np.zeros(85, ME_RESULT)
         pl = self._planes([fenc, ref])

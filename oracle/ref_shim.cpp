@@ -212,6 +212,13 @@ void x265r_extend_pic_border(uint8_t *pic, intptr_t stride, int width, int heigh
     extendPicBorder(pic, (int)stride, width, height, marginX, marginY); /* uses primitives.extendRowBorder */
 }
 
+void x265r_weight_pp(const uint8_t *src, uint8_t *dst, intptr_t sstride, intptr_t dstride, int width, int height,
+                     int w0, int round, int shift, int offset)
+{
+    init();
+    g_c.weight_pp((pixel *)src, dst, sstride, dstride, width, height, w0, round, shift, offset);
+}
+
 int x265r_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, int y, int w, int h, int qmvx,
                       int qmvy, int metric)
 {

@@ -1068,6 +1068,23 @@ void x265o_extend_pic_border(uint8_t *pic, intptr_t stride, int width, int heigh
         memcpy(bot + (y + 1) * stride, bot, stride);
 }
 
+/* ref: weight_pp_c, common/pixel.cpp:510-529 (8-bit: IF_INTERNAL_PREC - X265_DEPTH = 6) */
+void x265o_weight_pp(const uint8_t *src, uint8_t *dst, intptr_t sstride, intptr_t dstride, int width, int height,
+                     int w0, int round, int shift, int offset)
+{
+    for (int y = 0; y < height; y++)
+    {
+        for (int x = 0; x < width; x++)
+        {
+            int16_t val = (int16_t)(src[x] << 6);
+            int v = ((w0 * val + round) >> shift) + offset;
+            dst[x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+        src += sstride;
+        dst += dstride;
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* batched drivers (pthread fan-out over contiguous slices)                  */
 

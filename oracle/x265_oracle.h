@@ -106,6 +106,9 @@ void x265o_me_batch(const x265o_plane *planes, const uint16_t *const *costtabs, 
 void x265o_frame_init_lowres(const uint8_t *src0, uint8_t *dst0, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc,
                              intptr_t src_stride, intptr_t dst_stride, int width, int height);
 void x265o_extend_pic_border(uint8_t *pic, intptr_t stride, int width, int height, int marginX, int marginY);
+/* weight_pp (pixel.cpp:510-529): the weighted copy of a reference plane, MotionReference::applyWeight's kernel */
+void x265o_weight_pp(const uint8_t *src, uint8_t *dst, intptr_t sstride, intptr_t dstride, int width, int height,
+                     int w0, int round, int shift, int offset);
 
 /* Hierarchical full search used by config 2: for one 64x64 CTU at (ctu_x,ctu_y), every square PU of
  * sizes 64/32/16/8 (85 PUs, z-order within each level, levels 64,32,16,8) is searched over

@@ -118,6 +118,13 @@ def test_lookahead_planes_and_search_reproduce_reference_fixtures():
     want = g["results"].view(got.dtype)
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (g["jobs"][bad[0]], got[bad[0]], want[bad[0]])
+    # weighted reference planes: the fixture's CRCs cover whole buffers; 416 is not a multiple of 64, so the 32
+    # columns between the right margin and the stride are never written by either side (zero in both)
+    p = golden_planes()[0]
+    for (w0, off, den), want_crc in zip(g["weight_cases"], g["weight_crc"]):
+        ctx.plane_weight(20, 30, p.w, p.h, int(w0), int(off), int(den))
+        got_crc = zlib.crc32(ctx.plane_download(30, p.buf.size).tobytes()) & 0xffffffff
+        assert got_crc == int(want_crc), (w0, off, den)
     ctx.close()
 
 

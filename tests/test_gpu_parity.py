@@ -203,3 +203,36 @@ def test_lowres_planes_and_search(oracle, small_seq, costtabs):
     with pytest.raises(lib.X265HipError):
         ctx.me_batch(j)
     ctx.close()
+
+
+def test_plane_weight_and_border(oracle, small_seq):
+    """x265_hip_plane_weight against weight_pp + extendPicBorder, and x265_hip_plane_extend_border in place on a
+    plane whose margins were wiped"""
+    from x265_amd import lib
+    ctx = lib.Context(0)
+    p = small_seq[0]
+    ctx.plane_upload(0, p.buf, p.stride, p.origin)
+    rows = np.arange(p.rows)[:, None]
+    cols = np.arange(p.stride)[None, :]
+    # what the reference writes in every row: columns -marginX .. width + marginX - 1 (bytes beyond, up to the
+    # stride, are copies of unwritten memory there)
+    written = ((cols < p.w + 192) & (rows < p.h + 160)).reshape(-1)
+    for (w0, off, den) in ((64, 0, 6), (70, -3, 6), (37, 10, 5), (1, 0, 0), (200, -100, 7)):
+        ctx.plane_weight(0, 1, p.w, p.h, w0, off, den)
+        got = ctx.plane_download(1, p.buf.size)
+        want = oracle.weighted_plane(p.buf, p.origin, p.stride, p.w, p.h, w0, off, den)
+        bad = np.nonzero((got != want) & written)[0]
+        assert len(bad) == 0, f"weight {(w0, off, den)}: byte {bad[0]} (row {bad[0] // p.stride}, col {bad[0] % p.stride}) got {got[bad[0]]} want {want[bad[0]]}"
+    wiped = p.buf.reshape(p.rows, p.stride).copy()
+    inside = (rows >= 80) & (rows < 80 + p.h) & (cols >= 96) & (cols < 96 + p.w)
+    wiped[~inside] = 0x55
+    ctx.plane_upload(2, wiped.reshape(-1), p.stride, p.origin)
+    ctx.plane_extend_border(2, p.w, p.h)
+    got = ctx.plane_download(2, p.buf.size)
+    bad = np.nonzero((got != p.buf) & written)[0]
+    assert len(bad) == 0, f"border: byte {bad[0]} (row {bad[0] // p.stride}, col {bad[0] % p.stride})"
+    with pytest.raises(lib.X265HipError):
+        ctx.plane_extend_border(2, p.w + 2, p.h)  # width must be a multiple of 4
+    with pytest.raises(lib.X265HipError):
+        ctx.plane_extend_border(2, p.w, p.h, margin_y=200)  # does not fit the buffer
+    ctx.close()

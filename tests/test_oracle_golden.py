@@ -141,3 +141,10 @@ def test_lowres_planes_and_search_match_reference_fixtures(oracle):
     want = g["results"].view(got.dtype)
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (g["jobs"][bad[0]], got[bad[0]], want[bad[0]])
+
+
+def test_weighted_planes_match_reference_fixtures(oracle):
+    g = np.load(os.path.join(GOLD, "lowres.npz"))
+    p = golden_planes()[0]
+    got = [crc(oracle.weighted_plane(p.buf, p.origin, p.stride, p.w, p.h, int(a), int(b), int(c))) for a, b, c in g["weight_cases"]]
+    assert got == [int(v) for v in g["weight_crc"]]

@@ -80,3 +80,12 @@ def test_lowres_planes_and_search(oracle, ref, small_seq):
     a, b = oracle.me_batch(low_o, tabs, jobs), ref.me_batch(low_r, tabs, jobs)
     bad = np.nonzero(a != b)[0]
     assert len(bad) == 0, (jobs[bad[0]], a[bad[0]], b[bad[0]])
+
+
+def test_weighted_plane_and_border(oracle, ref, small_seq):
+    """weight_pp with applyWeight's corrected arguments + extendPicBorder, several weights / offsets / denominators"""
+    p = small_seq[0]
+    for (w0, off, den) in ((64, 0, 6), (70, -3, 6), (37, 10, 5), (1, 0, 0), (200, -100, 7), (128, 40, 7)):
+        a = oracle.weighted_plane(p.buf, p.origin, p.stride, p.w, p.h, w0, off, den)
+        b = ref.weighted_plane(p.buf, p.origin, p.stride, p.w, p.h, w0, off, den)
+        assert np.array_equal(a, b), (w0, off, den)

@@ -82,6 +82,12 @@ def run(w, h, tag):
     res["lowres_init"] = {"lowres_picture": f"{geo.width}x{geo.lines}", "ms_per_picture": ms,
                           "algorithmic_bytes": alg, "algorithmic_gb_per_s": alg / ms / 1e6, "frac_of_hbm_peak": alg / ms / 1e6 / 8000.0,
                           "bytes_incl_margins": wrote, "gb_per_s_incl_margins": wrote / ms / 1e6}
+    # reference-plane production: weighted copy + border extension of one picture
+    ms = timed(ext, ctx, lambda: ctx.plane_weight(0, 40, w, h, 70, -3, 6), 20)
+    alg = w * h + (w + 192) * (h + 160)  # picture read once, padded plane written once
+    res["plane_weight"] = {"ms_per_picture": ms, "algorithmic_bytes": alg, "algorithmic_gb_per_s": alg / ms / 1e6,
+                           "frac_of_hbm_peak": alg / ms / 1e6 / 8000.0}
+    ctx.plane_release(40)
     lmot = [(mx // 2, my // 2) for (mx, my) in (seq.global_motion(3, 2), seq.global_motion(3, 1))]
     lj = np.concatenate([synth.lookahead_jobs(geo.width, geo.lines, 8 + 4 * 3, 8 + 4 * r, m)
                          for r, m in zip((2, 1), lmot)])

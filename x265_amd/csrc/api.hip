@@ -349,6 +349,83 @@ int x265_hip_lowres_init(x265_hip_ctx *c, int src_plane, int width, int height, 
     return X265_HIP_OK;
 }
 
+static int border_args(x265_hip_ctx *c, const char *who, int src, int dst, int width, int height, int mx, int my,
+                       PlaneBorderArgs &a)
+{
+    const PlaneDesc &p = c->host_tabs.planes[src];
+    if (!p.origin)
+        return fail(X265_HIP_EINVAL, "%s: plane %d is not set", who, src);
+    if (width <= 0 || height <= 0 || (width & 3) || mx < 0 || my < 0 || (mx & 3) || (p.stride & 3) ||
+        ((c->plane_origin[src] - mx) & 3))
+        return fail(X265_HIP_EINVAL, "%s: width, marginX, stride and origin must be multiples of 4", who);
+    // the padded picture must lie inside the buffer
+    const long first = (long)c->plane_origin[src] - (long)my * p.stride - mx;
+    const long last = (long)c->plane_origin[src] + (long)(height - 1 + my) * p.stride + width + mx;
+    if (first < 0 || (size_t)last > c->plane_bytes[src] || width + 2 * mx > p.stride)
+        return fail(X265_HIP_EINVAL, "%s: %dx%d with margins %d/%d does not fit plane %d", who, width, height, mx, my, src);
+    a.src = p.origin;
+    a.dst = (uint8_t *)c->host_tabs.planes[dst].origin;
+    a.stride = p.stride;
+    a.width = width;
+    a.height = height;
+    a.margin_x = mx;
+    a.margin_y = my;
+    a.weighted = 0;
+    a.w0 = a.round = a.shift = a.offset = 0;
+    return 0;
+}
+
+int x265_hip_plane_extend_border(x265_hip_ctx *c, int id, int width, int height, int mx, int my)
+{
+    if (!c || id < 0 || id >= X265_HIP_MAX_PLANES)
+        return fail(X265_HIP_EINVAL, "plane_extend_border: bad plane id %d", id);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    PlaneBorderArgs a;
+    int r = border_args(c, "plane_extend_border", id, id, width, height, mx, my, a);
+    if (r)
+        return r;
+    launch_plane_border(a, c->stream);
+    HIP_TRY(hipGetLastError());
+    return X265_HIP_OK;
+}
+
+int x265_hip_plane_weight(x265_hip_ctx *c, int src, int dst, int width, int height, int mx, int my, int w0, int offset,
+                          int log2_denom)
+{
+    if (!c || src < 0 || src >= X265_HIP_MAX_PLANES || dst < 0 || dst >= X265_HIP_MAX_PLANES || src == dst ||
+        log2_denom < 0 || log2_denom > 7)
+        return fail(X265_HIP_EINVAL, "plane_weight: bad argument (src %d, dst %d, log2 denominator %d)", src, dst, log2_denom);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->host_tabs.planes[src].origin)
+        return fail(X265_HIP_EINVAL, "plane_weight: plane %d is not set", src);
+    const size_t bytes = c->plane_bytes[src];
+    if (!c->owned_plane[dst] || c->plane_bytes[dst] != bytes)
+    {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->owned_plane[dst])
+            (void)hipFree(c->owned_plane[dst]);
+        c->owned_plane[dst] = nullptr;
+        HIP_TRY(hipMalloc(&c->owned_plane[dst], bytes + 64));
+        HIP_TRY(hipMemsetAsync(c->owned_plane[dst], 0, bytes + 64, c->stream));
+    }
+    int r = plane_set(c, dst, c->owned_plane[dst], bytes, c->host_tabs.planes[src].stride, c->plane_origin[src]);
+    PlaneBorderArgs a;
+    if (r || (r = border_args(c, "plane_weight", src, dst, width, height, mx, my, a)))
+        return r;
+    // MotionReference::init / applyWeight, reference.cpp:57-61, 95-98
+    const int round = log2_denom ? 1 << (log2_denom - 1) : 0;
+    a.weighted = 1;
+    a.w0 = w0;
+    a.round = round << 6;
+    a.shift = log2_denom + 6;
+    a.offset = offset;
+    launch_plane_border(a, c->stream);
+    HIP_TRY(hipGetLastError());
+    return X265_HIP_OK;
+}
+
 int x265_hip_costtab_upload(x265_hip_ctx *c, int qp, const uint16_t *tab)
 {
     if (!c || !tab || qp < 0 || qp >= X265_HIP_MAX_QP)

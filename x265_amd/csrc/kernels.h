@@ -37,7 +37,17 @@ struct LowresArgs
     int margin_x, margin_y;
 };
 
+struct PlaneBorderArgs
+{
+    const uint8_t *src; // picture sample (0,0) of the source plane
+    uint8_t *dst;       // picture sample (0,0) of the destination plane (may equal src)
+    int stride;         // both planes
+    int width, height, margin_x, margin_y;
+    int weighted, w0, round, shift, offset; // weight_pp arguments as applyWeight passes them
+};
+
 void launch_lowres_init(const LowresArgs &a, hipStream_t st);
+void launch_plane_border(const PlaneBorderArgs &a, hipStream_t st);
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st);
 void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, hipStream_t st);
 void launch_prim_cmp(const PrimCmpArgs &a, int32_t *out, hipStream_t st);

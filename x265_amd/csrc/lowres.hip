@@ -1,4 +1,4 @@
-// lowres.hip -- lookahead planes on the device: frame_init_lowres_core (reference common/pixel.cpp:595-618)
+// lowres.hip -- plane production on the device.  Lookahead planes: frame_init_lowres_core (reference common/pixel.cpp:595-618)
 // fused with extendPicBorder (pixel.cpp:893-911; row margins from common/ipfilter.cpp:56-74).
 //
 // One thread produces four horizontally adjacent samples of all four planes at one padded position.  A
@@ -69,6 +69,45 @@ __global__ __launch_bounds__(256) void lowres_init_kernel(LowresArgs a)
 #pragma unroll
     for (int k = 0; k < 4; k++)
         *(uint32_t *)(a.dst[k] + off) = o[k];
+}
+
+// extendPicBorder (pixel.cpp:893-911), optionally behind weight_pp (pixel.cpp:510-529): every padded
+// position takes the (weighted) sample of the nearest picture position.  One thread per four columns.
+// In place (src == dst, no weighting) only positions outside the picture are written.
+__global__ __launch_bounds__(256) void plane_border_kernel(PlaneBorderArgs a)
+{
+    const int px4 = blockIdx.x * 256 + threadIdx.x;
+    const int py = blockIdx.y;
+    const int padw = a.width + 2 * a.margin_x;
+    if (4 * px4 >= padw)
+        return;
+    const int y = min(max(py - a.margin_y, 0), a.height - 1);
+    const int x0 = 4 * px4 - a.margin_x;
+    const bool inside = x0 >= 0 && x0 + 3 < a.width;
+    if (inside && !a.weighted && py == y + a.margin_y)
+        return; // picture samples stay as they are
+    const gptr_t s = as_global(a.src) + (long)y * a.stride;
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const int x = min(max(x0 + i, 0), a.width - 1);
+        int v = s[x];
+        if (a.weighted)
+        {
+            v = ((a.w0 * (v << 6) + a.round) >> a.shift) + a.offset; // val = src << (14 - 8), weight_pp_c
+            v = min(max(v, 0), 255);
+        }
+        o |= (uint32_t)v << (8 * i);
+    }
+    // picture origin - margins; 4-byte aligned when stride, origin and margin_x are (checked by the host)
+    *(uint32_t *)(a.dst + ((long)(py - a.margin_y) * a.stride + x0)) = o;
+}
+
+void launch_plane_border(const PlaneBorderArgs &a, hipStream_t st)
+{
+    const int padw = a.width + 2 * a.margin_x, padh = a.height + 2 * a.margin_y;
+    hipLaunchKernelGGL(plane_border_kernel, dim3(((padw + 3) / 4 + 255) / 256, padh), dim3(256), 0, st, a);
 }
 
 void launch_lowres_init(const LowresArgs &a, hipStream_t st)

@@ -32,6 +32,7 @@ EXPORTS = [
     "x265_hip_me_batch", "x265_hip_me_batch_device", "x265_hip_cost_batch_device", "x265_hip_fullsearch",
     "x265_hip_fullsearch_device", "x265_hip_costtab_build", "x265_hip_costtab_set_qp",
     "x265_hip_plane_download", "x265_hip_lowres_geometry_of", "x265_hip_lowres_init",
+    "x265_hip_plane_extend_border", "x265_hip_plane_weight",
 ]
 
 
@@ -155,6 +156,15 @@ class Context:
         _check(load().x265_hip_lowres_init(self._h, C.c_int(src_plane), C.c_int(width), C.c_int(height),
                                            C.c_int(margin_x), C.c_int(margin_y), C.c_int(dst_plane0)))
         return lowres_geometry(width, height, margin_x, margin_y)
+
+    def plane_extend_border(self, plane_id, width, height, margin_x=96, margin_y=80):
+        _check(load().x265_hip_plane_extend_border(self._h, C.c_int(plane_id), C.c_int(width), C.c_int(height),
+                                                   C.c_int(margin_x), C.c_int(margin_y)))
+
+    def plane_weight(self, src_plane, dst_plane, width, height, w0, offset, log2_denom, margin_x=96, margin_y=80):
+        _check(load().x265_hip_plane_weight(self._h, C.c_int(src_plane), C.c_int(dst_plane), C.c_int(width),
+                                            C.c_int(height), C.c_int(margin_x), C.c_int(margin_y), C.c_int(w0),
+                                            C.c_int(offset), C.c_int(log2_denom)))
 
     def costtab_upload(self, qp, tab):
         tab = np.ascontiguousarray(tab, np.uint16)
