@@ -251,7 +251,7 @@ def main():
         px_ops = positions / args.steps * 4096  # 64x64 pixel-ops per position per CTU with full 8x8 reuse
         alg_bytes = n_ctu * (4096 + (64 + 2 * RANGE) ** 2 + 85 * 8 + 28)
         line = {
-            "metric": "ME candidates/sec (integer-pel SAD full search, bit-exact)",
+            "metric": "SATD ME candidates/sec + ME-stage frames/sec, bit-exact: value = integer-pel search candidates/s (SAD, configs[1]); SATD candidates/s and ME-stage frames/s in satd_candidates / me_stage",
             "value": total_units / dt_fs, "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_fs / args.steps * 1e3,

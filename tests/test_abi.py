@@ -78,3 +78,24 @@ def test_synth_search_range_matches_reference_rule():
     assert (lox, loy, hix, hiy) == (-57, -57, 57, 57)
     lox, loy, hix, hiy = (int(v) for v in synth.search_range(np.int64(-200), np.int64(0), 64, 0, 0, 1920, 1080))
     assert lox == -71 and hix == 14
+
+
+def test_hot_kernels_use_no_scratch(tmp_path):
+    """the ME, cost and full-search kernels must keep their state in registers: a struct that slips into
+    scratch memory costs several KB of HBM writes per motionEstimate call (seen once, caught by WRITE_SIZE)"""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "x265_amd", "csrc")
+    for name in ("me_kernel.hip", "fullsearch.hip"):
+        out = tmp_path / (name + ".s")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out),
+                               os.path.join(src, name)], stderr=subprocess.DEVNULL)
+        text = out.read_text()
+        sizes = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", text)]
+        spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s*(\d+)", text)]
+        assert sizes and all(v == 0 for v in sizes), (name, sizes)
+        assert all(v == 0 for v in spills), (name, spills)

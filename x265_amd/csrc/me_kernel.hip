@@ -68,7 +68,7 @@ struct Wave
     // reference is a Lowres (ReferencePlanes::isLowres): ref is lowresPlane[0], these are [1..3], all at the
     // PU origin and of one stride
     bool lowres;
-    const uint8_t *lref[3];
+    const uint8_t *lref1, *lref2, *lref3;
 };
 
 #define PAT(dx, dy) (int)(((uint32_t)(uint16_t)(dy) << 16) | (uint16_t)(dx))
@@ -93,7 +93,7 @@ __device__ __forceinline__ void wave_init(Wave &wv, WaveLds *s, int w, int h)
     wv.mvpx = wv.mvpy = 0;
     wv.vc = wv.vx = wv.vy = wv.va = 0;
     wv.lowres = false;
-    wv.lref[0] = wv.lref[1] = wv.lref[2] = nullptr;
+    wv.lref1 = wv.lref2 = wv.lref3 = nullptr;
     wv.patv = wv.lane < PAT_N ? k_pat[wv.lane] : 0;
     if (wv.lane < PAT_N)
         s->pat[wv.lane] = wv.patv; // made visible by load_fenc's wave_sync
@@ -122,32 +122,32 @@ __device__ __forceinline__ void q_push(Wave &wv, int qx, int qy, int mvmode, int
 // ReferencePlanes::lowresQPelCost's pixels for one 4x4 tile (common/lowres.h:73-93): the half-pel plane the
 // quarter-pel vector selects, or the rounded average of two of them (pixelavg_pp, common/pixel.cpp:546-560)
 // when a component is odd.  `toff` is the tile's byte offset inside the block.
-__device__ __forceinline__ void lowres_tile(const Wave &wv, int qx, int qy, int toff, uint32_t P[4][2])
+__device__ __forceinline__ void lowres_tile(const uint8_t *p0, const uint8_t *p1, const uint8_t *p2, const uint8_t *p3,
+                                            int stride, int qx, int qy, int toff, uint32_t P[4][2])
 {
+    // the planes arrive by value: selecting between members of a struct behind a reference makes the compiler
+    // index the struct in memory (scratch)
     auto plane = [&](int hpel) {
-        const uint8_t *p = wv.ref;
-        p = hpel == 1 ? wv.lref[0] : p;
-        p = hpel == 2 ? wv.lref[1] : p;
-        p = hpel == 3 ? wv.lref[2] : p;
-        return as_global(p);
+        const uint8_t *lo = (hpel & 1) ? p1 : p0, *hi = (hpel & 1) ? p3 : p2;
+        return as_global((hpel & 2) ? hi : lo);
     };
-    const gptr_t a = plane((qy & 2) | ((qx & 2) >> 1)) + (qx >> 2) + (qy >> 2) * wv.stride + toff;
+    const gptr_t a = plane((qy & 2) | ((qx & 2) >> 1)) + (qx >> 2) + (qy >> 2) * stride + toff;
     uint32_t d[4];
     if ((qx | qy) & 1)
     {
         const int bx = s16(qx + (qx & 1) * 2), by = s16(qy + (qy & 1) * 2);
-        const gptr_t b = plane((by & 2) | ((bx & 2) >> 1)) + (bx >> 2) + (by >> 2) * wv.stride + toff;
+        const gptr_t b = plane((by & 2) | ((bx & 2) >> 1)) + (bx >> 2) + (by >> 2) * stride + toff;
 #pragma unroll
         for (int y = 0; y < 4; y++)
         {
-            const uint32_t u = ld4g(a + y * wv.stride), v = ld4g(b + y * wv.stride);
+            const uint32_t u = ld4g(a + y * stride), v = ld4g(b + y * stride);
             d[y] = (u | v) - (((u ^ v) >> 1) & 0x7f7f7f7fu); // per byte (u + v + 1) >> 1
         }
     }
     else
 #pragma unroll
         for (int y = 0; y < 4; y++)
-            d[y] = ld4g(a + y * wv.stride);
+            d[y] = ld4g(a + y * stride);
 #pragma unroll
     for (int y = 0; y < 4; y++)
     {
@@ -202,7 +202,7 @@ __device__ __forceinline__ void q_eval(Wave &wv, int metric)
         {
             uint32_t pix[4][2];
             if (wv.lowres)
-                lowres_tile(wv, qx, qy, 4 * ty * wv.stride + 4 * tx, pix);
+                lowres_tile(wv.ref, wv.lref1, wv.lref2, wv.lref3, wv.stride, qx, qy, 4 * ty * wv.stride + 4 * tx, pix);
             else
                 ref_tile(r, wv.stride, qx & 3, qy & 3, pix);
             v = tile_metric(f, 64, pix, metric);
@@ -1165,8 +1165,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void me
     if (j.method & X265_HIP_LOWRES_REF)
     {
         wv.lowres = true;
-        for (int k = 0; k < 3; k++)
-            wv.lref[k] = tabs->planes[j.ref_plane + 1 + k].origin + (long)j.pu_y * rp.stride + j.pu_x;
+        const long off = (long)j.pu_y * rp.stride + j.pu_x;
+        wv.lref1 = tabs->planes[j.ref_plane + 1].origin + off;
+        wv.lref2 = tabs->planes[j.ref_plane + 2].origin + off;
+        wv.lref3 = tabs->planes[j.ref_plane + 3].origin + off;
     }
     load_fenc(wv, fp.origin + (long)j.pu_y * fp.stride + j.pu_x, fp.stride);
     motion_estimate(wv, j, &out[id]);
