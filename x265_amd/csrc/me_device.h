@@ -270,7 +270,10 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
         const uint4 ve = *(const uint4 *)&k_vtaps_s16[yf][0], vo = *(const uint4 *)&k_vtaps_s16[yf][4];
         const uint32_t vo4 = k_vtaps_s16[yf][8];
         gptr_t p = r_ - 3 * stride - 3;
+        const int seed = 2048 + (8192 << 6);
         uint32_t q[NP][4];
+        // pairs are produced in order and a pair of output rows is emitted as soon as its five pairs exist,
+        // so only a window of five pairs is live at a time
 #pragma unroll
         for (int j = 0; j < NP; j++)
         {
@@ -288,23 +291,21 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
 #pragma unroll
             for (int x = 0; x < 4; x++)
                 q[j][x] = j < NP - 1 ? __builtin_amdgcn_perm((uint32_t)b[x], (uint32_t)a[x], 0x05040100) : ((uint32_t)a[x] & 0xffffu);
-        }
-        const int seed = 2048 + (8192 << 6);
-#pragma unroll
-        for (int y = 0; y < R; y += 2)
-        {
-            const int j = y >> 1; // output row y starts on source row y = pair j; row y + 1 in the middle of pair j
-            int e[4], o[4];
-#pragma unroll
-            for (int x = 0; x < 4; x++)
+            if (j >= 4)
             {
-                e[x] = sdot2(q[j + 3][x], ve.w, sdot2(q[j + 2][x], ve.z, sdot2(q[j + 1][x], ve.y, sdot2_first<seed>(q[j][x], ve.x))));
-                o[x] = sdot2(q[j + 4][x], vo4, sdot2(q[j + 3][x], vo.w, sdot2(q[j + 2][x], vo.z, sdot2(q[j + 1][x], vo.y, sdot2_first<seed>(q[j][x], vo.x)))));
+                const int k = j - 4, y = 2 * k; // output row y starts on pair k, row y + 1 in the middle of it
+                int e[4], o[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    e[x] = sdot2(q[k + 3][x], ve.w, sdot2(q[k + 2][x], ve.z, sdot2(q[k + 1][x], ve.y, sdot2_first<seed>(q[k][x], ve.x))));
+                    o[x] = sdot2(q[k + 4][x], vo4, sdot2(q[k + 3][x], vo.w, sdot2(q[k + 2][x], vo.z, sdot2(q[k + 1][x], vo.y, sdot2_first<seed>(q[k][x], vo.x)))));
+                }
+                P[y][0] = pack2(clip_pixel(e[0] >> 12), clip_pixel(e[1] >> 12));
+                P[y][1] = pack2(clip_pixel(e[2] >> 12), clip_pixel(e[3] >> 12));
+                P[y + 1][0] = pack2(clip_pixel(o[0] >> 12), clip_pixel(o[1] >> 12));
+                P[y + 1][1] = pack2(clip_pixel(o[2] >> 12), clip_pixel(o[3] >> 12));
             }
-            P[y][0] = pack2(clip_pixel(e[0] >> 12), clip_pixel(e[1] >> 12));
-            P[y][1] = pack2(clip_pixel(e[2] >> 12), clip_pixel(e[3] >> 12));
-            P[y + 1][0] = pack2(clip_pixel(o[0] >> 12), clip_pixel(o[1] >> 12));
-            P[y + 1][1] = pack2(clip_pixel(o[2] >> 12), clip_pixel(o[3] >> 12));
         }
     }
 }

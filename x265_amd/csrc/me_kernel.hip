@@ -1197,7 +1197,7 @@ struct CostLds
     int fstride[COST_BATCH], rstride[COST_BATCH], info[COST_BATCH];
 };
 
-__global__ __launch_bounds__(256) void cost_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void cost_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
                                                    int32_t *out)
 {
     __shared__ CostLds lds[4];
