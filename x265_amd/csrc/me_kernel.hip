@@ -1146,7 +1146,7 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
     }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
                                                 x265_hip_me_result *out)
 {
     __shared__ WaveLds lds;
