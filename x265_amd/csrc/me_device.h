@@ -175,8 +175,12 @@ __device__ __forceinline__ uint32_t pack2(int lo, int hi) { return (uint32_t)lo 
 // Fetch (or interpolate) a strip of NT vertically stacked 4x4 reference tiles whose top-left full-pel
 // sample is `ref`, for the quarter-pel fraction (xf, yf).  All work stays in registers.  A strip of two tiles
 // filters 15 source rows instead of 2 x 11 (vertical taps overlap), which is what NT = 2 is for.
+// `diag` sends a half-fractional position through the diagonal path as well: with the tap row {0,0,0,64,...}
+// for the integer direction that path gives (64 S + 2048) >> 12 = (S + 32) >> 6, the hpp / vpp result, bit for
+// bit.  A wave whose lanes hold positions of different kinds then runs one path instead of three.
 template <int NT>
-__device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf, int yf, uint32_t P[4 * NT][2])
+__device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf, int yf, uint32_t P[4 * NT][2],
+                                          bool diag = false)
 {
     constexpr int R = 4 * NT;
     const uint32_t bias = 0x80808080u;
@@ -191,7 +195,7 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
             P[y][1] = __builtin_amdgcn_perm(0, d, 0x0c030c02);
         }
     }
-    else if (yf == 0)
+    else if (yf == 0 && !diag)
     {
         // luma_hpp: dst = clip((sum_k src[x-3+k]*c[k] + 32) >> 6)
         const uint32_t tlo = k_taps_s8[xf][0], thi = k_taps_s8[xf][1];
@@ -211,7 +215,7 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
             P[y][1] = pack2(h[2], h[3]);
         }
     }
-    else if (xf == 0)
+    else if (xf == 0 && !diag)
     {
         // luma_vpp: same rounding, taps run down the column.  The R + 7 source rows are transposed
         // (v_perm_b32) into four column vectors of 4 (NT + 2) bytes; output row y takes bytes y .. y + 7.
@@ -311,9 +315,9 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
 }
 
 // one 4x4 tile
-__device__ __forceinline__ void ref_tile(const uint8_t *ref, int stride, int xf, int yf, uint32_t P[4][2])
+__device__ __forceinline__ void ref_tile(const uint8_t *ref, int stride, int xf, int yf, uint32_t P[4][2], bool diag = false)
 {
-    ref_strip<1>(ref, stride, xf, yf, P);
+    ref_strip<1>(ref, stride, xf, yf, P, diag);
 }
 
 // SAD or SATD of one 4x4 tile.  `f` walks the source block with `fstride`.

@@ -102,9 +102,10 @@ __device__ __forceinline__ void wave_init(Wave &wv, WaveLds *s, int w, int h)
 __device__ __forceinline__ void load_fenc(Wave &wv, const uint8_t *src, int sstride)
 {
     const int ndw = wv.ntx * wv.h;
+    const float inv_ntx = __builtin_amdgcn_rcpf((float)wv.ntx); // i / ntx below is exact: i < 1024, ntx <= 16
     for (int i = wv.lane; i < ndw; i += 64)
     {
-        int y = i / wv.ntx, x = i - y * wv.ntx;
+        int y = (int)(((float)i + 0.5f) * inv_ntx), x = i - y * wv.ntx;
         *(uint32_t *)(wv.s->fenc + y * 64 + 4 * x) = ld4g(as_global(src) + y * sstride + 4 * x);
     }
     wave_sync();
@@ -180,7 +181,7 @@ __device__ __forceinline__ void q_eval(Wave &wv, int metric)
     wave_sync();
     const int total = nq * wv.nt;
     // i / nt and t / ntx by reciprocal: exact for i < 4096, nt <= 256 (error 4e-4 << 0.5 / nt)
-    const float inv_nt = 1.0f / (float)wv.nt, inv_ntx = 1.0f / (float)wv.ntx;
+    const float inv_nt = __builtin_amdgcn_rcpf((float)wv.nt), inv_ntx = __builtin_amdgcn_rcpf((float)wv.ntx);
     for (int i = lane; i < total; i += 64)
     {
         const int c = (int)(((float)i + 0.5f) * inv_nt), t = i - c * wv.nt;
@@ -204,7 +205,11 @@ __device__ __forceinline__ void q_eval(Wave &wv, int metric)
             if (wv.lowres)
                 lowres_tile(wv.ref, wv.lref1, wv.lref2, wv.lref3, wv.stride, qx, qy, 4 * ty * wv.stride + 4 * tx, pix);
             else
-                ref_tile(r, wv.stride, qx & 3, qy & 3, pix);
+            {
+                // lanes of this pass that need the diagonal filter pull the half-fractional ones along
+                const bool any_diag = __ballot((qx & 3) && (qy & 3)) != 0;
+                ref_tile(r, wv.stride, qx & 3, qy & 3, pix, any_diag);
+            }
             v = tile_metric(f, 64, pix, metric);
         }
         atomicAdd(&s->cost[c], v);
