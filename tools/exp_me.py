@@ -36,6 +36,8 @@ def timeit(jobs, label, reps=5):
 
 base = synth.me_jobs(W, H, 3, refs, mot, method=abi.HEX, subme=2, merange=57)
 timeit(base, "all, HEX subme2")
+timeit(base[np.argsort(-base["pu_w"].astype(int), kind="stable")], "all, big PUs first")
+timeit(base[np.argsort(base["pu_w"].astype(int), kind="stable")], "all, small PUs first")
 for s in (64, 32, 16, 8):
     timeit(base[base["pu_w"] == s], f"only {s}x{s}")
 for sub in (0, 1, 2, 5, 7):

@@ -556,8 +556,9 @@ int x265_hip_me_batch(x265_hip_ctx *c, const x265_hip_me_job *jobs, int n, x265_
     if (r || (r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*jobs))) ||
         (r = ensure(c, c->out, (size_t)n * sizeof(*results))))
         return r;
-    memcpy(c->in.h, jobs, (size_t)n * sizeof(*jobs));
-    HIP_TRY(hipMemcpyAsync(c->in.d, c->in.h, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
+    // straight from the caller's memory: the runtime pipelines its own staging, which beats a copy into the
+    // pinned mirror followed by one DMA
+    HIP_TRY(hipMemcpyAsync(c->in.d, jobs, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
     launch_me(c->dev_tabs, (const x265_hip_me_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(*results), hipMemcpyDeviceToHost, c->stream));
