@@ -185,6 +185,24 @@ typedef struct x265_hip_cost_req
 
 int x265_hip_cost_batch(x265_hip_ctx *ctx, const x265_hip_cost_req *reqs, int n, int32_t *costs);
 
+/* Bidirectional candidate: the block against the rounded average of two uni-directional
+ * luma predictions, as TEncSearch::predInterSearch measures it (source/Lib/TLibEncoder/TEncSearch.cpp:2360-2412:
+ * xPredInterLumaBlk per list, TComPrediction.cpp:400-433 = the pixels of subpelCompare; pixelavg_pp,
+ * common/pixel.cpp:546-560; then satd / sad of the block).  No rate term is added. */
+typedef struct x265_hip_bidir_req
+{
+    int32_t fenc_plane;
+    int32_t ref0_plane, ref1_plane;
+    int16_t pu_x, pu_y;
+    uint8_t pu_w, pu_h; /* one of the 25 partitions */
+    uint8_t metric;     /* X265_HIP_SAD / X265_HIP_SATD */
+    uint8_t pad;
+    int16_t qmv0_x, qmv0_y, qmv1_x, qmv1_y;
+} x265_hip_bidir_req;
+
+int x265_hip_bidir_cost_batch(x265_hip_ctx *ctx, const x265_hip_bidir_req *reqs, int n, int32_t *costs);
+int x265_hip_bidir_cost_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs);
+
 /* one call of MotionEstimate::motionEstimate (motion.h:93; motion.cpp:526-1124), non-lowres branch */
 typedef struct x265_hip_me_job
 {

@@ -134,13 +134,17 @@ def gen_lowres(R):
     jobs = random_lowres_jobs(rng, 400, size[0], size[1], pyoracle.ME_JOB)
     tabs = {q: R.bitcost_table(q) for q in (12, 20, 33)}
     res = R.me_batch(low, tabs, jobs)
+    # bidirectional candidates on the full-resolution golden pictures
+    from conftest import random_bidir_reqs
+    breqs = random_bidir_reqs(np.random.default_rng(79), 400, planes[0].w, planes[0].h, pyoracle.BIDIR_REQ, pyoracle.PARTS)
+    bres = R.bidir_cost_batch([p.as_tuple() for p in planes], breqs)
     # weighted reference planes (MotionReference::applyWeight) of picture 0: (w0, offset, log2 denominator)
     wcases = np.array([(64, 0, 6), (70, -3, 6), (37, 10, 5), (1, 0, 0), (200, -100, 7)], np.int32)
     p = planes[0]
     wcrc = np.array([crc(R.weighted_plane(p.buf, p.origin, p.stride, p.w, p.h, int(a), int(b), int(c))) for a, b, c in wcases],
                     np.uint32)
     np.savez_compressed(os.path.join(OUT, "lowres.npz"), jobs=jobs, results=res, size=np.array(size, np.int32),
-                        plane_crc=np.array([crc(b) for (b, _, _) in low], np.uint32), weight_cases=wcases, weight_crc=wcrc)
+                        plane_crc=np.array([crc(b) for (b, _, _) in low], np.uint32), weight_cases=wcases, weight_crc=wcrc, bidir_reqs=breqs, bidir_costs=bres)
 
 
 def main():

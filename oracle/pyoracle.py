@@ -39,6 +39,14 @@ COST_REQ = np.dtype([
 ])
 assert COST_REQ.itemsize == 20
 
+BIDIR_REQ = np.dtype([
+    ("fenc_plane", "<i4"), ("ref0_plane", "<i4"), ("ref1_plane", "<i4"),
+    ("pu_x", "<i2"), ("pu_y", "<i2"),
+    ("pu_w", "u1"), ("pu_h", "u1"), ("metric", "u1"), ("pad", "u1"),
+    ("qmv0_x", "<i2"), ("qmv0_y", "<i2"), ("qmv1_x", "<i2"), ("qmv1_y", "<i2"),
+])
+assert BIDIR_REQ.itemsize == 28
+
 
 class _Plane(C.Structure):
     _fields_ = [("origin", C.c_void_p), ("stride", C.c_ssize_t)]
@@ -179,6 +187,12 @@ class Checker:
                              C.c_int(offset))
         self._f("extend_pic_border")(_ptr(out, origin), C.c_ssize_t(stride), C.c_int(width), C.c_int(height),
                                      C.c_int(margin_x), C.c_int(margin_y))
+        return out
+
+    def bidir_cost_batch(self, planes, reqs):
+        reqs = np.ascontiguousarray(reqs, dtype=BIDIR_REQ)
+        out = np.zeros(len(reqs), np.int32)
+        self._f("bidir_cost_batch")(self._planes(planes), _ptr(reqs), C.c_int(len(reqs)), _ptr(out))
         return out
 
     def ctu_fullsearch(self, fenc, ref, costtab, ctu_x, ctu_y, mvmin, mvmax, qmvp):

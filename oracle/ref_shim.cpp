@@ -212,6 +212,43 @@ void x265r_extend_pic_border(uint8_t *pic, intptr_t stride, int width, int heigh
     extendPicBorder(pic, (int)stride, width, height, marginX, marginY); /* uses primitives.extendRowBorder */
 }
 
+/* the call sequence of TComPrediction::xPredInterLumaBlk (TComPrediction.cpp:400-433) on the reference's primitives */
+static void ref_predict_luma(int part, int w, pixel *p, intptr_t stride, int qx, int qy, pixel *dst)
+{
+    int xf = qx & 3, yf = qy & 3;
+    p += (qx >> 2) + (qy >> 2) * stride;
+    if (!(xf | yf))
+        g_c.luma_copy_pp[part](dst, 64, p, stride);
+    else if (!yf)
+        g_c.luma_hpp[part](p, stride, dst, 64, xf);
+    else if (!xf)
+        g_c.luma_vpp[part](p, stride, dst, 64, yf);
+    else
+    {
+        static thread_local int16_t immed[64 * (64 + 8)];
+        g_c.luma_hps[part](p, stride, immed, w, xf, 1);
+        g_c.luma_vsp[part](immed + 3 * w, w, dst, 64, yf);
+    }
+}
+
+/* TEncSearch.cpp:2360-2412: pixelavg_pp of the two predictions, then satd / sad of the block */
+void x265r_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *reqs, int n, int32_t *out)
+{
+    init();
+    static thread_local pixel p0[64 * 64], p1[64 * 64], avg[64 * 64];
+    for (int i = 0; i < n; i++)
+    {
+        const x265o_bidir_req *r = &reqs[i];
+        const x265o_plane &f = planes[r->fenc_plane], &a = planes[r->ref0_plane], &b = planes[r->ref1_plane];
+        int part = partitionFromSizes(r->pu_w, r->pu_h);
+        ref_predict_luma(part, r->pu_w, (pixel *)a.origin + r->pu_x + (intptr_t)r->pu_y * a.stride, a.stride, r->qmv0_x, r->qmv0_y, p0);
+        ref_predict_luma(part, r->pu_w, (pixel *)b.origin + r->pu_x + (intptr_t)r->pu_y * b.stride, b.stride, r->qmv1_x, r->qmv1_y, p1);
+        g_c.pixelavg_pp[part](avg, 64, p0, 64, p1, 64, 32);
+        pixel *fe = (pixel *)f.origin + r->pu_x + (intptr_t)r->pu_y * f.stride;
+        out[i] = r->metric ? g_c.satd[part](fe, f.stride, avg, 64) : g_c.sad[part](fe, f.stride, avg, 64);
+    }
+}
+
 void x265r_weight_pp(const uint8_t *src, uint8_t *dst, intptr_t sstride, intptr_t dstride, int width, int height,
                      int w0, int round, int shift, int offset)
 {

@@ -1023,6 +1023,52 @@ int x265o_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, in
     return subpel_cost(&c, qmvx, qmvy, metric);
 }
 
+/* Bidirectional candidate, ref: TEncSearch::predInterSearch, Lib/TLibEncoder/TEncSearch.cpp:2360-2412:
+ * two uni-directional luma predictions (xPredInterLumaBlk, Lib/TLibCommon/TComPrediction.cpp:400-433: copy /
+ * luma_hpp / luma_vpp / luma_hps + luma_vsp, the pixels subpelCompare compares), pixelavg_pp
+ * (common/pixel.cpp:546-560), then sad / satd against the block. */
+static void predict_luma(int part, int w, const uint8_t *p, intptr_t stride, int qx, int qy, uint8_t *dst)
+{
+    int xf = qx & 3, yf = qy & 3;
+    p += (qx >> 2) + (qy >> 2) * stride;
+    if (!(xf | yf))
+        x265o_luma_copy_pp(part, dst, 64, p, stride);
+    else if (!yf)
+        x265o_luma_hpp(part, p, stride, dst, 64, xf);
+    else if (!xf)
+        x265o_luma_vpp(part, p, stride, dst, 64, yf);
+    else
+    {
+        int16_t immed[64 * (64 + 8)];
+        x265o_luma_hps(part, p, stride, immed, w, xf, 1);
+        x265o_luma_vsp(part, immed + 3 * w, w, dst, 64, yf);
+    }
+}
+
+int x265o_bidir_cost(const x265o_plane *fenc, const x265o_plane *ref0, const x265o_plane *ref1, int x, int y, int w,
+                     int h, int qmv0x, int qmv0y, int qmv1x, int qmv1y, int metric)
+{
+    uint8_t p0[64 * 64], p1[64 * 64], avg[64 * 64];
+    int part = x265o_partition_from_sizes(w, h);
+    predict_luma(part, w, ref0->origin + x + (intptr_t)y * ref0->stride, ref0->stride, qmv0x, qmv0y, p0);
+    predict_luma(part, w, ref1->origin + x + (intptr_t)y * ref1->stride, ref1->stride, qmv1x, qmv1y, p1);
+    for (int r = 0; r < h; r++)
+        for (int c = 0; c < w; c++)
+            avg[r * 64 + c] = (uint8_t)((p0[r * 64 + c] + p1[r * 64 + c] + 1) >> 1);
+    const uint8_t *f = fenc->origin + x + (intptr_t)y * fenc->stride;
+    return metric ? x265o_satd(part, f, fenc->stride, avg, 64) : sad_wh(w, h, f, fenc->stride, avg, 64);
+}
+
+void x265o_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *reqs, int n, int32_t *out)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const x265o_bidir_req *r = &reqs[i];
+        out[i] = x265o_bidir_cost(&planes[r->fenc_plane], &planes[r->ref0_plane], &planes[r->ref1_plane], r->pu_x, r->pu_y,
+                                  r->pu_w, r->pu_h, r->qmv0_x, r->qmv0_y, r->qmv1_x, r->qmv1_y, r->metric);
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* lookahead planes                                                          */
 

@@ -72,6 +72,18 @@ typedef struct x265o_cost_req
     int16_t qmv_x, qmv_y;
 } x265o_cost_req;
 
+/* block vs the average of two predictions (same layout as x265_hip_bidir_req) */
+typedef struct x265o_bidir_req
+{
+    int32_t fenc_plane;
+    int32_t ref0_plane, ref1_plane;
+    int16_t pu_x, pu_y;
+    uint8_t pu_w, pu_h;
+    uint8_t metric;
+    uint8_t pad;
+    int16_t qmv0_x, qmv0_y, qmv1_x, qmv1_y;
+} x265o_bidir_req;
+
 int  x265o_partition_from_sizes(int w, int h);
 void x265o_partition_size(int part, int *w, int *h);
 
@@ -101,6 +113,11 @@ int  x265o_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, i
 void x265o_cost_batch(const x265o_plane *planes, const x265o_cost_req *reqs, int n, int32_t *out, int nthreads);
 void x265o_me_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_me_job *jobs, int n,
                     x265o_me_result *out, int nthreads);
+
+/* bidirectional candidate: TEncSearch.cpp:2360-2412 (two xPredInterLumaBlk predictions, pixelavg_pp, sad / satd) */
+int  x265o_bidir_cost(const x265o_plane *fenc, const x265o_plane *ref0, const x265o_plane *ref1, int x, int y, int w,
+                      int h, int qmv0x, int qmv0y, int qmv1x, int qmv1y, int metric);
+void x265o_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *reqs, int n, int32_t *out);
 
 /* lookahead planes: frame_init_lowres_core (pixel.cpp:595-618) and extendPicBorder (pixel.cpp:893-911) */
 void x265o_frame_init_lowres(const uint8_t *src0, uint8_t *dst0, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc,

@@ -105,3 +105,16 @@ def random_lowres_jobs(rng, n, lw, ll, dtype, fenc_plane=4, ref_planes=(0, 8), m
             j["mvc"][2 * c] = int(rng.integers(-30, 30)) if rng.integers(3) else 0
             j["mvc"][2 * c + 1] = int(rng.integers(-30, 30)) if rng.integers(3) else 0
     return jobs
+
+
+def random_bidir_reqs(rng, n, W, H, dtype, parts, planes=(1, 0, 2)):
+    """blocks of every partition against the average of two predictions at random quarter-pel vectors"""
+    reqs = np.zeros(n, dtype)
+    for r in reqs:
+        w, h = parts[int(rng.integers(0, 25))]
+        r["fenc_plane"], r["ref0_plane"], r["ref1_plane"] = planes[0], planes[1], int(rng.choice(planes[1:]))
+        r["pu_x"], r["pu_y"] = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+        r["pu_w"], r["pu_h"], r["metric"] = w, h, int(rng.integers(0, 2))
+        for k in ("qmv0_x", "qmv0_y", "qmv1_x", "qmv1_y"):
+            r[k] = int(rng.integers(-90, 90)) if rng.integers(4) else 4 * int(rng.integers(-20, 20))
+    return reqs

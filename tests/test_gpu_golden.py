@@ -118,6 +118,11 @@ def test_lookahead_planes_and_search_reproduce_reference_fixtures():
     want = g["results"].view(got.dtype)
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (g["jobs"][bad[0]], got[bad[0]], want[bad[0]])
+    # bidirectional candidates on the full-resolution pictures (planes 20..22)
+    br = g["bidir_reqs"].copy()
+    for k in ("fenc_plane", "ref0_plane", "ref1_plane"):
+        br[k] += 20
+    assert np.array_equal(ctx.bidir_cost_batch(br), g["bidir_costs"])
     # weighted reference planes: the fixture's CRCs cover whole buffers; 416 is not a multiple of 64, so the 32
     # columns between the right margin and the stride are never written by either side (zero in both)
     p = golden_planes()[0]

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import random_lowres_jobs, random_me_jobs
+from conftest import random_bidir_reqs, random_lowres_jobs, random_me_jobs
 
 pytestmark = pytest.mark.gpu
 
@@ -236,3 +236,15 @@ def test_plane_weight_and_border(oracle, small_seq):
     with pytest.raises(lib.X265HipError):
         ctx.plane_extend_border(2, p.w, p.h, margin_y=200)  # does not fit the buffer
     ctx.close()
+
+
+@pytest.mark.parametrize("n", [1, 33, 2500])
+def test_bidir_cost_batch(gpu_ctx, oracle, small_seq, n):
+    """x265_hip_bidir_cost_batch: block vs the rounded average of two interpolated predictions"""
+    from x265_amd import abi
+    rng = np.random.default_rng(200 + n)
+    reqs = random_bidir_reqs(rng, n, small_seq[0].w, small_seq[0].h, abi.BIDIR_REQ, abi.PARTS)
+    got = gpu_ctx.bidir_cost_batch(reqs)
+    want = oracle.bidir_cost_batch(_planes(small_seq), reqs)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, f"request {bad[0]}: {reqs[bad[0]]} got {got[bad[0]]} want {want[bad[0]]}"

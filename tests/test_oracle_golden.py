@@ -148,3 +148,9 @@ def test_weighted_planes_match_reference_fixtures(oracle):
     p = golden_planes()[0]
     got = [crc(oracle.weighted_plane(p.buf, p.origin, p.stride, p.w, p.h, int(a), int(b), int(c))) for a, b, c in g["weight_cases"]]
     assert got == [int(v) for v in g["weight_crc"]]
+
+
+def test_bidir_costs_match_reference_fixtures(oracle):
+    g = np.load(os.path.join(GOLD, "lowres.npz"))
+    got = oracle.bidir_cost_batch([p.as_tuple() for p in golden_planes()], g["bidir_reqs"])
+    assert np.array_equal(got, g["bidir_costs"])

@@ -3,7 +3,7 @@ Skipped where oracle/_ref/libx265ref.so is absent (it is built only where /root/
 import numpy as np
 import pytest
 
-from conftest import random_lowres_jobs, random_me_jobs
+from conftest import random_bidir_reqs, random_lowres_jobs, random_me_jobs
 from oracle import pyoracle
 
 pytestmark = pytest.mark.skipif(not pyoracle.have_ref(), reason="reference build not present")
@@ -89,3 +89,13 @@ def test_weighted_plane_and_border(oracle, ref, small_seq):
         a = oracle.weighted_plane(p.buf, p.origin, p.stride, p.w, p.h, w0, off, den)
         b = ref.weighted_plane(p.buf, p.origin, p.stride, p.w, p.h, w0, off, den)
         assert np.array_equal(a, b), (w0, off, den)
+
+
+def test_bidir_cost(oracle, ref, small_seq):
+    """two xPredInterLumaBlk predictions, pixelavg_pp, sad / satd: all partitions, all fraction pairs"""
+    rng = np.random.default_rng(12)
+    planes = [p.as_tuple() for p in small_seq]
+    reqs = random_bidir_reqs(rng, 1500, small_seq[0].w, small_seq[0].h, pyoracle.BIDIR_REQ, pyoracle.PARTS)
+    a, b = oracle.bidir_cost_batch(planes, reqs), ref.bidir_cost_batch(planes, reqs)
+    bad = np.nonzero(a != b)[0]
+    assert len(bad) == 0, (reqs[bad[0]], a[bad[0]], b[bad[0]])

@@ -34,3 +34,11 @@ COST_REQ = np.dtype([
     ("qmv_x", "<i2"), ("qmv_y", "<i2"),
 ])
 assert COST_REQ.itemsize == 20
+
+BIDIR_REQ = np.dtype([
+    ("fenc_plane", "<i4"), ("ref0_plane", "<i4"), ("ref1_plane", "<i4"),
+    ("pu_x", "<i2"), ("pu_y", "<i2"),
+    ("pu_w", "u1"), ("pu_h", "u1"), ("metric", "u1"), ("pad", "u1"),
+    ("qmv0_x", "<i2"), ("qmv0_y", "<i2"), ("qmv1_x", "<i2"), ("qmv1_y", "<i2"),
+])
+assert BIDIR_REQ.itemsize == 28

@@ -611,6 +611,49 @@ int x265_hip_cost_batch(x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n, i
     return X265_HIP_OK;
 }
 
+int x265_hip_bidir_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void *d_costs)
+{
+    if (!c || n < 0 || (n && (!d_reqs || !d_costs)))
+        return fail(X265_HIP_EINVAL, "bidir_cost_batch_device: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = push_tabs(c);
+    if (r)
+        return r;
+    launch_bidir_cost(c->dev_tabs, (const x265_hip_bidir_req *)d_reqs, n, (int32_t *)d_costs, c->stream);
+    HIP_TRY(hipGetLastError());
+    return X265_HIP_OK;
+}
+
+int x265_hip_bidir_cost_batch(x265_hip_ctx *c, const x265_hip_bidir_req *reqs, int n, int32_t *costs)
+{
+    if (!c || n < 0 || (n && (!reqs || !costs)))
+        return fail(X265_HIP_EINVAL, "bidir_cost_batch: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++)
+    {
+        int r = check_block(c, reqs[i].fenc_plane, reqs[i].ref0_plane, reqs[i].pu_w, reqs[i].pu_h, "bidir_req", i);
+        if (r || (r = check_block(c, reqs[i].fenc_plane, reqs[i].ref1_plane, reqs[i].pu_w, reqs[i].pu_h, "bidir_req", i)))
+            return r;
+        if (reqs[i].metric > X265_HIP_SATD)
+            return fail(X265_HIP_EINVAL, "bidir_req[%d]: unknown metric %d", i, reqs[i].metric);
+    }
+    int r;
+    if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))) ||
+        (r = ensure(c, c->out, (size_t)n * sizeof(int32_t))))
+        return r;
+    HIP_TRY(hipMemcpyAsync(c->in.d, reqs, (size_t)n * sizeof(*reqs), hipMemcpyHostToDevice, c->stream));
+    launch_bidir_cost(c->dev_tabs, (const x265_hip_bidir_req *)c->in.d, n, (int32_t *)c->out.d, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(costs, c->out.h, (size_t)n * sizeof(int32_t));
+    return X265_HIP_OK;
+}
+
 int x265_hip_fullsearch_device(x265_hip_ctx *c, const void *d_jobs, int n, void *d_results)
 {
     if (!c || n < 0 || (n && (!d_jobs || !d_results)))

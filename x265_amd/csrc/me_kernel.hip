@@ -1200,10 +1200,33 @@ struct CostLds
     const uint8_t *fenc[COST_BATCH];
     const uint8_t *ref[COST_BATCH];
     int fstride[COST_BATCH], rstride[COST_BATCH], info[COST_BATCH];
+    // bidirectional requests: the second prediction; its fraction sits in info bits 14..17
+    const uint8_t *ref1[COST_BATCH];
+    int rstride1[COST_BATCH];
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void cost_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
-                                                   int32_t *out)
+// rounded average of two predictions, packed pairs: pixelavg_pp (reference common/pixel.cpp:546-560)
+__device__ __forceinline__ uint32_t avg_pairs(uint32_t a, uint32_t b)
+{
+    return ((a + b + 0x00010001u) >> 1) & 0x01ff01ffu; // halves are <= 255 + 255 + 1: no carry across them
+}
+
+__device__ __forceinline__ int req_ref0(const x265_hip_cost_req &r) { return r.ref_plane; }
+__device__ __forceinline__ int req_qx0(const x265_hip_cost_req &r) { return r.qmv_x; }
+__device__ __forceinline__ int req_qy0(const x265_hip_cost_req &r) { return r.qmv_y; }
+__device__ __forceinline__ int req_ref1(const x265_hip_cost_req &) { return 0; }
+__device__ __forceinline__ int req_qx1(const x265_hip_cost_req &) { return 0; }
+__device__ __forceinline__ int req_qy1(const x265_hip_cost_req &) { return 0; }
+__device__ __forceinline__ int req_ref0(const x265_hip_bidir_req &r) { return r.ref0_plane; }
+__device__ __forceinline__ int req_qx0(const x265_hip_bidir_req &r) { return r.qmv0_x; }
+__device__ __forceinline__ int req_qy0(const x265_hip_bidir_req &r) { return r.qmv0_y; }
+__device__ __forceinline__ int req_ref1(const x265_hip_bidir_req &r) { return r.ref1_plane; }
+__device__ __forceinline__ int req_qx1(const x265_hip_bidir_req &r) { return r.qmv1_x; }
+__device__ __forceinline__ int req_qy1(const x265_hip_bidir_req &r) { return r.qmv1_y; }
+
+// BIDIR: requests are x265_hip_bidir_req; the block is compared with the average of two predictions
+template <bool BIDIR, typename Req>
+__device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *reqs, int n, int32_t *out)
 {
     __shared__ CostLds lds[4];
     __shared__ PlaneDesc planes[X265_HIP_MAX_PLANES];
@@ -1216,7 +1239,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void c
     const int lane = threadIdx.x & 63;
     const int nbatch = (n + COST_BATCH - 1) / COST_BATCH, nwaves = gridDim.x * 4;
     int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    x265_hip_cost_req cur = {};
+    Req cur = {};
     if (lane < COST_BATCH && b * COST_BATCH + lane < n)
         cur = reqs[b * COST_BATCH + lane];
     for (; b < nbatch; b += nwaves)
@@ -1226,14 +1249,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void c
         int ni = 0;
         if (have)
         {
-            const PlaneDesc fp = planes[cur.fenc_plane], rp = planes[cur.ref_plane];
+            const PlaneDesc fp = planes[cur.fenc_plane], rp = planes[req_ref0(cur)];
             const int tall = (cur.pu_h & 7) == 0;
+            const int qx = req_qx0(cur), qy = req_qy0(cur);
             ni = (cur.pu_w >> 2) * (cur.pu_h >> (2 + tall));
             L.fenc[lane] = fp.origin + (long)cur.pu_y * fp.stride + cur.pu_x;
-            L.ref[lane] = rp.origin + (long)(cur.pu_y + (cur.qmv_y >> 2)) * rp.stride + cur.pu_x + (cur.qmv_x >> 2);
+            L.ref[lane] = rp.origin + (long)(cur.pu_y + (qy >> 2)) * rp.stride + cur.pu_x + (qx >> 2);
             L.fstride[lane] = fp.stride;
             L.rstride[lane] = rp.stride;
-            L.info[lane] = (cur.pu_w >> 2) | ((cur.qmv_x & 3) << 8) | ((cur.qmv_y & 3) << 10) | (cur.metric << 12) | (tall << 13);
+            int info = (cur.pu_w >> 2) | ((qx & 3) << 8) | ((qy & 3) << 10) | (cur.metric << 12) | (tall << 13);
+            if (BIDIR)
+            {
+                const PlaneDesc rp1 = planes[req_ref1(cur)];
+                const int qx1 = req_qx1(cur), qy1 = req_qy1(cur);
+                L.ref1[lane] = rp1.origin + (long)(cur.pu_y + (qy1 >> 2)) * rp1.stride + cur.pu_x + (qx1 >> 2);
+                L.rstride1[lane] = rp1.stride;
+                info |= ((qx1 & 3) << 14) | ((qy1 & 3) << 16);
+            }
+            L.info[lane] = info;
         }
         const bool small = __ballot(ni > 2) == 0;
         if (lane < COST_BATCH)
@@ -1284,17 +1317,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void c
             const int xf = (info >> 8) & 3, yf = (info >> 10) & 3, metric = (info >> 12) & 1;
             const int ty = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)ntx)), tx = t - ty * ntx; // exact: t < 256, ntx <= 16
             int v;
-            if (info >> 13)
+            if ((info >> 13) & 1)
             {
                 const uint8_t *f = L.fenc[k] + 8 * ty * fstride + 4 * tx;
                 uint32_t pix[8][2];
                 ref_strip<2>(L.ref[k] + 8 * ty * rstride + 4 * tx, rstride, xf, yf, pix);
+                if (BIDIR)
+                {
+                    const int rs1 = L.rstride1[k];
+                    uint32_t pix1[8][2];
+                    ref_strip<2>(L.ref1[k] + 8 * ty * rs1 + 4 * tx, rs1, (info >> 14) & 3, (info >> 16) & 3, pix1);
+#pragma unroll
+                    for (int y = 0; y < 8; y++)
+                    {
+                        pix[y][0] = avg_pairs(pix[y][0], pix1[y][0]);
+                        pix[y][1] = avg_pairs(pix[y][1], pix1[y][1]);
+                    }
+                }
                 v = tile_metric<true>(f, fstride, pix, metric) + tile_metric<true>(f + 4 * fstride, fstride, pix + 4, metric);
             }
             else
             {
                 uint32_t pix[4][2];
                 ref_strip<1>(L.ref[k] + 4 * ty * rstride + 4 * tx, rstride, xf, yf, pix);
+                if (BIDIR)
+                {
+                    const int rs1 = L.rstride1[k];
+                    uint32_t pix1[4][2];
+                    ref_strip<1>(L.ref1[k] + 4 * ty * rs1 + 4 * tx, rs1, (info >> 14) & 3, (info >> 16) & 3, pix1);
+#pragma unroll
+                    for (int y = 0; y < 4; y++)
+                    {
+                        pix[y][0] = avg_pairs(pix[y][0], pix1[y][0]);
+                        pix[y][1] = avg_pairs(pix[y][1], pix1[y][1]);
+                    }
+                }
                 v = tile_metric<true>(L.fenc[k] + 4 * ty * fstride + 4 * tx, fstride, pix, metric);
             }
             atomicAdd(&L.cost[k], v);
@@ -1306,10 +1363,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void c
     }
 }
 
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void cost_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
+                                                                                           int32_t *out)
+{
+    cost_body<false>(tabs, reqs, n, out);
+}
+
+__global__ __launch_bounds__(256) void bidir_cost_kernel(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out)
+{
+    cost_body<true>(tabs, reqs, n, out);
+}
+
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st)
 {
     if (n > 0)
         hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, st, tabs, jobs, n, out);
+}
+
+void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out, hipStream_t st)
+{
+    if (n > 0)
+    {
+        const int blocks = ((n + COST_BATCH - 1) / COST_BATCH + 3) / 4;
+        hipLaunchKernelGGL(bidir_cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out);
+    }
 }
 
 void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, hipStream_t st)

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from .abi import COST_REQ, ME_JOB, ME_RESULT, NUM_PARTS
+from .abi import BIDIR_REQ, COST_REQ, ME_JOB, ME_RESULT, NUM_PARTS
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libx265_hip.so")
@@ -33,6 +33,7 @@ EXPORTS = [
     "x265_hip_fullsearch_device", "x265_hip_costtab_build", "x265_hip_costtab_set_qp",
     "x265_hip_plane_download", "x265_hip_lowres_geometry_of", "x265_hip_lowres_init",
     "x265_hip_plane_extend_border", "x265_hip_plane_weight",
+    "x265_hip_bidir_cost_batch", "x265_hip_bidir_cost_batch_device",
 ]
 
 
@@ -179,6 +180,15 @@ class Context:
         out = np.zeros(len(reqs), np.int32)
         _check(load().x265_hip_cost_batch(self._h, _p(reqs), C.c_int(len(reqs)), _p(out)))
         return out
+
+    def bidir_cost_batch(self, reqs):
+        reqs = np.ascontiguousarray(reqs, BIDIR_REQ)
+        out = np.zeros(len(reqs), np.int32)
+        _check(load().x265_hip_bidir_cost_batch(self._h, _p(reqs), C.c_int(len(reqs)), _p(out)))
+        return out
+
+    def bidir_cost_batch_device(self, d_reqs, n, d_costs):
+        _check(load().x265_hip_bidir_cost_batch_device(self._h, C.c_void_p(d_reqs), C.c_int(n), C.c_void_p(d_costs)))
 
     def me_batch(self, jobs):
         jobs = np.ascontiguousarray(jobs, ME_JOB)
