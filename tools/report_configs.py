@@ -82,6 +82,22 @@ def run(w, h, tag):
     res["lowres_init"] = {"lowres_picture": f"{geo.width}x{geo.lines}", "ms_per_picture": ms,
                           "algorithmic_bytes": alg, "algorithmic_gb_per_s": alg / ms / 1e6, "frac_of_hbm_peak": alg / ms / 1e6 / 8000.0,
                           "bytes_incl_margins": wrote, "gb_per_s_incl_margins": wrote / ms / 1e6}
+    # bidirectional candidates: every square PU, predictions from references 2 and 1 at
+    # quarter-pel vectors (both diagonal: the most expensive case), SATD against their average
+    pus = synth.square_pus(w, h)
+    br = np.zeros(len(pus), abi.BIDIR_REQ)
+    br["fenc_plane"], br["ref0_plane"], br["ref1_plane"] = 3, 2, 1
+    br["pu_x"], br["pu_y"] = pus[:, 0], pus[:, 1]
+    br["pu_w"] = br["pu_h"] = pus[:, 2]
+    br["metric"] = abi.SATD
+    br["qmv0_x"], br["qmv0_y"] = 4 * mot[0][0] + 1, 4 * mot[0][1] + 2
+    br["qmv1_x"], br["qmv1_y"] = 4 * mot[1][0] - 1, 4 * mot[1][1] + 1
+    d = torch.from_numpy(br.view(np.uint8).copy()).to(dev)
+    o = torch.empty(len(br), dtype=torch.int32, device=dev)
+    ms = timed(ext, ctx, lambda: ctx.bidir_cost_batch_device(d.data_ptr(), len(br), o.data_ptr()), 10)
+    res["bidir_candidates"] = {"requests": len(br), "ms": ms, "candidates_per_s": len(br) / ms * 1e3,
+                               "pixels_per_s": float((br["pu_w"].astype(np.int64) * br["pu_h"]).sum()) / ms * 1e3}
+
     # reference-plane production: weighted copy + border extension of one picture
     ms = timed(ext, ctx, lambda: ctx.plane_weight(0, 40, w, h, 70, -3, 6), 20)
     alg = w * h + (w + 192) * (h + 160)  # picture read once, padded plane written once
