@@ -29,7 +29,10 @@ __device__ __forceinline__ int s16(int v) { return (int)(int16_t)v; }
 #define QMAX 16
 #define PAT_HEX 0
 #define PAT_SQ 8
-#define PAT_N 17
+#define PAT_STAR8 17  // small star ring in visiting order, units of dist / 2
+#define PAT_STAR16 25 // large star ring (dist > 8) in visiting order, units of dist / 4
+#define PAT_HEX4 41   // UMH hexagon grid, units of the ring index
+#define PAT_N 57
 #define SPEC_SQ_TILES 4    // speculate the square refine for PUs of at most this many 4x4 tiles
 #define SPEC_QPEL_TILES 16 // same for the quarter-pel ring
 
@@ -40,7 +43,7 @@ struct WaveLds
     int qy[QMAX];
     int cost[QMAX];
     int aux[QMAX];         // (tag << 2) | mv-rate mode
-    int pat[PAT_N];        // search patterns, (dy << 16) | (dx & 0xffff): hex2[0..7], then square1[0..8]
+    int pat[PAT_N];        // search patterns, (dy << 16) | (dx & 0xffff): hex2[0..7], square1[0..8], star rings, hex4
 };
 
 // how the evaluation seeds a candidate's cost with its motion-vector rate
@@ -76,6 +79,15 @@ struct Wave
 __device__ __constant__ const int k_pat[PAT_N] = {
     PAT(-1, -2), PAT(-2, 0), PAT(-1, 2), PAT(1, 2), PAT(2, 0), PAT(1, -2), PAT(-1, -2), PAT(-2, 0),
     PAT(0, 0), PAT(0, -1), PAT(0, 1), PAT(-1, 0), PAT(1, 0), PAT(-1, -1), PAT(-1, 1), PAT(1, -1), PAT(1, 1),
+    // StarPatternSearch, dist <= 8 (motion.cpp:300-420): points 2,1,3,4,5,6,8,7; the diagonal ones sit at dist / 2
+    PAT(0, -2), PAT(-1, -1), PAT(1, -1), PAT(-2, 0), PAT(2, 0), PAT(-1, 1), PAT(1, 1), PAT(0, 2),
+    // dist > 8 (motion.cpp:421-520): top, left, right, bottom, then three steps along each edge of the diamond
+    PAT(0, -4), PAT(-4, 0), PAT(4, 0), PAT(0, 4),
+    PAT(-1, -3), PAT(1, -3), PAT(-1, 3), PAT(1, 3), PAT(-2, -2), PAT(2, -2), PAT(-2, 2), PAT(2, 2),
+    PAT(-3, -1), PAT(3, -1), PAT(-3, 1), PAT(3, 1),
+    // hex4 (motion.cpp:132-138)
+    PAT(0, -4), PAT(0, 4), PAT(-2, -3), PAT(2, -3), PAT(-4, -2), PAT(4, -2), PAT(-4, -1), PAT(4, -1),
+    PAT(-4, 0), PAT(4, 0), PAT(-4, 1), PAT(4, 1), PAT(-4, 2), PAT(4, 2), PAT(-2, 3), PAT(2, 3),
 };
 __device__ __forceinline__ int pat_dx(int p) { return (int)(int16_t)p; }
 __device__ __forceinline__ int pat_dy(int p) { return p >> 16; }
@@ -250,6 +262,22 @@ __device__ __forceinline__ void push_pat(Wave &wv, int cx, int cy, int first, in
     wv.nq += count;
 }
 
+// Queue the points lanes 0 .. count-1 offer, skipping the invalid ones and keeping lane order (= the
+// reference's visiting order): lane k's slot is the number of valid lanes below it.
+__device__ __forceinline__ void push_lanes(Wave &wv, int count, int qx, int qy, int aux, bool valid)
+{
+    const bool mine = valid && wv.lane < count;
+    const unsigned long long m = __ballot(mine);
+    if (mine)
+    {
+        const int slot = wv.nq + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        wv.s->qx[slot] = qx;
+        wv.s->qy[slot] = qy;
+        wv.s->aux[slot] = aux;
+    }
+    wv.nq += __popcll(m);
+}
+
 // pattern entry k as a wave-uniform value (k uniform)
 __device__ __forceinline__ int pat_at(const Wave &wv, int k) { return __builtin_amdgcn_readlane(wv.patv, k); }
 
@@ -266,8 +294,6 @@ __device__ __forceinline__ int q_argmin(const Wave &wv, int off, int count)
     return __builtin_amdgcn_readlane(key, 0);
 }
 
-__device__ __constant__ const int8_t k_hex4[16][2] = { { 0, -4 }, { 0, 4 }, { -2, -3 }, { 2, -3 }, { -4, -2 }, { 4, -2 }, { -4, -1 }, { 4, -1 },
-                                                      { -4, 0 }, { 4, 0 }, { -4, 1 }, { 4, 1 }, { -4, 2 }, { 4, 2 }, { -2, 3 }, { 2, 3 } };
 __device__ __constant__ const int8_t k_twopoint[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
                                                           { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
 // {hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd}, motion.cpp:47-57
@@ -783,24 +809,15 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
             {
                 if (ring_raw)
                 {
-                    int dx = 0, dy = 0;
-                    bool moved = false;
-                    for (int k = 0; k < 16; k++)
-                    {
-                        const int cost = q_cost(wv, k);
-                        if (cost < bcost)
-                        {
-                            bcost = cost;
-                            dx = k_hex4[k][0];
-                            dy = k_hex4[k][1];
-                            moved = true;
-                        }
-                    }
+                    // strict-less updates in table order: the first minimum, if it beats bcost
+                    const int key = q_argmin(wv, 0, 16);
                     wv.nq = 0;
-                    if (moved)
+                    if ((key >> 4) < bcost)
                     {
-                        bx = s16(ox + ring * dx);
-                        by = s16(oy + ring * dy);
+                        const int p = pat_at(wv, PAT_HEX4 + (key & 15));
+                        bcost = key >> 4;
+                        bx = s16(ox + ring * pat_dx(p));
+                        by = s16(oy + ring * pat_dy(p));
                     }
                 }
                 ring = (ring + 1) & 0xffff; // uint16_t counter in the reference
@@ -812,20 +829,16 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
             }
             const int room = min(min(hix - ox, ox - lox), min(hiy - oy, oy - loy));
             ring_raw = !(4 * ring > room);
-            if (ring_raw)
             {
-                for (int k = 0; k < 16; k++)
-                    q_push(wv, (ox + k_hex4[k][0] * ring) * 4, (oy + k_hex4[k][1] * ring) * 4, MV_RAW);
-            }
-            else
-            {
-                for (int k = 0; k < 16; k++)
+                const int p = wv.s->pat[PAT_HEX4 + (wv.lane & 15)];
+                if (ring_raw)
+                    push_lanes(wv, 16, (ox + pat_dx(p) * ring) * 4, (oy + pat_dy(p) * ring) * 4, MV_RAW, true);
+                else
                 {
-                    const int mx = s16(ox + s16(k_hex4[k][0] * s16(ring))), my = s16(oy + s16(k_hex4[k][1] * s16(ring)));
-                    if (IN_RANGE(mx, my))
-                        push_f(wv, mx, my);
+                    const int mx = s16(ox + s16(pat_dx(p) * s16(ring))), my = s16(oy + s16(pat_dy(p) * s16(ring)));
+                    push_lanes(wv, 16, s16(s16(mx) << 2), s16(s16(my) << 2), MV_COST, IN_RANGE(mx, my));
+                    flush = FL_BEST;
                 }
-                flush = FL_BEST;
             }
             st = ST_URING;
             break;
@@ -863,66 +876,23 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
                 }
             }
             saved = bcost;
-            if (sd <= 8)
             {
-                const int half = sd >> 1;
-                const int top = s16(oy - sd), bottom = s16(oy + sd), left = s16(ox - sd), right = s16(ox + sd);
-                const int top2 = s16(oy - half), bottom2 = s16(oy + half), left2 = s16(ox - half), right2 = s16(ox + half);
-                // visiting order 2,1,3,4,5,6,8,7; points 1,3,6,8 exist only for dist >= 2
-                if (top >= loy)
-                    push_f(wv, ox, top, 2, sd);
-                if (sd > 1 && top2 >= loy)
-                {
-                    if (left2 >= lox)
-                        push_f(wv, left2, top2, 1, half);
-                    if (right2 <= hix)
-                        push_f(wv, right2, top2, 3, half);
-                }
-                if (left >= lox)
-                    push_f(wv, left, oy, 4, sd);
-                if (right <= hix)
-                    push_f(wv, right, oy, 5, sd);
-                if (sd > 1 && bottom2 <= hiy)
-                {
-                    if (left2 >= lox)
-                        push_f(wv, left2, bottom2, 6, half);
-                    if (right2 <= hix)
-                        push_f(wv, right2, bottom2, 8, half);
-                }
-                if (bottom <= hiy)
-                    push_f(wv, ox, bottom, 7, sd);
-            }
-            else
-            {
-                const int q = sd >> 2;
-                const int top = s16(oy - sd), bottom = s16(oy + sd), left = s16(ox - sd), right = s16(ox + sd);
-                if (top >= loy)
-                    push_f(wv, ox, top, 0, sd);
-                if (left >= lox)
-                    push_f(wv, left, oy, 0, sd);
-                if (right <= hix)
-                    push_f(wv, right, oy, 0, sd);
-                if (bottom <= hiy)
-                    push_f(wv, ox, bottom, 0, sd);
-                for (int idx = 1; idx < 4; idx++)
-                {
-                    const int yt = s16(top + q * idx), yb = s16(bottom - q * idx);
-                    const int xl = s16(ox - q * idx), xr = s16(ox + q * idx);
-                    if (yt >= loy)
-                    {
-                        if (xl >= lox)
-                            push_f(wv, xl, yt, 0, sd);
-                        if (xr <= hix)
-                            push_f(wv, xr, yt, 0, sd);
-                    }
-                    if (yb <= hiy)
-                    {
-                        if (xl >= lox)
-                            push_f(wv, xl, yb, 0, sd);
-                        if (xr <= hix)
-                            push_f(wv, xr, yb, 0, sd);
-                    }
-                }
+                // lane k offers the k-th point of the ring in the reference's visiting order.  A point is
+                // guarded only on the sides it is displaced to, as in the reference (e.g. "if (top >= mvmin.y)").
+                const bool small = sd <= 8;
+                const int k = wv.lane & 15;
+                const int p = wv.s->pat[(small ? PAT_STAR8 : PAT_STAR16) + (small ? (k & 7) : k)];
+                const int ux = pat_dx(p), uy = pat_dy(p);
+                // small ring: units of dist / 2 (the diagonal points, 1 3 6 8, exist only for dist >= 2 and carry
+                // dist / 2 as their distance); large ring: units of dist / 4, no point number
+                const bool diag = small && ((0x66 >> (k & 7)) & 1);
+                const int dx = small ? (ux * sd) >> 1 : ux * (sd >> 2), dy = small ? (uy * sd) >> 1 : uy * (sd >> 2);
+                const int mx = s16(ox + dx), my = s16(oy + dy);
+                const int pnt = small ? (0x78654312 >> (4 * (k & 7))) & 15 : 0;
+                const int dst = diag ? sd >> 1 : sd;
+                const bool ok = !(diag && sd == 1) && (ux < 0 ? mx >= lox : (ux > 0 ? mx <= hix : true)) &&
+                                (uy < 0 ? my >= loy : (uy > 0 ? my <= hiy : true));
+                push_lanes(wv, small ? 8 : 16, s16(s16(mx) << 2), s16(s16(my) << 2), ((((pnt << 16) | dst)) << 2) | MV_COST, ok);
             }
             flush = FL_STAR;
             st = ST_STAR_RING;
