@@ -20,8 +20,8 @@
 //     (v_mad_u32_u16 builds a key from a packed u16 SAD, v_min3_u32 folds two keys per instruction);
 //     the unsigned minimum is the first minimum in raster order.  At the end the keys are widened to
 //     (cost, y, x) and meet in LDS through 64-bit atomic minima.
-//   * Columns beyond a multiple of four (the 129th of a +-64 window) are a second pass through the same
-//     loop: all 32 lane rows take those columns and 1/32 of the window rows each.
+//   * Columns beyond a multiple of four (the 129th of a +-64 window) are done one at a time with v_sad_u8 in
+//     the same streaming form: all 32 lane rows take the column and 1/32 of the window rows each.
 //   * Windows narrower than four columns go through a one-position-per-thread v_sad_u8 loop.
 #include "kernels.h"
 #include "me_device.h"
@@ -160,13 +160,7 @@ __global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTab
     }
     __syncthreads();
 
-    // ---- qsad passes ---------------------------------------------------------------------------
-    // pass 0: x positions [0, 4G), one group of four per 16-lane row, all ny rows.
-    // pass 1: the remaining columns [4G, nx) (the 129th of a +-64 window): every 16-lane row takes the
-    //         same four columns and a slice of ceil(ny / 32) rows (slices may overlap: a position
-    //         evaluated twice yields the same key twice).
     const int G = min(32, nx >> 2);
-    const int npass = G == 0 ? 0 : (nx > 4 * G ? 2 : 1);
     if (G > 0)
     {
         const int lane = tid & 63, wave = tid >> 6;
@@ -197,34 +191,15 @@ __global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTab
             for (int b = 0; b < 4; b++)
                 acc[k][b] = 0;
 
-#pragma clang loop unroll(disable)
-        for (int pass = 0; pass < npass; pass++)
+        // ---- main pass: x positions [0, 4G), one group of four per 16-lane row, all ny rows -------------
         {
-        int xbase, ybase, npos;
-        bool active;
-        if (pass == 0)
-        {
-            active = g < G;
-            xbase = 4 * (active ? g : G - 1);
-            ybase = 0;
-            npos = ny;
-        }
-        else
-        {
-            npos = (ny + 31) >> 5;
-            active = true;
-            xbase = 4 * G;
-            ybase = min(g * npos, ny - npos);
-        }
-        unsigned cx[4];  // x part of the key: (cost_x << 10) | i
-        unsigned inv[4]; // top bit set for columns outside the window: such keys never win
+        const bool active = g < G; // rows beyond G repeat group G - 1: the same keys twice
+        const int xbase = 4 * (active ? g : G - 1), ybase = 0, npos = ny;
+        unsigned cx[4]; // x part of the key: (cost_x << 10) | i
 #pragma unroll
         for (int i = 0; i < 4; i++)
-        {
             cx[i] = ((unsigned)tab_at(tab, j.qmvp_x, fs_s16((j.mvmin_x + xbase + i) << 2)) << FS_KSHIFT) | (unsigned)i;
-            inv[i] = xbase + i < nx ? 0u : 0x80000000u;
-        }
-        const unsigned cxl = cx[xl], invl = inv[xl]; // cxl carries i = xl in its low bits
+        const unsigned cxl = cx[xl]; // carries i = xl in its low bits
 
         unsigned best8[4], best16 = 0xffffffffu, best32 = 0xffffffffu, best64 = 0xffffffffu;
 #pragma unroll
@@ -288,7 +263,7 @@ __global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTab
                     unsigned kmv[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        kmv[i] = ((cx[i] + cyv) & kmask) | inv[i]; // v_and_or_b32
+                        kmv[i] = (cx[i] + cyv) & kmask;
                     unsigned lo[4], hi[4];
 #pragma unroll
                     for (int b = 0; b < 4; b++)
@@ -308,7 +283,7 @@ __global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTab
                     const unsigned pa = __builtin_amdgcn_ubfe(slo, sh_keep, 16) + dpp_get<0xB1>(__builtin_amdgcn_ubfe(slo, sh_send, 16));
                     const unsigned pb = __builtin_amdgcn_ubfe(shi, sh_keep, 16) + dpp_get<0xB1>(__builtin_amdgcn_ubfe(shi, sh_send, 16));
                     const unsigned s32 = (keep_b ? pb : pa) + dpp_get<0x4E>(keep_b ? pa : pb);
-                    const unsigned kmvl = ((cxl + cyv) & kmask) | invl;
+                    const unsigned kmvl = (cxl + cyv) & kmask;
                     best32 = min(best32, (s32 << FS_KSHIFT) + kmvl);
                     const unsigned s64 = dpp_add<0x128>(dpp_add<0x124>(s32));
                     best64 = min(best64, (s64 << FS_KSHIFT) + kmvl);
@@ -333,7 +308,82 @@ __global__ __launch_bounds__(FS_THREADS) void fullsearch2_kernel(const DeviceTab
             if (q < 4)
                 atomicMin(&L.best[0], widen(best64));
         }
-        } // pass
+        } // main pass
+
+        // ---- columns [4G, nx): one column at a time with v_sad_u8 (same pixel rate as qsad, and a single
+        // column is a quarter of a qsad step's work).  Every 16-lane row takes ceil(ny / 32) window rows
+        // (slices may overlap: a position evaluated twice yields the same key twice); same rotating
+        // accumulators, now one u32 per 8x8 block.
+#pragma clang loop unroll(disable)
+        for (int xt = 4 * G; xt < nx; xt++)
+        {
+            const int npos = (ny + 31) >> 5;
+            const int ybase = min(g * npos, ny - npos);
+            const unsigned cxk = ((unsigned)tab_at(tab, j.qmvp_x, fs_s16((j.mvmin_x + xt) << 2)) << FS_KSHIFT) | (unsigned)(xt & 3);
+            const unsigned kmask = (1u << (16 + FS_KSHIFT)) - 1;
+            unsigned b8[4], b16 = 0xffffffffu, b32 = 0xffffffffu, b64 = 0xffffffffu;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                b8[b] = 0xffffffffu;
+            uint32_t a[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    a[k][b] = 0;
+            const uint8_t *wtop = L.win + (by16 + ybase) * FS_WS + bx16 + xt; // any byte alignment
+            const unsigned *cyp = L.cy + ybase;
+            const int S = npos + 7;
+            for (int s0 = 0; s0 < S; s0 += 8)
+            {
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                {
+                    const int s = s0 + jj;
+                    const uint8_t *pt = wtop + s * FS_WS, *pb = pt + 8 * FS_WS;
+                    const uint32_t t0 = ld4u(pt), t1 = ld4u(pt + 4), t2 = ld4u(pt + 8), t3 = ld4u(pt + 12);
+                    const uint32_t u0 = ld4u(pb), u1 = ld4u(pb + 4), u2 = ld4u(pb + 8), u3 = ld4u(pb + 12);
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                    {
+                        const int k = (jj - i) & 7;
+                        a[k][0] = __builtin_amdgcn_sad_u8(t1, f[i][1], __builtin_amdgcn_sad_u8(t0, f[i][0], i ? a[k][0] : 0u));
+                        a[k][1] = __builtin_amdgcn_sad_u8(t3, f[i][3], __builtin_amdgcn_sad_u8(t2, f[i][2], i ? a[k][1] : 0u));
+                        a[k][2] = __builtin_amdgcn_sad_u8(u1, f[8 + i][1], __builtin_amdgcn_sad_u8(u0, f[8 + i][0], i ? a[k][2] : 0u));
+                        a[k][3] = __builtin_amdgcn_sad_u8(u3, f[8 + i][3], __builtin_amdgcn_sad_u8(u2, f[8 + i][2], i ? a[k][3] : 0u));
+                    }
+                    const int y = s - 7;
+                    if (y >= 0 && y < npos)
+                    {
+                        const int k = (jj + 1) & 7;
+                        const unsigned kmv = (cxk + cyp[y + 8]) & kmask;
+#pragma unroll
+                        for (int b = 0; b < 4; b++)
+                            b8[b] = min(b8[b], (a[k][b] << FS_KSHIFT) + kmv);
+                        const unsigned s16sum = a[k][0] + a[k][1] + a[k][2] + a[k][3];
+                        b16 = min(b16, (s16sum << FS_KSHIFT) + kmv);
+                        const unsigned s32 = dpp_add<0x4E>(dpp_add<0xB1>(s16sum)); // the quad's four 16x16 blocks
+                        b32 = min(b32, (s32 << FS_KSHIFT) + kmv);
+                        const unsigned s64 = dpp_add<0x128>(dpp_add<0x124>(s32));  // the row's four quads
+                        b64 = min(b64, (s64 << FS_KSHIFT) + kmv);
+                    }
+                }
+            }
+            auto widen = [&](unsigned k) {
+                return ((unsigned long long)(k >> FS_KSHIFT) << 16) | (((k >> 2) & 255u) << 8) | (unsigned)((xt & ~3) + (k & 3u));
+            };
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+            {
+                const int x8 = bx16 + (b & 1) * 8, y8 = by16 + (b >> 1) * 8;
+                atomicMin(&L.best[21 + (y8 >> 3) * 8 + (x8 >> 3)], widen(b8[b]));
+            }
+            atomicMin(&L.best[5 + (by16 >> 4) * 4 + (bx16 >> 4)], widen(b16));
+            if (sub == 0)
+                atomicMin(&L.best[1 + q32], widen(b32));
+            if (q == 0)
+                atomicMin(&L.best[0], widen(b64));
+        }
     }
     __syncthreads();
 
