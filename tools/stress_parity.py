@@ -1,0 +1,86 @@
+"""One-off stress run: many random requests through every batched entry point against the oracle (16 threads).
+Prints the number of mismatches per family; exits non-zero if there is any."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+from conftest import random_bidir_reqs, random_lowres_jobs, random_me_jobs
+from oracle import pyoracle
+from x265_amd import abi, lib, synth
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+O = pyoracle.load_oracle()
+seq = synth.Sequence(832, 480, seed=11, n_patches=5)
+planes = [synth.Plane(seq.frame(i)) for i in range(3)]
+flat = synth.Plane(np.full((480, 832), 77, np.uint8))
+noise = synth.Plane(np.random.default_rng(1).integers(0, 256, (480, 832), dtype=np.uint8))
+planes += [flat, noise]
+pl = [p.as_tuple() for p in planes]
+ctx = lib.Context(0)
+for i, p in enumerate(planes):
+    ctx.plane_upload(i, p.buf, p.stride, p.origin)
+tabs = {q: O.bitcost_table(q) for q in range(0, 52)}
+for q, t in tabs.items():
+    ctx.costtab_upload(q, t)
+W, H = 832, 480
+bad_total = 0
+
+
+def report(name, got, want, recs):
+    global bad_total
+    bad = np.nonzero(got != want)[0]
+    bad_total += len(bad)
+    print(f"{name:34s} n={len(recs):7d} mismatches={len(bad)}", flush=True)
+    if len(bad):
+        print("   first:", recs[bad[0]], got[bad[0]], want[bad[0]], flush=True)
+
+
+rng = np.random.default_rng(2024)
+for method in range(5):
+    n = N if method < 4 else 200
+    mer = (4, 8, 16, 32, 57) if method < 4 else (2, 5)
+    jobs = []
+    for subme in range(8):
+        for planes_sel in ((1, (0, 2)), (1, (3,)), (4, (0, 4)), (3, (3,))):  # natural, flat ref, noise, flat vs flat
+            j = random_me_jobs(rng, max(1, n // 32), method, subme, W, H, abi.ME_JOB, synth.search_range, abi.PARTS,
+                               meranges=mer, planes=planes_sel)
+            j["qp"] = rng.integers(0, 52, len(j))
+            jobs.append(j)
+    jobs = np.concatenate(jobs)
+    t0 = time.time()
+    want = O.me_batch(pl, tabs, jobs, nthreads=16)
+    got = ctx.me_batch(jobs)
+    report(f"me_batch method {method} ({time.time() - t0:.1f} s)", got, want, jobs)
+
+low, size = [], None
+for p in planes[:3]:
+    four, size = O.lowres_planes(p.buf, p.origin, p.stride, p.w, p.h)
+    low += four
+for i, p in enumerate(planes[:3]):
+    ctx.lowres_init(i, p.w, p.h, 8 + 4 * i)
+jobs = random_lowres_jobs(rng, N, size[0], size[1], abi.ME_JOB, fenc_plane=4, ref_planes=(0, 8))
+want = O.me_batch(low, tabs, jobs, nthreads=16)
+gj = jobs.copy()
+gj["fenc_plane"] += 8
+gj["ref_plane"] += 8
+report("me_batch lowres", ctx.me_batch(gj), want, jobs)
+
+reqs = np.zeros(4 * N, abi.COST_REQ)
+for r in reqs:
+    w, h = abi.PARTS[int(rng.integers(0, 25))]
+    r["fenc_plane"], r["ref_plane"] = int(rng.choice([1, 4])), int(rng.choice([0, 2, 3, 4]))
+    r["pu_x"], r["pu_y"] = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+    r["pu_w"], r["pu_h"], r["metric"] = w, h, int(rng.integers(0, 2))
+    r["qmv_x"], r["qmv_y"] = int(rng.integers(-200, 200)), int(rng.integers(-200, 200))
+report("cost_batch", ctx.cost_batch(reqs), O.cost_batch(pl, reqs, nthreads=16), reqs)
+
+br = random_bidir_reqs(rng, 2 * N, W, H, abi.BIDIR_REQ, abi.PARTS, planes=(1, 0, 2, 4))
+report("bidir_cost_batch", ctx.bidir_cost_batch(br), O.bidir_cost_batch(pl, br), br)
+ctx.close()
+print("TOTAL MISMATCHES", bad_total)
+sys.exit(1 if bad_total else 0)
