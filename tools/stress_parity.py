@@ -81,6 +81,35 @@ report("cost_batch", ctx.cost_batch(reqs), O.cost_batch(pl, reqs, nthreads=16), 
 
 br = random_bidir_reqs(rng, 2 * N, W, H, abi.BIDIR_REQ, abi.PARTS, planes=(1, 0, 2, 4))
 report("bidir_cost_batch", ctx.bidir_cost_batch(br), O.bidir_cost_batch(pl, br), br)
+# CTU full search: random windows (every width / height up to 132), predictors and QPs; natural, flat, noise
+from concurrent.futures import ThreadPoolExecutor
+nctu = max(50, N // 400)
+cj = np.zeros(nctu, lib.CTU_JOB)
+for j in cj:
+    nx, ny = int(rng.integers(1, 133)), int(rng.integers(1, 133))
+    if rng.integers(3) == 0:
+        nx, ny = 129, 129
+    j["fenc_plane"], j["ref_plane"] = int(rng.choice([1, 4, 3])), int(rng.choice([0, 2, 3, 4]))
+    j["ctu_x"], j["ctu_y"] = 64 * int(rng.integers(1, W // 64 - 1)), 64 * int(rng.integers(1, H // 64 - 1))
+    lox, loy = -int(rng.integers(0, min(nx, 65))), -int(rng.integers(0, min(ny, 65)))
+    lox, loy = max(lox, -(nx - 1)), max(loy, -(ny - 1))
+    lox, loy = max(lox, 64 - (nx - 1)) if nx - 1 + lox > 64 else lox, max(loy, 64 - (ny - 1)) if ny - 1 + loy > 64 else loy
+    j["mvmin_x"], j["mvmin_y"], j["mvmax_x"], j["mvmax_y"] = lox, loy, lox + nx - 1, loy + ny - 1
+    j["qmvp_x"], j["qmvp_y"] = int(rng.integers(-300, 300)), int(rng.integers(-300, 300))
+    j["qp"] = int(rng.integers(0, 52))
+got = ctx.fullsearch(cj)
+
+
+def one(k):
+    j = cj[k]
+    return O.ctu_fullsearch(pl[int(j["fenc_plane"])], pl[int(j["ref_plane"])], tabs[int(j["qp"])], int(j["ctu_x"]), int(j["ctu_y"]),
+                            (int(j["mvmin_x"]), int(j["mvmin_y"])), (int(j["mvmax_x"]), int(j["mvmax_y"])),
+                            (int(j["qmvp_x"]), int(j["qmvp_y"])))
+
+
+with ThreadPoolExecutor(16) as ex:
+    want = np.stack(list(ex.map(one, range(nctu))))
+report("fullsearch (CTUs x 85 PUs)", got.reshape(-1), want.reshape(-1).view(got.dtype), np.repeat(cj, 85))
 ctx.close()
 print("TOTAL MISMATCHES", bad_total)
 sys.exit(1 if bad_total else 0)
