@@ -87,6 +87,14 @@ typedef void (*x265_hip_filter_hps_t)(uint8_t *src, intptr_t srcStride, int16_t 
                                       int isRowExt);
 typedef void (*x265_hip_filter_sp_t)(int16_t *src, intptr_t srcStride, uint8_t *dst, intptr_t dstStride, int coeffIdx);
 
+/* primitives.h:134, 154, 157-158 */
+typedef void (*x265_hip_pixelavg_pp_t)(uint8_t *dst, intptr_t dstride, uint8_t *src0, intptr_t sstride0, uint8_t *src1,
+                                       intptr_t sstride1, int weight);
+typedef void (*x265_hip_weightp_pp_t)(uint8_t *src, uint8_t *dst, intptr_t srcStride, intptr_t dstStride, int width,
+                                      int height, int w0, int round, int shift, int offset);
+typedef void (*x265_hip_downscale_t)(uint8_t *src0, uint8_t *dstf, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc,
+                                     intptr_t src_stride, intptr_t dst_stride, int width, int height);
+
 /* the slice of EncoderPrimitives this library replaces; member names are the reference's */
 typedef struct x265_hip_primitives
 {
@@ -98,6 +106,10 @@ typedef struct x265_hip_primitives
     x265_hip_filter_hps_t  luma_hps[X265_HIP_NUM_LUMA_PARTITIONS]; /* primitives.h:222; C: ipfilter.cpp:117-160 */
     x265_hip_filter_pp_t   luma_vpp[X265_HIP_NUM_LUMA_PARTITIONS]; /* primitives.h:223; C: ipfilter.cpp:162-201 */
     x265_hip_filter_sp_t   luma_vsp[X265_HIP_NUM_LUMA_PARTITIONS]; /* primitives.h:225; C: ipfilter.cpp:241-282 */
+    /* the steps either side of the path */
+    x265_hip_pixelavg_pp_t pixelavg_pp[X265_HIP_NUM_LUMA_PARTITIONS]; /* primitives.h:234; C: pixel.cpp:546-560 */
+    x265_hip_weightp_pp_t  weight_pp;                                 /* primitives.h:232; C: pixel.cpp:510-529 */
+    x265_hip_downscale_t   frame_init_lowres_core;                    /* primitives.h:257; C: pixel.cpp:595-618 */
 } x265_hip_primitives;
 
 /* Replaces the assignments Setup_C_PixelPrimitives / Setup_C_IPFilterPrimitives make for these

@@ -116,6 +116,19 @@ class Checker:
         self._f("luma_copy_pp")(C.c_int(part), _ptr(dst, doff), C.c_ssize_t(dstride), _ptr(src, soff),
                                 C.c_ssize_t(sstride))
 
+    def pixelavg_pp(self, part, dst, doff, dstride, s0, o0, ss0, s1, o1, ss1):
+        self._f("pixelavg_pp")(C.c_int(part), _ptr(dst, doff), C.c_ssize_t(dstride), _ptr(s0, o0), C.c_ssize_t(ss0),
+                               _ptr(s1, o1), C.c_ssize_t(ss1))
+
+    def weight_pp(self, src, soff, dst, doff, sstride, dstride, width, height, w0, rnd, shift, offset):
+        self._f("weight_pp")(_ptr(src, soff), _ptr(dst, doff), C.c_ssize_t(sstride), C.c_ssize_t(dstride), C.c_int(width),
+                             C.c_int(height), C.c_int(w0), C.c_int(rnd), C.c_int(shift), C.c_int(offset))
+
+    def frame_init_lowres(self, src, soff, dsts, doff, sstride, dstride, width, height):
+        self._f("frame_init_lowres")(_ptr(src, soff), _ptr(dsts[0], doff), _ptr(dsts[1], doff), _ptr(dsts[2], doff),
+                                     _ptr(dsts[3], doff), C.c_ssize_t(sstride), C.c_ssize_t(dstride), C.c_int(width),
+                                     C.c_int(height))
+
     def partition_from_sizes(self, w, h):
         return self._f("partition_from_sizes", C.c_int)(C.c_int(w), C.c_int(h))
 

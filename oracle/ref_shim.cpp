@@ -249,6 +249,13 @@ void x265r_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *re
     }
 }
 
+void x265r_pixelavg_pp(int part, uint8_t *dst, intptr_t dstride, const uint8_t *src0, intptr_t sstride0,
+                       const uint8_t *src1, intptr_t sstride1)
+{
+    init();
+    g_c.pixelavg_pp[part](dst, dstride, (pixel *)src0, sstride0, (pixel *)src1, sstride1, 32);
+}
+
 void x265r_weight_pp(const uint8_t *src, uint8_t *dst, intptr_t sstride, intptr_t dstride, int width, int height,
                      int w0, int round, int shift, int offset)
 {

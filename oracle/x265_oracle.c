@@ -1114,6 +1114,16 @@ void x265o_extend_pic_border(uint8_t *pic, intptr_t stride, int width, int heigh
         memcpy(bot + (y + 1) * stride, bot, stride);
 }
 
+/* ref: pixelavg_pp<lx, ly>, common/pixel.cpp:546-560 (the weight argument is unused there) */
+void x265o_pixelavg_pp(int part, uint8_t *dst, intptr_t dstride, const uint8_t *src0, intptr_t sstride0,
+                       const uint8_t *src1, intptr_t sstride1)
+{
+    int w = k_part_w[part], h = k_part_h[part];
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            dst[y * dstride + x] = (uint8_t)((src0[y * sstride0 + x] + src1[y * sstride1 + x] + 1) >> 1);
+}
+
 /* ref: weight_pp_c, common/pixel.cpp:510-529 (8-bit: IF_INTERNAL_PREC - X265_DEPTH = 6) */
 void x265o_weight_pp(const uint8_t *src, uint8_t *dst, intptr_t sstride, intptr_t dstride, int width, int height,
                      int w0, int round, int shift, int offset)

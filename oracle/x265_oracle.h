@@ -123,6 +123,8 @@ void x265o_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *re
 void x265o_frame_init_lowres(const uint8_t *src0, uint8_t *dst0, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc,
                              intptr_t src_stride, intptr_t dst_stride, int width, int height);
 void x265o_extend_pic_border(uint8_t *pic, intptr_t stride, int width, int height, int marginX, int marginY);
+void x265o_pixelavg_pp(int part, uint8_t *dst, intptr_t dstride, const uint8_t *src0, intptr_t sstride0,
+                       const uint8_t *src1, intptr_t sstride1);
 /* weight_pp (pixel.cpp:510-529): the weighted copy of a reference plane, MotionReference::applyWeight's kernel */
 void x265o_weight_pp(const uint8_t *src, uint8_t *dst, intptr_t sstride, intptr_t dstride, int width, int height,
                      int w0, int round, int shift, int offset);

@@ -42,7 +42,11 @@ void Setup_HIP_Primitives(EncoderPrimitives &p, x265_param *param, int device)
         p.luma_hps[i] = (filter_hps_t)t.luma_hps[i];
         p.luma_vpp[i] = (filter_pp_t)t.luma_vpp[i];
         p.luma_vsp[i] = (filter_sp_t)t.luma_vsp[i];
+        p.pixelavg_pp[i] = (pixelavg_pp_t)t.pixelavg_pp[i];
     }
+    /* the plane producers either side of the path (primitives.h:232, 257) */
+    p.weight_pp = (weightp_pp_t)t.weight_pp;
+    p.frame_init_lowres_core = (downscale_t)t.frame_init_lowres_core;
 }
 }
 

@@ -248,3 +248,35 @@ def test_bidir_cost_batch(gpu_ctx, oracle, small_seq, n):
     want = oracle.bidir_cost_batch(_planes(small_seq), reqs)
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, f"request {bad[0]}: {reqs[bad[0]]} got {got[bad[0]]} want {want[bad[0]]}"
+
+
+def test_primitive_table_plane_entries(oracle):
+    """pixelavg_pp[25], weight_pp and frame_init_lowres_core of the function-pointer table (host pointers, odd
+    strides and offsets, widths that are not multiples of four): whole destination buffers compared, so nothing
+    outside the block may be written"""
+    import ctypes as C
+    from x265_amd import lib
+    t = lib.setup_primitives(0)
+    rng = np.random.default_rng(22)
+    a, b = rng.integers(0, 256, 200 * 200, dtype=np.uint8), rng.integers(0, 256, 200 * 200, dtype=np.uint8)
+
+    def addr(x, off=0):
+        return C.c_void_p(x.ctypes.data + off)
+
+    for part in range(25):
+        d1, d2 = np.full(200 * 200, 0x5A, np.uint8), np.full(200 * 200, 0x5A, np.uint8)
+        t.pixelavg_pp[part](addr(d1, 3), 71, addr(a, 5), 83, addr(b, 9), 64, 32)
+        oracle.pixelavg_pp(part, d2, 3, 71, a, 5, 83, b, 9, 64)
+        assert np.array_equal(d1, d2), part
+    for (w, h, w0, rnd, sh, off) in ((64, 48, 70, 2048, 12, -3), (16, 16, 37, 1024, 11, 10), (128, 33, 1, 0, 6, 0), (30, 5, 90, 32, 6, 4)):
+        d1, d2 = np.full(200 * 200, 0x5A, np.uint8), np.full(200 * 200, 0x5A, np.uint8)
+        t.weight_pp(addr(a, 7), addr(d1, 11), 150, 160, w, h, w0, rnd, sh, off)
+        oracle.weight_pp(a, 7, d2, 11, 150, 160, w, h, w0, rnd, sh, off)
+        assert np.array_equal(d1, d2), (w, h)
+    for (w, h) in ((48, 40), (17, 9), (80, 24), (4, 4)):
+        o1 = [np.full(200 * 200, 0x5A, np.uint8) for _ in range(4)]
+        o2 = [np.full(200 * 200, 0x5A, np.uint8) for _ in range(4)]
+        t.frame_init_lowres_core(addr(a, 3), addr(o1[0], 5), addr(o1[1], 5), addr(o1[2], 5), addr(o1[3], 5), 190, 97, w, h)
+        oracle.frame_init_lowres(a, 3, o2, 5, 190, 97, w, h)
+        for k, (x, y) in enumerate(zip(o1, o2)):
+            assert np.array_equal(x, y), (w, h, k)

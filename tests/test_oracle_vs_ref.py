@@ -99,3 +99,26 @@ def test_bidir_cost(oracle, ref, small_seq):
     a, b = oracle.bidir_cost_batch(planes, reqs), ref.bidir_cost_batch(planes, reqs)
     bad = np.nonzero(a != b)[0]
     assert len(bad) == 0, (reqs[bad[0]], a[bad[0]], b[bad[0]])
+
+
+def test_pixelavg_weight_lowres_primitives(oracle, ref):
+    """pixelavg_pp[25], weight_pp and frame_init_lowres_core called the way the function-pointer table is"""
+    rng = np.random.default_rng(21)
+    a, b = rng.integers(0, 256, 200 * 200, dtype=np.uint8), rng.integers(0, 256, 200 * 200, dtype=np.uint8)
+    for part in range(25):
+        d1, d2 = np.full(200 * 200, 0x5A, np.uint8), np.full(200 * 200, 0x5A, np.uint8)
+        oracle.pixelavg_pp(part, d1, 3, 71, a, 5, 83, b, 9, 64)
+        ref.pixelavg_pp(part, d2, 3, 71, a, 5, 83, b, 9, 64)
+        assert np.array_equal(d1, d2), part
+    for (w, h, w0, rnd, sh, off) in ((64, 48, 70, 2048, 12, -3), (16, 16, 37, 1024, 11, 10), (128, 33, 1, 0, 6, 0)):
+        d1, d2 = np.full(200 * 200, 0x5A, np.uint8), np.full(200 * 200, 0x5A, np.uint8)
+        oracle.weight_pp(a, 7, d1, 11, 150, 160, w, h, w0, rnd, sh, off)
+        ref.weight_pp(a, 7, d2, 11, 150, 160, w, h, w0, rnd, sh, off)
+        assert np.array_equal(d1, d2), (w, h)
+    for (w, h) in ((48, 40), (17, 9), (80, 24)):
+        o1 = [np.full(200 * 200, 0x5A, np.uint8) for _ in range(4)]
+        o2 = [np.full(200 * 200, 0x5A, np.uint8) for _ in range(4)]
+        oracle.frame_init_lowres(a, 3, o1, 5, 190, 97, w, h)
+        ref.frame_init_lowres(a, 3, o2, 5, 190, 97, w, h)
+        for x, y in zip(o1, o2):
+            assert np.array_equal(x, y), (w, h)

@@ -926,9 +926,139 @@ void t_vsp(int16_t *src, intptr_t ss, uint8_t *dst, intptr_t ds, int coeff)
         prim_fatal("luma_vsp");
 }
 
+// rows of `rowbytes` from host memory into the pinned mirror at `pitch`, then to the device
+int stage_rows(x265_hip_ctx *c, Buf &b, size_t off, const uint8_t *src, long sstride, int rowbytes, int rows, int pitch)
+{
+    for (int y = 0; y < rows; y++)
+        memcpy((uint8_t *)b.h + off + (size_t)y * pitch, src + (long)y * sstride, rowbytes);
+    HIP_TRY(hipMemcpyAsync((uint8_t *)b.d + off, (uint8_t *)b.h + off, (size_t)rows * pitch, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int prim_avg(int part, uint8_t *dst, intptr_t ds, const uint8_t *s0, intptr_t ss0, const uint8_t *s1, intptr_t ss1)
+{
+    x265_hip_ctx *c = g_prim_ctx;
+    if (!c)
+        return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
+    const int w = k_part_w[part], h = k_part_h[part];
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    const size_t blk = (size_t)w * h;
+    if ((r = ensure(c, c->prim_a, 2 * blk + 64)) || (r = ensure(c, c->prim_b, blk + 64)) ||
+        (r = stage_rows(c, c->prim_a, 0, s0, ss0, w, h, w)) || (r = stage_rows(c, c->prim_a, blk, s1, ss1, w, h, w)))
+        return r;
+    PrimAvgArgs a = { (const uint8_t *)c->prim_a.d, (const uint8_t *)c->prim_a.d + blk, (uint8_t *)c->prim_b.d, w, w, w, w, h };
+    launch_prim_avg(a, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->prim_b.h, c->prim_b.d, blk, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int y = 0; y < h; y++)
+        memcpy(dst + (long)y * ds, (uint8_t *)c->prim_b.h + (size_t)y * w, w);
+    return 0;
+}
+
+int prim_weight(const uint8_t *src, uint8_t *dst, intptr_t ss, intptr_t ds, int width, int height, int w0, int round, int shift,
+                int offset)
+{
+    x265_hip_ctx *c = g_prim_ctx;
+    if (!c)
+        return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
+    if (width <= 0 || height <= 0)
+        return 0;
+    const int pitch = (width + 3) & ~3;
+    const size_t blk = (size_t)pitch * height;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = ensure(c, c->prim_a, blk + 64)) || (r = ensure(c, c->prim_b, blk + 64)) ||
+        (r = stage_rows(c, c->prim_a, 0, src, ss, width, height, pitch)))
+        return r;
+    PlaneBorderArgs a;
+    a.src = (const uint8_t *)c->prim_a.d;
+    a.dst = (uint8_t *)c->prim_b.d;
+    a.stride = pitch;
+    a.width = width;
+    a.height = height;
+    a.margin_x = a.margin_y = 0;
+    a.weighted = 1;
+    a.w0 = w0;
+    a.round = round;
+    a.shift = shift;
+    a.offset = offset;
+    launch_plane_border(a, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->prim_b.h, c->prim_b.d, blk, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int y = 0; y < height; y++)
+        memcpy(dst + (long)y * ds, (uint8_t *)c->prim_b.h + (size_t)y * pitch, width);
+    return 0;
+}
+
+int prim_lowres(const uint8_t *src0, uint8_t *const dst[4], intptr_t ss, intptr_t ds, int width, int height)
+{
+    x265_hip_ctx *c = g_prim_ctx;
+    if (!c)
+        return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
+    if (width <= 0 || height <= 0)
+        return 0;
+    // the reference reads 2 height + 1 rows of 2 width + 1 samples; the kernel's dword loads may run up to
+    // seven bytes further inside the padded staging rows
+    const int srows = 2 * height + 1, scols = 2 * width + 1, spitch = (scols + 8 + 3) & ~3;
+    const int dpitch = (width + 3) & ~3;
+    const size_t sblk = (size_t)spitch * srows, dblk = (size_t)dpitch * height;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = ensure(c, c->prim_a, sblk + 64)) || (r = ensure(c, c->prim_b, 4 * dblk + 64)))
+        return r;
+    memset(c->prim_a.h, 0, sblk);
+    if ((r = stage_rows(c, c->prim_a, 0, src0, ss, scols, srows, spitch)))
+        return r;
+    LowresArgs a;
+    a.src = (const uint8_t *)c->prim_a.d;
+    a.src_stride = spitch;
+    a.dst_stride = dpitch;
+    a.width = width;
+    a.lines = height;
+    a.margin_x = a.margin_y = 0;
+    for (int k = 0; k < 4; k++)
+        a.dst[k] = (uint8_t *)c->prim_b.d + k * dblk;
+    launch_lowres_init(a, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->prim_b.h, c->prim_b.d, 4 * dblk, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 4; k++)
+        for (int y = 0; y < height; y++)
+            memcpy(dst[k] + (long)y * ds, (uint8_t *)c->prim_b.h + k * dblk + (size_t)y * dpitch, width);
+    return 0;
+}
+
+template <int P>
+void t_avg(uint8_t *dst, intptr_t ds, uint8_t *s0, intptr_t ss0, uint8_t *s1, intptr_t ss1, int)
+{
+    if (prim_avg(P, dst, ds, s0, ss0, s1, ss1))
+        prim_fatal("pixelavg_pp");
+}
+
+void t_weight(uint8_t *src, uint8_t *dst, intptr_t ss, intptr_t ds, int width, int height, int w0, int round, int shift, int offset)
+{
+    if (prim_weight(src, dst, ss, ds, width, height, w0, round, shift, offset))
+        prim_fatal("weight_pp");
+}
+
+void t_lowres(uint8_t *src0, uint8_t *dstf, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc, intptr_t ss, intptr_t ds, int width,
+              int height)
+{
+    uint8_t *const dst[4] = { dstf, dsth, dstv, dstc };
+    if (prim_lowres(src0, dst, ss, ds, width, height))
+        prim_fatal("frame_init_lowres_core");
+}
+
 template <int P>
 void fill(x265_hip_primitives *t)
 {
+    t->pixelavg_pp[P] = t_avg<P>;
     t->sad[P] = t_sad<P>;
     t->sad_x3[P] = t_sad_x3<P>;
     t->sad_x4[P] = t_sad_x4<P>;
@@ -959,6 +1089,8 @@ int x265_hip_setup_primitives(x265_hip_primitives *table, int device)
         g_prim_ctx = c;
     }
     fill<0>(table);
+    table->weight_pp = t_weight;
+    table->frame_init_lowres_core = t_lowres;
     return X265_HIP_OK;
 }
 

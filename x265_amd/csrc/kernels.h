@@ -48,6 +48,14 @@ struct PlaneBorderArgs
 
 void launch_lowres_init(const LowresArgs &a, hipStream_t st);
 void launch_plane_border(const PlaneBorderArgs &a, hipStream_t st);
+struct PrimAvgArgs
+{
+    const uint8_t *src0, *src1;
+    uint8_t *dst;
+    int sstride0, sstride1, dstride, w, h;
+};
+
+void launch_prim_avg(const PrimAvgArgs &a, hipStream_t st);
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st);
 void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, hipStream_t st);
 void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out, hipStream_t st);

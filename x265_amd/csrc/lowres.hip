@@ -113,7 +113,7 @@ void launch_plane_border(const PlaneBorderArgs &a, hipStream_t st)
 void launch_lowres_init(const LowresArgs &a, hipStream_t st)
 {
     const int padw = a.width + 2 * a.margin_x, padh = a.lines + 2 * a.margin_y;
-    hipLaunchKernelGGL(lowres_init_kernel, dim3((padw / 4 + 255) / 256, padh), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lowres_init_kernel, dim3(((padw + 3) / 4 + 255) / 256, padh), dim3(256), 0, st, a);
 }
 
 } // namespace x265hip

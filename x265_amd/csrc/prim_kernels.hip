@@ -77,6 +77,21 @@ void launch_prim_cmp(const PrimCmpArgs &a, int32_t *out, hipStream_t st)
     hipLaunchKernelGGL(prim_cmp_kernel, dim3(1), dim3(64), 0, st, a, out);
 }
 
+// pixelavg_pp on raw device pointers (reference common/pixel.cpp:546-560), one thread per sample
+__global__ __launch_bounds__(256) void prim_avg_kernel(PrimAvgArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.w * a.h)
+        return;
+    const int y = idx / a.w, x = idx - y * a.w;
+    a.dst[(long)y * a.dstride + x] = (uint8_t)((a.src0[(long)y * a.sstride0 + x] + a.src1[(long)y * a.sstride1 + x] + 1) >> 1);
+}
+
+void launch_prim_avg(const PrimAvgArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(prim_avg_kernel, dim3((a.w * a.h + 255) / 256), dim3(256), 0, st, a);
+}
+
 void launch_prim_filter(const PrimFilterArgs &a, hipStream_t st)
 {
     const int total = a.w * a.rows;

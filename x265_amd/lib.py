@@ -72,11 +72,15 @@ class Primitives(C.Structure):
     _x3 = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p)
     _x4 = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p)
     _pp = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int)
+    _avg = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int)
+    _wpp = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
+    _down = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int)
     _hps = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int)
     _fields_ = [
         ("sad", _cmp * NUM_PARTS), ("sad_x3", _x3 * NUM_PARTS), ("sad_x4", _x4 * NUM_PARTS),
         ("satd", _cmp * NUM_PARTS), ("luma_hpp", _pp * NUM_PARTS), ("luma_hps", _hps * NUM_PARTS),
         ("luma_vpp", _pp * NUM_PARTS), ("luma_vsp", _pp * NUM_PARTS),
+        ("pixelavg_pp", _avg * NUM_PARTS), ("weight_pp", _wpp), ("frame_init_lowres_core", _down),
     ]
 
 
