@@ -63,6 +63,8 @@ struct x265_hip_ctx
     DeviceTables host_tabs;
     DeviceTables *dev_tabs = nullptr;
     bool tabs_dirty = true;
+    uint32_t *batch_counter = nullptr; // batch counters of the cost kernels (two sets, see launch_cost)
+    int batch_parity = 0;
     void *owned_plane[X265_HIP_MAX_PLANES] = {};
     size_t plane_bytes[X265_HIP_MAX_PLANES] = {};
     int plane_origin[X265_HIP_MAX_PLANES] = {};
@@ -151,14 +153,18 @@ int x265_hip_ctx_create(int device, x265_hip_ctx **out)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess)
         e = hipMalloc((void **)&c->dev_tabs, sizeof(DeviceTables));
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&c->batch_counter, X265HIP_COST_COUNTER_BYTES);
+    if (e == hipSuccess)
+        e = hipMemset(c->batch_counter, 0, X265HIP_COST_COUNTER_BYTES);
     if (e != hipSuccess)
     {
-        delete c;
+        x265_hip_ctx_destroy(c);
         return fail(X265_HIP_ERUNTIME, "context setup: %s", hipGetErrorString(e));
     }
     if (fullsearch2_setup() != 0)
     {
-        delete c;
+        x265_hip_ctx_destroy(c);
         return fail(X265_HIP_ERUNTIME, "fullsearch kernel attribute setup failed");
     }
     *out = c;
@@ -188,6 +194,8 @@ void x265_hip_ctx_destroy(x265_hip_ctx *c)
     }
     if (c->dev_tabs)
         (void)hipFree(c->dev_tabs);
+    if (c->batch_counter)
+        (void)hipFree(c->batch_counter);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
@@ -576,7 +584,7 @@ int x265_hip_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void 
     int r = push_tabs(c);
     if (r)
         return r;
-    launch_cost(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, c->stream);
+    launch_cost(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream);
     HIP_TRY(hipGetLastError());
     return X265_HIP_OK;
 }
@@ -603,7 +611,7 @@ int x265_hip_cost_batch(x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n, i
         return r;
     memcpy(c->in.h, reqs, (size_t)n * sizeof(*reqs));
     HIP_TRY(hipMemcpyAsync(c->in.d, c->in.h, (size_t)n * sizeof(*reqs), hipMemcpyHostToDevice, c->stream));
-    launch_cost(c->dev_tabs, (const x265_hip_cost_req *)c->in.d, n, (int32_t *)c->out.d, c->stream);
+    launch_cost(c->dev_tabs, (const x265_hip_cost_req *)c->in.d, n, (int32_t *)c->out.d, c->batch_counter, c->batch_parity ^= 1, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -620,7 +628,7 @@ int x265_hip_bidir_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n,
     int r = push_tabs(c);
     if (r)
         return r;
-    launch_bidir_cost(c->dev_tabs, (const x265_hip_bidir_req *)d_reqs, n, (int32_t *)d_costs, c->stream);
+    launch_bidir_cost(c->dev_tabs, (const x265_hip_bidir_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream);
     HIP_TRY(hipGetLastError());
     return X265_HIP_OK;
 }
@@ -646,7 +654,7 @@ int x265_hip_bidir_cost_batch(x265_hip_ctx *c, const x265_hip_bidir_req *reqs, i
         (r = ensure(c, c->out, (size_t)n * sizeof(int32_t))))
         return r;
     HIP_TRY(hipMemcpyAsync(c->in.d, reqs, (size_t)n * sizeof(*reqs), hipMemcpyHostToDevice, c->stream));
-    launch_bidir_cost(c->dev_tabs, (const x265_hip_bidir_req *)c->in.d, n, (int32_t *)c->out.d, c->stream);
+    launch_bidir_cost(c->dev_tabs, (const x265_hip_bidir_req *)c->in.d, n, (int32_t *)c->out.d, c->batch_counter, c->batch_parity ^= 1, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -57,8 +57,13 @@ struct PrimAvgArgs
 
 void launch_prim_avg(const PrimAvgArgs &a, hipStream_t st);
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st);
-void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, hipStream_t st);
-void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out, hipStream_t st);
+// `counters`: X265HIP_COST_COUNTER_BYTES of zeroed device memory owned by the context (two alternating sets of
+// batch counters); `parity` flips with every launch that shares them, and such launches are ordered on one stream
+#define X265HIP_COST_COUNTER_BYTES (2 * 64 * 64)
+void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, uint32_t *counters, int parity,
+                 hipStream_t st);
+void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out, uint32_t *counters, int parity,
+                       hipStream_t st);
 void launch_prim_cmp(const PrimCmpArgs &a, int32_t *out, hipStream_t st);
 void launch_prim_filter(const PrimFilterArgs &a, hipStream_t st);
 void launch_fullsearch2(const DeviceTables *tabs, const x265_hip_ctu_job *jobs, int n, x265_hip_me_result *out,

@@ -1149,9 +1149,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void me
     motion_estimate(wv, j, &out[id]);
 }
 
-// Cost requests in batches of 32 per wave; a wave walks batches wave, wave + nwaves, ... and fetches the
-// next batch's request records while it computes the current one (the plane directory sits in LDS), so the
-// only memory latency in front of a batch's arithmetic is that of its pixel loads.
+// Cost requests in batches of 32 per wave.  Batches differ sevenfold in work when block sizes are mixed, so a
+// fixed stride leaves SIMDs idle at the end; instead the batches are dealt round-robin to up to COST_PARTS
+// parts (so a list sorted by size loads every part alike), part p is served by the blocks p, p + parts, ...,
+// and their waves take the part's batches in order from its counter in device memory (one counter for all
+// waves would serialise: about 12 ns per atomic on one address).  A wave fetches
+// the next batch's request records while it computes the current one (the plane directory sits in LDS), so
+// the only memory latency in front of a batch's arithmetic is that of its pixel loads.  Two sets of counters
+// alternate between launches: a launch counts in set `parity` and clears the other one for its successor.
+// Every wave leaves the loop as soon as its part's counter passes the part's last batch.
 // Work items are (request, strip) pairs dealt round-robin to the 64 lanes, a strip being 4 pixels wide and 8
 // tall (4 tall for block heights that are not multiples of 8), so requests of different sizes in one batch do
 // not wait for each other: a prefix sum of the item counts sits in LDS and a lane finds its request by binary
@@ -1160,6 +1166,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void me
 // is reused); partial sums meet in LDS atomics.
 #define COST_BATCH 32
 #define COST_MAX_BLOCKS (256 * 6)
+#define COST_PARTS 64 // counters are 64 bytes apart
 
 struct CostLds
 {
@@ -1196,7 +1203,7 @@ __device__ __forceinline__ int req_qy1(const x265_hip_bidir_req &r) { return r.q
 
 // BIDIR: requests are x265_hip_bidir_req; the block is compared with the average of two predictions
 template <bool BIDIR, typename Req>
-__device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *reqs, int n, int32_t *out)
+__device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *reqs, int n, int32_t *out, uint32_t *counters, int parity)
 {
     __shared__ CostLds lds[4];
     __shared__ PlaneDesc planes[X265_HIP_MAX_PLANES];
@@ -1207,14 +1214,24 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
 
     CostLds &L = lds[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
-    const int nbatch = (n + COST_BATCH - 1) / COST_BATCH, nwaves = gridDim.x * 4;
-    int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nbatch = (n + COST_BATCH - 1) / COST_BATCH;
+    const int parts = min((int)gridDim.x, COST_PARTS), part = blockIdx.x % parts;
+    const int nwaves = 4 * (((int)gridDim.x - part + parts - 1) / parts); // waves serving this part
+    const int hi = (nbatch - part + parts - 1) / parts; // batches of this part: part + j * parts, j < hi
+    uint32_t *const counter = counters + (parity * COST_PARTS + part) * 16;
+    if (blockIdx.x == 0 && threadIdx.x < COST_PARTS)
+        counters[((parity ^ 1) * COST_PARTS + threadIdx.x) * 16] = 0;
+    int b = (blockIdx.x / parts) * 4 + (threadIdx.x >> 6);
     Req cur = {};
-    if (lane < COST_BATCH && b * COST_BATCH + lane < n)
-        cur = reqs[b * COST_BATCH + lane];
-    for (; b < nbatch; b += nwaves)
+    if (lane < COST_BATCH && (long)(part + b * parts) * COST_BATCH + lane < n)
+        cur = reqs[(part + b * parts) * COST_BATCH + lane];
+    while (b < hi)
     {
-        const int base = b * COST_BATCH;
+        int nb = 0;
+        if (lane == 0)
+            nb = (int)atomicAdd(counter, 1u);
+        nb = nwaves + uniform(nb);
+        const int base = (part + b * parts) * COST_BATCH;
         const bool have = lane < COST_BATCH && base + lane < n;
         int ni = 0;
         if (have)
@@ -1258,8 +1275,8 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
         }
         // next batch's records: in flight during this batch's arithmetic
         {
-            const int nid = (b + nwaves) * COST_BATCH + lane;
-            if (lane < COST_BATCH && b + nwaves < nbatch && nid < n)
+            const int nid = (part + nb * parts) * COST_BATCH + lane;
+            if (lane < COST_BATCH && nb < hi && nid < n)
                 cur = reqs[nid];
         }
         wave_sync();
@@ -1330,18 +1347,20 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
         if (have)
             out[base + lane] = L.cost[lane];
         wave_sync(); // the next batch rewrites this wave's LDS record
+        b = nb;
     }
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void cost_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
-                                                                                           int32_t *out)
+                                                                                           int32_t *out, uint32_t *counters, int parity)
 {
-    cost_body<false>(tabs, reqs, n, out);
+    cost_body<false>(tabs, reqs, n, out, counters, parity);
 }
 
-__global__ __launch_bounds__(256) void bidir_cost_kernel(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out)
+__global__ __launch_bounds__(256) void bidir_cost_kernel(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out,
+                                                         uint32_t *counters, int parity)
 {
-    cost_body<true>(tabs, reqs, n, out);
+    cost_body<true>(tabs, reqs, n, out, counters, parity);
 }
 
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st)
@@ -1350,21 +1369,21 @@ void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x26
         hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, st, tabs, jobs, n, out);
 }
 
-void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out, hipStream_t st)
+void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out, uint32_t *counters, int parity, hipStream_t st)
 {
     if (n > 0)
     {
         const int blocks = ((n + COST_BATCH - 1) / COST_BATCH + 3) / 4;
-        hipLaunchKernelGGL(bidir_cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out);
+        hipLaunchKernelGGL(bidir_cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity);
     }
 }
 
-void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, hipStream_t st)
+void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, uint32_t *counters, int parity, hipStream_t st)
 {
     if (n > 0)
     {
         const int blocks = ((n + COST_BATCH - 1) / COST_BATCH + 3) / 4;
-        hipLaunchKernelGGL(cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out);
+        hipLaunchKernelGGL(cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity);
     }
 }
 
