@@ -51,7 +51,8 @@ enum
 
 /* search methods, values of the reference's X265_*_SEARCH (source/x265.h:143-147) */
 enum { X265_HIP_DIA = 0, X265_HIP_HEX = 1, X265_HIP_UMH = 2, X265_HIP_STAR = 3, X265_HIP_FULL = 4 };
-enum { X265_HIP_SAD = 0, X265_HIP_SATD = 1 };
+/* block comparisons; SA8D and SSE (the mode-decision distortions sa8d_inter / sse_pp) only in x265_hip_dist_batch */
+enum { X265_HIP_SAD = 0, X265_HIP_SATD = 1, X265_HIP_SA8D = 2, X265_HIP_SSE = 3 };
 /* OR-ed into x265_hip_me_job::method: the reference is a Lowres (ReferencePlanes::isLowres, lowres.h:42):
  * ref_plane .. ref_plane + 3 are lowresPlane[0..3] with one stride, the block must be the lookahead's 8x8 CU,
  * and sub-pel costs come from lowresQPelCost (lowres.h:73-93) along motion.cpp:556-557, 587-588, 1055-1080 */
@@ -110,6 +111,9 @@ typedef struct x265_hip_primitives
     x265_hip_pixelavg_pp_t pixelavg_pp[X265_HIP_NUM_LUMA_PARTITIONS]; /* primitives.h:234; C: pixel.cpp:546-560 */
     x265_hip_weightp_pp_t  weight_pp;                                 /* primitives.h:232; C: pixel.cpp:510-529 */
     x265_hip_downscale_t   frame_init_lowres_core;                    /* primitives.h:257; C: pixel.cpp:595-618 */
+    /* the distortions mode decision takes of a prediction */
+    x265_hip_pixelcmp_t    sa8d_inter[X265_HIP_NUM_LUMA_PARTITIONS];  /* primitives.h:200; C: pixel.cpp:290-376, 1117-1141 */
+    x265_hip_pixelcmp_t    sse_pp[X265_HIP_NUM_LUMA_PARTITIONS];      /* primitives.h:196; C: pixel.cpp:158-177, 1095 */
 } x265_hip_primitives;
 
 /* Replaces the assignments Setup_C_PixelPrimitives / Setup_C_IPFilterPrimitives make for these
@@ -196,6 +200,15 @@ typedef struct x265_hip_cost_req
 } x265_hip_cost_req;
 
 int x265_hip_cost_batch(x265_hip_ctx *ctx, const x265_hip_cost_req *reqs, int n, int32_t *costs);
+
+/* Distortion of a uni-directional luma prediction: the same request, the same predicted
+ * pixels (xPredInterLumaBlk, TComPrediction.cpp:400-433), compared with any of the four block comparisons;
+ * X265_HIP_SA8D is primitives.sa8d_inter[part] (MotionEstimate::bufSA8D, encoder/motion.h:89, motion.cpp:116;
+ * for square blocks the same functions as primitives.sa8d[sizeIdx], which inter mode decision applies to the
+ * prediction, encoder/compress.cpp:215, 265; C: common/pixel.cpp:290-376, tables at 1111-1141); X265_HIP_SSE is
+ * primitives.sse_pp[part] (pixel.cpp:158-177, 1095; TEncSearch.cpp:2651, 2780 on luma). */
+int x265_hip_dist_batch(x265_hip_ctx *ctx, const x265_hip_cost_req *reqs, int n, int32_t *costs);
+int x265_hip_dist_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs);
 
 /* Bidirectional candidate: the block against the rounded average of two uni-directional
  * luma predictions, as TEncSearch::predInterSearch measures it (source/Lib/TLibEncoder/TEncSearch.cpp:2360-2412:

@@ -147,6 +147,16 @@ def gen_lowres(R):
                         plane_crc=np.array([crc(b) for (b, _, _) in low], np.uint32), weight_cases=wcases, weight_crc=wcrc, bidir_reqs=breqs, bidir_costs=bres)
 
 
+def gen_dist(R):
+    """mode-decision distortions (sa8d_inter, sse_pp, and sad / satd beside them) of predictions on the golden pictures"""
+    from conftest import random_cost_reqs
+    planes = golden_sequence()
+    reqs = random_cost_reqs(np.random.default_rng(80), 600, planes[0].w, planes[0].h, pyoracle.COST_REQ, pyoracle.PARTS,
+                            metrics=(0, 1, 2, 2, 3, 3))
+    costs = R.cost_batch([p.as_tuple() for p in planes], reqs)
+    np.savez_compressed(os.path.join(OUT, "dist.npz"), reqs=reqs, costs=costs)
+
+
 def main():
     if not pyoracle.have_ref():
         sys.exit("oracle/_ref/libx265ref.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -156,6 +166,7 @@ def main():
     gen_bitcost(R)
     gen_me(R)
     gen_lowres(R)
+    gen_dist(R)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -84,6 +84,14 @@ class Checker:
         return self._f("satd", C.c_int)(C.c_int(part), _ptr(fenc, foff), C.c_ssize_t(fstride), _ptr(fref, roff),
                                         C.c_ssize_t(rstride))
 
+    def sa8d_inter(self, part, fenc, foff, fstride, fref, roff, rstride):
+        return self._f("sa8d_inter", C.c_int)(C.c_int(part), _ptr(fenc, foff), C.c_ssize_t(fstride), _ptr(fref, roff),
+                                              C.c_ssize_t(rstride))
+
+    def sse_pp(self, part, fenc, foff, fstride, fref, roff, rstride):
+        return self._f("sse_pp", C.c_int)(C.c_int(part), _ptr(fenc, foff), C.c_ssize_t(fstride), _ptr(fref, roff),
+                                          C.c_ssize_t(rstride))
+
     def sad_x3(self, part, fenc, foff, fref, roffs, rstride):
         res = np.zeros(3, np.int32)
         self._f("sad_x3")(C.c_int(part), _ptr(fenc, foff), _ptr(fref, roffs[0]), _ptr(fref, roffs[1]),

@@ -81,6 +81,18 @@ int x265r_satd(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *f
     return g_c.satd[part]((pixel *)fenc, fstride, (pixel *)fref, rstride);
 }
 
+int x265r_sa8d_inter(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *fref, intptr_t rstride)
+{
+    init();
+    return g_c.sa8d_inter[part]((pixel *)fenc, fstride, (pixel *)fref, rstride);
+}
+
+int x265r_sse_pp(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *fref, intptr_t rstride)
+{
+    init();
+    return g_c.sse_pp[part]((pixel *)fenc, fstride, (pixel *)fref, rstride);
+}
+
 void x265r_luma_hpp(int part, const uint8_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int coeffIdx)
 {
     init();
@@ -274,7 +286,9 @@ int x265r_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, in
     me.setSourcePlane((pixel *)fenc->origin, fenc->stride);
     me.setSourcePU(x + y * (int)fenc->stride, w, h);
     int part = partitionFromSizes(w, h);
-    return me.subpelCompare(&rp, MV(qmvx, qmvy), metric ? primitives.satd[part] : primitives.sad[part]);
+    pixelcmp_t cmp = metric == X265O_SSE ? primitives.sse_pp[part] : metric == X265O_SA8D ? primitives.sa8d_inter[part]
+                   : metric ? primitives.satd[part] : primitives.sad[part];
+    return me.subpelCompare(&rp, MV(qmvx, qmvy), cmp);
 }
 
 void x265r_cost_batch(const x265o_plane *planes, const x265o_cost_req *reqs, int n, int32_t *out, int nthreads)

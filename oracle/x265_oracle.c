@@ -119,6 +119,92 @@ int x265o_satd(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *f
 }
 
 /* ------------------------------------------------------------------------- */
+/* mode-decision distortions   ref: common/pixel.cpp:158-177 (sse), 290-376 (sa8d), 1095, 1117-1141 (tables)
+ *
+ * _sa8d_8x8 is the sum of the absolute coefficients of an 8x8 Hadamard transform of the differences; the
+ * reference runs it on two 16-bit lanes per uint32, which is exact for 8-bit input (coefficients are at most
+ * 64 * 255, a lane's eight absolute values sum to at most sqrt(8) * 64 * 255 < 65536).  Rounding: once per 8x8
+ * block (sa8d_8x8, sa8d8<>) or once per 16x16 block over its four raw sums (sa8d_16x16, sa8d16<>). */
+
+static int sa8d_8x8_raw(const uint8_t *a, intptr_t as, const uint8_t *b, intptr_t bs)
+{
+    int m[8][8];
+    for (int y = 0; y < 8; y++)
+    {
+        for (int x = 0; x < 8; x++)
+            m[y][x] = (int)a[y * as + x] - (int)b[y * bs + x];
+        for (int s = 1; s < 8; s <<= 1)
+            for (int x = 0; x < 8; x++)
+                if (!(x & s))
+                {
+                    int u = m[y][x], v = m[y][x | s];
+                    m[y][x] = u + v;
+                    m[y][x | s] = u - v;
+                }
+    }
+    int acc = 0;
+    for (int x = 0; x < 8; x++)
+    {
+        for (int s = 1; s < 8; s <<= 1)
+            for (int y = 0; y < 8; y++)
+                if (!(y & s))
+                {
+                    int u = m[y][x], v = m[y | s][x];
+                    m[y][x] = u + v;
+                    m[y | s][x] = u - v;
+                }
+        for (int y = 0; y < 8; y++)
+            acc += abs(m[y][x]);
+    }
+    return acc;
+}
+
+/* sa8d_inter[part]: the table of pixel.cpp:1117-1141 (sa8d16<> where both sides are multiples of 16, sa8d8<>
+ * where both are multiples of 8, satd for the rest) */
+int x265o_sa8d_inter(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *fref, intptr_t rstride)
+{
+    int w = k_part_w[part], h = k_part_h[part], cost = 0;
+    if (!(w & 15) && !(h & 15))
+    {
+        for (int y = 0; y < h; y += 16)
+            for (int x = 0; x < w; x += 16)
+            {
+                int sum = 0;
+                for (int k = 0; k < 4; k++)
+                {
+                    int ox = x + 8 * (k & 1), oy = y + 8 * (k >> 1);
+                    sum += sa8d_8x8_raw(fenc + oy * fstride + ox, fstride, fref + oy * rstride + ox, rstride);
+                }
+                cost += (sum + 2) >> 2;
+            }
+        return cost;
+    }
+    if (!(w & 7) && !(h & 7))
+    {
+        for (int y = 0; y < h; y += 8)
+            for (int x = 0; x < w; x += 8)
+                cost += (sa8d_8x8_raw(fenc + y * fstride + x, fstride, fref + y * rstride + x, rstride) + 2) >> 2;
+        return cost;
+    }
+    return x265o_satd(part, fenc, fstride, fref, rstride);
+}
+
+/* sse_pp[part]: ref common/pixel.cpp:158-177 */
+int x265o_sse_pp(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *fref, intptr_t rstride)
+{
+    int w = k_part_w[part], h = k_part_h[part], sum = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            int d = (int)fenc[y * fstride + x] - (int)fref[y * rstride + x];
+            sum += d * d;
+        }
+    return sum;
+}
+
+static int block_metric(int metric, int part, int w, int h, const uint8_t *f, intptr_t fs, const uint8_t *r, intptr_t rs);
+
+/* ------------------------------------------------------------------------- */
 /* 8-tap luma interpolation         ref: common/ipfilter.cpp:76-160,162-201,241-282,399-406;
  *                                       Lib/TLibCommon/TComRom.cpp:335-341; TComRom.h:117-121 */
 
@@ -338,8 +424,19 @@ static int subpel_cost(const me_ctx *c, int qx, int qy, int use_satd)
         x265o_luma_hps(c->part, p, c->stride, immed, c->w, xf, 1);
         x265o_luma_vsp(c->part, immed + 3 * c->w, c->w, buf, 64, yf);
     }
-    return use_satd ? x265o_satd(c->part, c->fenc, 64, cmp, cmpstride)
-                    : sad_wh(c->w, c->h, c->fenc, 64, cmp, cmpstride);
+    return block_metric(use_satd, c->part, c->w, c->h, c->fenc, 64, cmp, cmpstride);
+}
+
+/* the comparison subpelCompare is handed (motion.cpp:1126): 0 sad, 1 satd, 2 sa8d_inter, 3 sse_pp */
+static int block_metric(int metric, int part, int w, int h, const uint8_t *f, intptr_t fs, const uint8_t *r, intptr_t rs)
+{
+    switch (metric)
+    {
+    case X265O_SATD: return x265o_satd(part, f, fs, r, rs);
+    case X265O_SA8D: return x265o_sa8d_inter(part, f, fs, r, rs);
+    case X265O_SSE: return x265o_sse_pp(part, f, fs, r, rs);
+    default: return sad_wh(w, h, f, fs, r, rs);
+    }
 }
 
 typedef struct

@@ -93,6 +93,11 @@ void x265o_sad_x3(int part, const uint8_t *fenc, const uint8_t *r0, const uint8_
 void x265o_sad_x4(int part, const uint8_t *fenc, const uint8_t *r0, const uint8_t *r1, const uint8_t *r2,
                   const uint8_t *r3, intptr_t rstride, int32_t *res);
 int  x265o_satd(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *fref, intptr_t rstride);
+/* mode-decision distortions: sa8d_inter[part] (pixel.cpp:290-376, 1117-1141), sse_pp[part] (pixel.cpp:158-177, 1095) */
+int  x265o_sa8d_inter(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *fref, intptr_t rstride);
+int  x265o_sse_pp(int part, const uint8_t *fenc, intptr_t fstride, const uint8_t *fref, intptr_t rstride);
+/* metric codes of the cost requests */
+enum { X265O_SAD = 0, X265O_SATD = 1, X265O_SA8D = 2, X265O_SSE = 3 };
 
 void x265o_luma_hpp(int part, const uint8_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int coeffIdx);
 void x265o_luma_vpp(int part, const uint8_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int coeffIdx);

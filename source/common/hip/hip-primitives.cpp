@@ -43,6 +43,8 @@ void Setup_HIP_Primitives(EncoderPrimitives &p, x265_param *param, int device)
         p.luma_vpp[i] = (filter_pp_t)t.luma_vpp[i];
         p.luma_vsp[i] = (filter_sp_t)t.luma_vsp[i];
         p.pixelavg_pp[i] = (pixelavg_pp_t)t.pixelavg_pp[i];
+        p.sa8d_inter[i] = (pixelcmp_t)t.sa8d_inter[i];
+        p.sse_pp[i] = (pixelcmp_t)t.sse_pp[i];
     }
     /* the plane producers either side of the path (primitives.h:232, 257) */
     p.weight_pp = (weightp_pp_t)t.weight_pp;

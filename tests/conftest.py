@@ -118,3 +118,16 @@ def random_bidir_reqs(rng, n, W, H, dtype, parts, planes=(1, 0, 2)):
         for k in ("qmv0_x", "qmv0_y", "qmv1_x", "qmv1_y"):
             r[k] = int(rng.integers(-90, 90)) if rng.integers(4) else 4 * int(rng.integers(-20, 20))
     return reqs
+
+
+def random_cost_reqs(rng, n, W, H, dtype, parts, metrics=(0, 1), planes=(1, (0, 2))):
+    """blocks of every partition at random quarter-pel vectors with a metric drawn from `metrics`"""
+    reqs = np.zeros(n, dtype)
+    for r in reqs:
+        w, h = parts[int(rng.integers(0, 25))]
+        r["fenc_plane"], r["ref_plane"] = planes[0], int(rng.choice(planes[1]))
+        r["pu_x"], r["pu_y"], r["pu_w"], r["pu_h"] = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1)), w, h
+        r["metric"] = int(rng.choice(metrics))
+        r["qmv_x"] = int(rng.integers(-90, 90)) if rng.integers(4) else 4 * int(rng.integers(-20, 20))
+        r["qmv_y"] = int(rng.integers(-90, 90)) if rng.integers(4) else 4 * int(rng.integers(-20, 20))
+    return reqs

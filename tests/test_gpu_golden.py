@@ -133,6 +133,15 @@ def test_lookahead_planes_and_search_reproduce_reference_fixtures():
     ctx.close()
 
 
+def test_distortions_reproduce_reference_fixtures(gpu_ctx):
+    """dist.npz: sa8d_inter / sse_pp / satd / sad of predictions on the golden pictures (gpu_ctx holds them as planes
+    0..2), computed by the reference build"""
+    g = np.load(os.path.join(GOLD, "dist.npz"))
+    got = gpu_ctx.dist_batch(g["reqs"])
+    bad = np.nonzero(got != g["costs"])[0]
+    assert len(bad) == 0, (g["reqs"][bad[0]], got[bad[0]], g["costs"][bad[0]])
+
+
 def test_bad_arguments_are_rejected(gpu_ctx):
     from x265_amd import abi, lib
     jobs = np.zeros(1, abi.ME_JOB)
@@ -152,3 +161,10 @@ def test_bad_arguments_are_rejected(gpu_ctx):
     with pytest.raises(lib.X265HipError):
         gpu_ctx.fullsearch(cj)  # window wider than 132 positions
     assert len(gpu_ctx.me_batch(np.zeros(0, abi.ME_JOB))) == 0  # empty batch is fine
+    rq = np.zeros(1, abi.COST_REQ)
+    rq["fenc_plane"], rq["ref_plane"], rq["pu_w"], rq["pu_h"], rq["metric"] = 1, 0, 16, 16, abi.SA8D
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.cost_batch(rq)  # sa8d / sse are dist_batch's
+    rq["metric"] = 4
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.dist_batch(rq)

@@ -280,3 +280,49 @@ def test_primitive_table_plane_entries(oracle):
         oracle.frame_init_lowres(a, 3, o2, 5, 190, 97, w, h)
         for k, (x, y) in enumerate(zip(o1, o2)):
             assert np.array_equal(x, y), (w, h, k)
+
+
+def test_dist_batch_all_metrics(gpu_ctx, oracle, small_seq):
+    """x265_hip_dist_batch: sad / satd / sa8d_inter / sse_pp of predictions, every partition and fraction; lists
+    of one metric, mixed lists (sa8d blocks beside single-strip blocks inside a batch), and ragged lengths"""
+    from conftest import random_cost_reqs
+    from x265_amd import abi
+    planes = [p.as_tuple() for p in small_seq]
+    W, H = small_seq[0].w, small_seq[0].h
+    rng = np.random.default_rng(61)
+    for metrics, n in (((2,), 3000), ((3,), 1500), ((0, 1, 2, 3), 4000), ((2, 3), 33), ((2,), 1)):
+        reqs = random_cost_reqs(rng, n, W, H, abi.COST_REQ, oracle_parts(), metrics=metrics)
+        got, want = gpu_ctx.dist_batch(reqs), oracle.cost_batch(planes, reqs)
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (metrics, reqs[bad[0]], got[bad[0]], want[bad[0]])
+    # a list of 8x8 blocks only (two strips each: the batch layout without the item search), saturated differences
+    reqs = random_cost_reqs(rng, 500, W, H, abi.COST_REQ, oracle_parts(), metrics=(2,))
+    reqs["pu_w"] = reqs["pu_h"] = 8
+    reqs["pu_x"] = np.minimum(reqs["pu_x"], W - 8)
+    reqs["pu_y"] = np.minimum(reqs["pu_y"], H - 8)
+    assert np.array_equal(gpu_ctx.dist_batch(reqs), oracle.cost_batch(planes, reqs))
+
+
+def oracle_parts():
+    from oracle import pyoracle
+    return pyoracle.PARTS
+
+
+def test_primitive_table_distortions(oracle):
+    """sa8d_inter[25] and sse_pp[25] of the function-pointer table: random, flat and checkerboard content"""
+    import ctypes as C
+    from x265_amd import lib
+    t = lib.setup_primitives(0)
+    rng = np.random.default_rng(23)
+    n = 64 * 90
+    yy, xx = np.mgrid[0:90, 0:64]
+    bufs = [rng.integers(0, 256, n, dtype=np.uint8), np.zeros(n, np.uint8), np.full(n, 255, np.uint8),
+            (((xx ^ yy) & 1) * 255).astype(np.uint8).reshape(-1), (((xx >> 2) & 1) * 255).astype(np.uint8).reshape(-1)]
+    for part in range(25):
+        for _ in range(6):
+            a, b = bufs[rng.integers(5)], bufs[rng.integers(5)]
+            fo, ro = int(rng.integers(0, 16)) * 16, int(rng.integers(0, 1000))
+            for rs in (64, 71):
+                pa, pb = C.c_void_p(a.ctypes.data + fo), C.c_void_p(b.ctypes.data + ro)
+                assert t.sa8d_inter[part](pa, 64, pb, rs) == oracle.sa8d_inter(part, a, fo, 64, b, ro, rs), part
+                assert t.sse_pp[part](pa, 64, pb, rs) == oracle.sse_pp(part, a, fo, 64, b, ro, rs), part

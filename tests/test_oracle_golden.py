@@ -154,3 +154,11 @@ def test_bidir_costs_match_reference_fixtures(oracle):
     g = np.load(os.path.join(GOLD, "lowres.npz"))
     got = oracle.bidir_cost_batch([p.as_tuple() for p in golden_planes()], g["bidir_reqs"])
     assert np.array_equal(got, g["bidir_costs"])
+
+
+def test_distortions_match_reference_fixtures(oracle):
+    """dist.npz: sa8d_inter / sse_pp / satd / sad of predictions, computed by the reference build"""
+    g = np.load(os.path.join(GOLD, "dist.npz"))
+    got = oracle.cost_batch([p.as_tuple() for p in golden_planes()], g["reqs"])
+    assert set(g["reqs"]["metric"]) == {0, 1, 2, 3}
+    assert np.array_equal(got, g["costs"])

@@ -25,6 +25,8 @@ def test_pixelcmp_random(oracle, ref):
             for rs in (64, 59, 100):
                 assert oracle.sad(part, a, fo, 64, b, ro, rs) == ref.sad(part, a, fo, 64, b, ro, rs)
                 assert oracle.satd(part, a, fo, 64, b, ro, rs) == ref.satd(part, a, fo, 64, b, ro, rs)
+                assert oracle.sa8d_inter(part, a, fo, 64, b, ro, rs) == ref.sa8d_inter(part, a, fo, 64, b, ro, rs)
+                assert oracle.sse_pp(part, a, fo, 64, b, ro, rs) == ref.sse_pp(part, a, fo, 64, b, ro, rs)
                 assert np.array_equal(oracle.sad_x4(part, a, fo, b, [ro, ro + 1, ro + 2, ro + 3], rs),
                                       ref.sad_x4(part, a, fo, b, [ro, ro + 1, ro + 2, ro + 3], rs))
 
@@ -122,3 +124,34 @@ def test_pixelavg_weight_lowres_primitives(oracle, ref):
         ref.frame_init_lowres(a, 3, o2, 5, 190, 97, w, h)
         for x, y in zip(o1, o2):
             assert np.array_equal(x, y), (w, h)
+
+
+def test_sa8d_extreme_blocks(oracle, ref):
+    """patterns that put all the energy of an 8x8 difference into few Hadamard coefficients (the 16-bit lanes of the
+    reference's packed arithmetic are fullest there)"""
+    n = 64 * 80
+    yy, xx = np.mgrid[0:80, 0:64]
+    pats = [np.zeros((80, 64)), np.full((80, 64), 255), (xx & 1) * 255, (yy & 1) * 255, ((xx ^ yy) & 1) * 255,
+            ((xx >> 1) & 1) * 255, ((yy >> 2) & 1) * 255, ((xx >> 2 ^ yy >> 1) & 1) * 255]
+    pats = [p.astype(np.uint8).reshape(-1) for p in pats]
+    for part in range(25):
+        for a in pats:
+            for b in pats:
+                assert oracle.sa8d_inter(part, a, 0, 64, b, 0, 64) == ref.sa8d_inter(part, a, 0, 64, b, 0, 64)
+                assert oracle.sse_pp(part, a, 0, 64, b, 0, 64) == ref.sse_pp(part, a, 0, 64, b, 0, 64)
+
+
+def test_cost_requests_all_metrics(oracle, ref, small_seq):
+    """subpelCompare with each of the four comparisons (sad, satd, sa8d_inter, sse_pp), all partitions and fractions"""
+    rng = np.random.default_rng(33)
+    planes = [p.as_tuple() for p in small_seq]
+    W, H = small_seq[0].w, small_seq[0].h
+    reqs = np.zeros(2000, pyoracle.COST_REQ)
+    for r in reqs:
+        w, h = pyoracle.PARTS[int(rng.integers(0, 25))]
+        r["fenc_plane"], r["ref_plane"] = 1, int(rng.choice([0, 2]))
+        r["pu_x"], r["pu_y"], r["pu_w"], r["pu_h"] = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1)), w, h
+        r["qmv_x"], r["qmv_y"], r["metric"] = int(rng.integers(-90, 90)), int(rng.integers(-90, 90)), int(rng.integers(0, 4))
+    a, b = oracle.cost_batch(planes, reqs), ref.cost_batch(planes, reqs)
+    bad = np.nonzero(a != b)[0]
+    assert len(bad) == 0, (reqs[bad[0]], a[bad[0]], b[bad[0]])

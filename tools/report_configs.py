@@ -164,6 +164,16 @@ def run(w, h, tag):
         ops = synth.satd_lane_ops(sel)
         res["satd_candidates"][f"{size}x{size}"] = {"requests": len(sel), "ms": ms, "candidates_per_s": len(sel) / ms * 1e3,
                                                     "frac_of_valu_peak": ops / ms * 1e3 / LANE_PEAK}
+    # mode-decision distortions of the same predictions: x265_hip_dist_batch
+    res["dist_candidates"] = {}
+    for name, metric in (("sa8d", abi.SA8D), ("sse", abi.SSE)):
+        sel = rq.copy()
+        sel["metric"] = metric
+        d = torch.from_numpy(sel.view(np.uint8).copy()).to(dev)
+        ms = timed(ext, ctx, lambda: ctx.dist_batch_device(d.data_ptr(), len(sel), o.data_ptr()), 5)
+        ops = synth.satd_lane_ops(sel)
+        res["dist_candidates"][name] = {"requests": len(sel), "ms": ms, "candidates_per_s": len(sel) / ms * 1e3,
+                                        "frac_of_valu_peak": ops / ms * 1e3 / LANE_PEAK}
     ctx.close()
     return res
 

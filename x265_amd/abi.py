@@ -10,7 +10,7 @@ PARTS = [(4, 4), (8, 8), (8, 4), (4, 8), (16, 16), (16, 8), (8, 16), (16, 12), (
          (64, 48), (48, 64), (64, 16), (16, 64)]
 
 DIA, HEX, UMH, STAR, FULL = range(5)
-SAD, SATD = 0, 1
+SAD, SATD, SA8D, SSE = 0, 1, 2, 3
 LOWRES_REF = 0x80  # OR-ed into ME_JOB.method: the reference is a Lowres (four half-pel planes, 8x8 blocks)
 
 ME_JOB = np.dtype([

@@ -619,6 +619,49 @@ int x265_hip_cost_batch(x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n, i
     return X265_HIP_OK;
 }
 
+int x265_hip_dist_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void *d_costs)
+{
+    if (!c || n < 0 || (n && (!d_reqs || !d_costs)))
+        return fail(X265_HIP_EINVAL, "dist_batch_device: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = push_tabs(c);
+    if (r)
+        return r;
+    launch_dist(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream);
+    HIP_TRY(hipGetLastError());
+    return X265_HIP_OK;
+}
+
+int x265_hip_dist_batch(x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n, int32_t *costs)
+{
+    if (!c || n < 0 || (n && (!reqs || !costs)))
+        return fail(X265_HIP_EINVAL, "dist_batch: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++)
+    {
+        int r = check_block(c, reqs[i].fenc_plane, reqs[i].ref_plane, reqs[i].pu_w, reqs[i].pu_h, "dist_req", i);
+        if (r)
+            return r;
+        if (reqs[i].metric > X265_HIP_SSE)
+            return fail(X265_HIP_EINVAL, "dist_req[%d]: unknown metric %d", i, reqs[i].metric);
+    }
+    int r;
+    if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))) ||
+        (r = ensure(c, c->out, (size_t)n * sizeof(int32_t))))
+        return r;
+    HIP_TRY(hipMemcpyAsync(c->in.d, reqs, (size_t)n * sizeof(*reqs), hipMemcpyHostToDevice, c->stream));
+    launch_dist(c->dev_tabs, (const x265_hip_cost_req *)c->in.d, n, (int32_t *)c->out.d, c->batch_counter, c->batch_parity ^= 1, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(costs, c->out.h, (size_t)n * sizeof(int32_t));
+    return X265_HIP_OK;
+}
+
 int x265_hip_bidir_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void *d_costs)
 {
     if (!c || n < 0 || (n && (!d_reqs || !d_costs)))
@@ -891,6 +934,26 @@ int t_satd(uint8_t *fenc, intptr_t fs, uint8_t *fref, intptr_t rs)
 }
 
 template <int P>
+int t_sa8d_inter(uint8_t *fenc, intptr_t fs, uint8_t *fref, intptr_t rs)
+{
+    int32_t res[4];
+    const uint8_t *r[1] = { fref };
+    if (prim_cmp(P, X265_HIP_SA8D, fenc, fs, r, 1, rs, res))
+        prim_fatal("sa8d_inter");
+    return res[0];
+}
+
+template <int P>
+int t_sse_pp(uint8_t *fenc, intptr_t fs, uint8_t *fref, intptr_t rs)
+{
+    int32_t res[4];
+    const uint8_t *r[1] = { fref };
+    if (prim_cmp(P, X265_HIP_SSE, fenc, fs, r, 1, rs, res))
+        prim_fatal("sse_pp");
+    return res[0];
+}
+
+template <int P>
 void t_sad_x3(uint8_t *fenc, uint8_t *r0, uint8_t *r1, uint8_t *r2, intptr_t rs, int32_t *res)
 {
     const uint8_t *r[3] = { r0, r1, r2 };
@@ -1071,6 +1134,8 @@ void fill(x265_hip_primitives *t)
     t->sad_x3[P] = t_sad_x3<P>;
     t->sad_x4[P] = t_sad_x4<P>;
     t->satd[P] = t_satd<P>;
+    t->sa8d_inter[P] = t_sa8d_inter<P>;
+    t->sse_pp[P] = t_sse_pp<P>;
     t->luma_hpp[P] = t_hpp<P>;
     t->luma_hps[P] = t_hps<P>;
     t->luma_vpp[P] = t_vpp<P>;

@@ -378,6 +378,85 @@ __device__ __forceinline__ int tile_metric(const uint8_t *f, int fstride, const 
     return (int)((su & 0xffffu) + (su >> 16));
 }
 
+// ---- mode-decision distortions of an 8-row strip ---------------------------------------------------
+//
+// sa8d (reference common/pixel.cpp:290-325): sum of the absolute coefficients of the 8x8 Hadamard transform of
+// the differences.  Lanes 2j and 2j + 1 hold the left and right 4-column halves of one 8x8 block; each runs the
+// 8-point transform down its columns and the 4-point transform along its rows, the last butterfly across the
+// halves is folded into |a + b| + |a - b| = 2 max(|a|, |b|), the even lane taking vertical frequencies 0..3 and
+// the odd lane 4..7.  The return value is this lane's share of _sa8d_8x8's sum; the caller adds the shares of a
+// block (or of the four blocks of a 16x16) before the reference's rounding.  Packed 16-bit throughout:
+// coefficients before the last stage are at most 32 * 255, and a lane's sixteen maxima sum to half of 32
+// coefficients' absolute sum, at most sqrt(32) * 64 * 255 / 2 < 65536.
+// Both lanes of a pair must be active.
+template <bool F_GLOBAL>
+__device__ __forceinline__ int sa8d_strip(const uint8_t *f, int fstride, const uint32_t P[8][2], bool odd)
+{
+    auto ldf = [&](int y) { return F_GLOBAL ? ld4g(as_global(f) + y * fstride) : ld4u(f + y * fstride); };
+    s16x2 a[8], b[8];
+#pragma unroll
+    for (int y = 0; y < 8; y++)
+    {
+        const uint32_t fv = ldf(y);
+        a[y] = as_s2(__builtin_amdgcn_perm(0, fv, 0x0c010c00)) - as_s2(P[y][0]);
+        b[y] = as_s2(__builtin_amdgcn_perm(0, fv, 0x0c030c02)) - as_s2(P[y][1]);
+    }
+#pragma unroll
+    for (int s = 1; s < 8; s <<= 1)
+#pragma unroll
+        for (int y = 0; y < 8; y++)
+            if (!(y & s))
+            {
+                const s16x2 u = a[y], v = a[y | s], p = b[y], q = b[y | s];
+                a[y] = u + v;
+                a[y | s] = u - v;
+                b[y] = p + q;
+                b[y | s] = p - q;
+            }
+    // rows: (c0, c1), (c2, c3) -> the four 4-point outputs as (s.lo + s.hi, t.lo + t.hi), (s.lo - s.hi, t.lo - t.hi)
+#pragma unroll
+    for (int y = 0; y < 8; y++)
+    {
+        const uint32_t sm = as_u32(a[y] + b[y]), df = as_u32(a[y] - b[y]);
+        const s16x2 u = as_s2(__builtin_amdgcn_perm(df, sm, 0x05040100)), v = as_s2(__builtin_amdgcn_perm(df, sm, 0x07060302));
+        a[y] = u + v;
+        b[y] = u - v;
+    }
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 acc = { 0, 0 };
+    const s16x2 zero = { 0, 0 };
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+    {
+        const s16x2 keep_a = odd ? a[y + 4] : a[y], send_a = odd ? a[y] : a[y + 4];
+        const s16x2 keep_b = odd ? b[y + 4] : b[y], send_b = odd ? b[y] : b[y + 4];
+        const s16x2 oth_a = as_s2((uint32_t)__builtin_amdgcn_update_dpp(0, (int)as_u32(send_a), 0xB1, 0xf, 0xf, true)); // quad_perm 1,0,3,2
+        const s16x2 oth_b = as_s2((uint32_t)__builtin_amdgcn_update_dpp(0, (int)as_u32(send_b), 0xB1, 0xf, 0xf, true));
+        const s16x2 ma = __builtin_elementwise_max(__builtin_elementwise_max(keep_a, zero - keep_a), __builtin_elementwise_max(oth_a, zero - oth_a));
+        const s16x2 mb = __builtin_elementwise_max(__builtin_elementwise_max(keep_b, zero - keep_b), __builtin_elementwise_max(oth_b, zero - oth_b));
+        acc += __builtin_bit_cast(u16x2, ma) + __builtin_bit_cast(u16x2, mb);
+    }
+    const uint32_t su = __builtin_bit_cast(uint32_t, acc);
+    return (int)(2 * ((su & 0xffffu) + (su >> 16)));
+}
+
+// sse_pp (reference common/pixel.cpp:158-177) of NR rows x 4 columns
+template <int NR, bool F_GLOBAL>
+__device__ __forceinline__ int sse_strip(const uint8_t *f, int fstride, const uint32_t P[NR][2])
+{
+    int acc = 0;
+#pragma unroll
+    for (int y = 0; y < NR; y++)
+    {
+        const uint32_t fv = F_GLOBAL ? ld4g(as_global(f) + y * fstride) : ld4u(f + y * fstride);
+        const s16x2 d0 = as_s2(__builtin_amdgcn_perm(0, fv, 0x0c010c00)) - as_s2(P[y][0]);
+        const s16x2 d1 = as_s2(__builtin_amdgcn_perm(0, fv, 0x0c030c02)) - as_s2(P[y][1]);
+        acc = __builtin_amdgcn_sdot2(d0, d0, acc, false);
+        acc = __builtin_amdgcn_sdot2(d1, d1, acc, false);
+    }
+    return acc;
+}
+
 // ---- mvcost -----------------------------------------------------------------------------------
 
 // m_cost[v - mvp]; indices wrap inside the 65536-entry row (the reference reads outside its row

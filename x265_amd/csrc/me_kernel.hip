@@ -1173,11 +1173,11 @@ struct CostLds
     int pre[COST_BATCH + 1]; // exclusive prefix of item counts
     int cost[COST_BATCH];
     // per request, resolved once by lane k: block origins, strides,
-    // ntx | xf << 8 | yf << 10 | metric << 12 | (8-row strips) << 13
+    // ntx | xf << 8 | yf << 10 | metric << 12 | (8-row strips) << 14 | sa8d kind << 19 | units per row << 21
     const uint8_t *fenc[COST_BATCH];
     const uint8_t *ref[COST_BATCH];
     int fstride[COST_BATCH], rstride[COST_BATCH], info[COST_BATCH];
-    // bidirectional requests: the second prediction; its fraction sits in info bits 14..17
+    // bidirectional requests: the second prediction; its fraction sits in info bits 15..18
     const uint8_t *ref1[COST_BATCH];
     int rstride1[COST_BATCH];
 };
@@ -1201,11 +1201,21 @@ __device__ __forceinline__ int req_ref1(const x265_hip_bidir_req &r) { return r.
 __device__ __forceinline__ int req_qx1(const x265_hip_bidir_req &r) { return r.qmv1_x; }
 __device__ __forceinline__ int req_qy1(const x265_hip_bidir_req &r) { return r.qmv1_y; }
 
-// BIDIR: requests are x265_hip_bidir_req; the block is compared with the average of two predictions
-template <bool BIDIR, typename Req>
+// MODE_BIDIR: requests are x265_hip_bidir_req; the block is compared with the average of two predictions.
+// MODE_DIST: the metric may also be sa8d_inter or sse_pp (reference common/pixel.cpp:158-177, 290-376,
+// 1117-1141).  sa8d rounds once per 8x8 or once per 16x16 block, so those blocks' raw sums meet in a per-request
+// array of LDS accumulators (`units`) and are rounded when the batch is written out; a request's items start on
+// an even slot so that the two halves of an 8x8 block sit in lanes 2j and 2j + 1 (sa8d_strip).
+enum { MODE_COST = 0, MODE_BIDIR = 1, MODE_DIST = 2 };
+#define DIST_UNITS 16 // 64x64: sixteen 16x16 blocks; 32x24 / 24x32: twelve 8x8 blocks
+
+template <int MODE, typename Req>
 __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *reqs, int n, int32_t *out, uint32_t *counters, int parity)
 {
+    constexpr bool BIDIR = MODE == MODE_BIDIR, DIST = MODE == MODE_DIST;
     __shared__ CostLds lds[4];
+    __shared__ int count_lds[4][COST_BATCH];                              // items of a request (pre[] holds the padded count)
+    __shared__ int units_lds[DIST ? 4 : 1][COST_BATCH * DIST_UNITS];
     __shared__ PlaneDesc planes[X265_HIP_MAX_PLANES];
     static_assert(sizeof(PlaneDesc) == 16 && X265_HIP_MAX_PLANES * 4 <= 256, "plane directory copy below");
     if (threadIdx.x < X265_HIP_MAX_PLANES * 4)
@@ -1213,6 +1223,8 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
     __syncthreads();
 
     CostLds &L = lds[threadIdx.x >> 6];
+    int *const count = count_lds[threadIdx.x >> 6];
+    int *const units = units_lds[DIST ? threadIdx.x >> 6 : 0];
     const int lane = threadIdx.x & 63;
     const int nbatch = (n + COST_BATCH - 1) / COST_BATCH;
     const int parts = min((int)gridDim.x, COST_PARTS), part = blockIdx.x % parts;
@@ -1233,7 +1245,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
         nb = nwaves + uniform(nb);
         const int base = (part + b * parts) * COST_BATCH;
         const bool have = lane < COST_BATCH && base + lane < n;
-        int ni = 0;
+        int ni = 0, nunits = 0;
         if (have)
         {
             const PlaneDesc fp = planes[cur.fenc_plane], rp = planes[req_ref0(cur)];
@@ -1244,16 +1256,38 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
             L.ref[lane] = rp.origin + (long)(cur.pu_y + (qy >> 2)) * rp.stride + cur.pu_x + (qx >> 2);
             L.fstride[lane] = fp.stride;
             L.rstride[lane] = rp.stride;
-            int info = (cur.pu_w >> 2) | ((qx & 3) << 8) | ((qy & 3) << 10) | (cur.metric << 12) | (tall << 13);
+            int info = (cur.pu_w >> 2) | ((qx & 3) << 8) | ((qy & 3) << 10) | (cur.metric << 12) | (tall << 14);
+            if (DIST && cur.metric == X265_HIP_SA8D)
+            {
+                // the table of pixel.cpp:1117-1141: sa8d16<> / sa8d8<> / satd by the block's divisibility
+                const int kind = ((cur.pu_w | cur.pu_h) & 15) == 0 ? 2 : ((cur.pu_w | cur.pu_h) & 7) == 0 ? 1 : 0;
+                if (kind)
+                {
+                    const int nux = cur.pu_w >> (2 + kind);
+                    nunits = nux * (cur.pu_h >> (2 + kind));
+                    info |= (kind << 19) | (nux << 21);
+                }
+            }
             if (BIDIR)
             {
                 const PlaneDesc rp1 = planes[req_ref1(cur)];
                 const int qx1 = req_qx1(cur), qy1 = req_qy1(cur);
                 L.ref1[lane] = rp1.origin + (long)(cur.pu_y + (qy1 >> 2)) * rp1.stride + cur.pu_x + (qx1 >> 2);
                 L.rstride1[lane] = rp1.stride;
-                info |= ((qx1 & 3) << 14) | ((qy1 & 3) << 16);
+                info |= ((qx1 & 3) << 15) | ((qy1 & 3) << 17);
             }
             L.info[lane] = info;
+        }
+        if (lane < COST_BATCH)
+            count[lane] = ni;
+        if (DIST)
+        {
+            ni = (ni + 1) & ~1;
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const i32x4 z = { 0, 0, 0, 0 };
+            static_assert(COST_BATCH * DIST_UNITS == 64 * 8, "two 16-byte stores per lane clear the accumulators");
+            ((i32x4 *)units)[2 * lane] = z;
+            ((i32x4 *)units)[2 * lane + 1] = z;
         }
         const bool small = __ballot(ni > 2) == 0;
         if (lane < COST_BATCH)
@@ -1298,13 +1332,13 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                         k += step;
                 t = i - L.pre[k];
             }
-            if (t >= L.pre[k + 1] - L.pre[k]) // also skips requests past n (no items)
+            if (t >= count[k]) // also skips requests past n (no items)
                 continue;
             const int info = L.info[k], ntx = info & 255, fstride = L.fstride[k], rstride = L.rstride[k];
-            const int xf = (info >> 8) & 3, yf = (info >> 10) & 3, metric = (info >> 12) & 1;
+            const int xf = (info >> 8) & 3, yf = (info >> 10) & 3, metric = (info >> 12) & (DIST ? 3 : 1);
             const int ty = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)ntx)), tx = t - ty * ntx; // exact: t < 256, ntx <= 16
             int v;
-            if ((info >> 13) & 1)
+            if ((info >> 14) & 1)
             {
                 const uint8_t *f = L.fenc[k] + 8 * ty * fstride + 4 * tx;
                 uint32_t pix[8][2];
@@ -1313,7 +1347,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                 {
                     const int rs1 = L.rstride1[k];
                     uint32_t pix1[8][2];
-                    ref_strip<2>(L.ref1[k] + 8 * ty * rs1 + 4 * tx, rs1, (info >> 14) & 3, (info >> 16) & 3, pix1);
+                    ref_strip<2>(L.ref1[k] + 8 * ty * rs1 + 4 * tx, rs1, (info >> 15) & 3, (info >> 17) & 3, pix1);
 #pragma unroll
                     for (int y = 0; y < 8; y++)
                     {
@@ -1321,7 +1355,21 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                         pix[y][1] = avg_pairs(pix[y][1], pix1[y][1]);
                     }
                 }
-                v = tile_metric<true>(f, fstride, pix, metric) + tile_metric<true>(f + 4 * fstride, fstride, pix + 4, metric);
+                const int kind = DIST ? (info >> 19) & 3 : 0;
+                if (DIST && kind)
+                {
+                    // unit = the 8x8 (kind 1) or 16x16 (kind 2) block this strip lies in
+                    const int u = (ty >> (kind - 1)) * ((info >> 21) & 7) + (tx >> kind);
+                    atomicAdd(&units[k * DIST_UNITS + u], sa8d_strip<true>(f, fstride, pix, tx & 1));
+                    continue;
+                }
+                if (DIST && metric == X265_HIP_SSE)
+                    v = sse_strip<8, true>(f, fstride, pix);
+                else
+                {
+                    const int m = DIST ? metric != X265_HIP_SAD : metric; // sa8d_inter of the remaining blocks is satd
+                    v = tile_metric<true>(f, fstride, pix, m) + tile_metric<true>(f + 4 * fstride, fstride, pix + 4, m);
+                }
             }
             else
             {
@@ -1331,7 +1379,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                 {
                     const int rs1 = L.rstride1[k];
                     uint32_t pix1[4][2];
-                    ref_strip<1>(L.ref1[k] + 4 * ty * rs1 + 4 * tx, rs1, (info >> 14) & 3, (info >> 16) & 3, pix1);
+                    ref_strip<1>(L.ref1[k] + 4 * ty * rs1 + 4 * tx, rs1, (info >> 15) & 3, (info >> 17) & 3, pix1);
 #pragma unroll
                     for (int y = 0; y < 4; y++)
                     {
@@ -1339,13 +1387,23 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                         pix[y][1] = avg_pairs(pix[y][1], pix1[y][1]);
                     }
                 }
-                v = tile_metric<true>(L.fenc[k] + 4 * ty * fstride + 4 * tx, fstride, pix, metric);
+                const uint8_t *f = L.fenc[k] + 4 * ty * fstride + 4 * tx;
+                if (DIST && metric == X265_HIP_SSE)
+                    v = sse_strip<4, true>(f, fstride, pix);
+                else
+                    v = tile_metric<true>(f, fstride, pix, DIST ? metric != X265_HIP_SAD : metric);
             }
             atomicAdd(&L.cost[k], v);
         }
         wave_sync();
         if (have)
-            out[base + lane] = L.cost[lane];
+        {
+            int c = L.cost[lane];
+            if (DIST)
+                for (int u = 0; u < nunits; u++)
+                    c += (units[lane * DIST_UNITS + u] + 2) >> 2;
+            out[base + lane] = c;
+        }
         wave_sync(); // the next batch rewrites this wave's LDS record
         b = nb;
     }
@@ -1354,13 +1412,20 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void cost_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
                                                                                            int32_t *out, uint32_t *counters, int parity)
 {
-    cost_body<false>(tabs, reqs, n, out, counters, parity);
+    cost_body<MODE_COST>(tabs, reqs, n, out, counters, parity);
 }
 
 __global__ __launch_bounds__(256) void bidir_cost_kernel(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out,
                                                          uint32_t *counters, int parity)
 {
-    cost_body<true>(tabs, reqs, n, out, counters, parity);
+    cost_body<MODE_BIDIR>(tabs, reqs, n, out, counters, parity);
+}
+
+// cost requests whose metric may be any of sad, satd, sa8d_inter, sse_pp (x265_hip_dist_batch)
+__global__ __launch_bounds__(256) void dist_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out,
+                                                   uint32_t *counters, int parity)
+{
+    cost_body<MODE_DIST>(tabs, reqs, n, out, counters, parity);
 }
 
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st)
@@ -1375,6 +1440,15 @@ void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs,
     {
         const int blocks = ((n + COST_BATCH - 1) / COST_BATCH + 3) / 4;
         hipLaunchKernelGGL(bidir_cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity);
+    }
+}
+
+void launch_dist(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, uint32_t *counters, int parity, hipStream_t st)
+{
+    if (n > 0)
+    {
+        const int blocks = ((n + COST_BATCH - 1) / COST_BATCH + 3) / 4;
+        hipLaunchKernelGGL(dist_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity);
     }
 }
 

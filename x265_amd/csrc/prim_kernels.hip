@@ -1,5 +1,5 @@
 // prim_kernels.hip -- single primitive calls on raw device pointers (gfx950): the kernels behind the
-// function-pointer table (sad / sad_x3 / sad_x4 / satd, luma_hpp / vpp / hps / vsp).
+// function-pointer table (sad / sad_x3 / sad_x4 / satd / sa8d_inter / sse_pp, luma_hpp / vpp / hps / vsp, ...).
 #include "kernels.h"
 #include "me_device.h"
 
@@ -16,6 +16,33 @@ __global__ __launch_bounds__(64) void prim_cmp_kernel(PrimCmpArgs a, int32_t *ou
         acc[lane] = 0;
     wave_sync();
     const int ntx = a.w >> 2, nt = ntx * (a.h >> 2);
+    // sa8d_inter (pixel.cpp:1117-1141): 16x16 units, 8x8 units, or satd where the block has neither
+    const int kind = a.metric != X265_HIP_SA8D ? 0 : ((a.w | a.h) & 15) == 0 ? 2 : ((a.w | a.h) & 7) == 0 ? 1 : 0;
+    if (kind)
+    {
+        __shared__ int units[16];
+        if (lane < 16)
+            units[lane] = 0;
+        wave_sync();
+        const int nux = a.w >> (2 + kind), nunits = nux * (a.h >> (2 + kind));
+        for (int i = lane; i < ntx * (a.h >> 3); i += 64) // even: lanes 2j, 2j + 1 hold the halves of an 8x8 block
+        {
+            const int ty = i / ntx, tx = i - ty * ntx;
+            uint32_t pix[8][2];
+            ref_strip<2>(a.fref[0] + (long)(8 * ty) * a.rstride + 4 * tx, a.rstride, 0, 0, pix);
+            atomicAdd(&units[(ty >> (kind - 1)) * nux + (tx >> kind)],
+                      sa8d_strip<true>(a.fenc + (long)(8 * ty) * a.fstride + 4 * tx, a.fstride, pix, tx & 1));
+        }
+        wave_sync();
+        if (lane == 0)
+        {
+            int c = 0;
+            for (int u = 0; u < nunits; u++)
+                c += (units[u] + 2) >> 2;
+            out[0] = c;
+        }
+        return;
+    }
     const int total = a.nref * nt;
     for (int i = lane; i < total; i += 64)
     {
@@ -23,7 +50,8 @@ __global__ __launch_bounds__(64) void prim_cmp_kernel(PrimCmpArgs a, int32_t *ou
         int ty = t / ntx, tx = t - ty * ntx;
         uint32_t pix[4][2];
         ref_tile(a.fref[c] + (long)(4 * ty) * a.rstride + 4 * tx, a.rstride, 0, 0, pix);
-        int v = tile_metric<true>(a.fenc + (long)(4 * ty) * a.fstride + 4 * tx, a.fstride, pix, a.metric);
+        const uint8_t *f = a.fenc + (long)(4 * ty) * a.fstride + 4 * tx;
+        int v = a.metric == X265_HIP_SSE ? sse_strip<4, true>(f, a.fstride, pix) : tile_metric<true>(f, a.fstride, pix, a.metric != X265_HIP_SAD);
         atomicAdd(&acc[c], v);
     }
     wave_sync();

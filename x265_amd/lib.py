@@ -34,6 +34,7 @@ EXPORTS = [
     "x265_hip_plane_download", "x265_hip_lowres_geometry_of", "x265_hip_lowres_init",
     "x265_hip_plane_extend_border", "x265_hip_plane_weight",
     "x265_hip_bidir_cost_batch", "x265_hip_bidir_cost_batch_device",
+    "x265_hip_dist_batch", "x265_hip_dist_batch_device",
 ]
 
 
@@ -81,6 +82,7 @@ class Primitives(C.Structure):
         ("satd", _cmp * NUM_PARTS), ("luma_hpp", _pp * NUM_PARTS), ("luma_hps", _hps * NUM_PARTS),
         ("luma_vpp", _pp * NUM_PARTS), ("luma_vsp", _pp * NUM_PARTS),
         ("pixelavg_pp", _avg * NUM_PARTS), ("weight_pp", _wpp), ("frame_init_lowres_core", _down),
+        ("sa8d_inter", _cmp * NUM_PARTS), ("sse_pp", _cmp * NUM_PARTS),
     ]
 
 
@@ -184,6 +186,15 @@ class Context:
         out = np.zeros(len(reqs), np.int32)
         _check(load().x265_hip_cost_batch(self._h, _p(reqs), C.c_int(len(reqs)), _p(out)))
         return out
+
+    def dist_batch(self, reqs):
+        reqs = np.ascontiguousarray(reqs, COST_REQ)
+        out = np.zeros(len(reqs), np.int32)
+        _check(load().x265_hip_dist_batch(self._h, _p(reqs), C.c_int(len(reqs)), _p(out)))
+        return out
+
+    def dist_batch_device(self, d_reqs, n, d_costs):
+        _check(load().x265_hip_dist_batch_device(self._h, C.c_void_p(d_reqs), C.c_int(n), C.c_void_p(d_costs)))
 
     def bidir_cost_batch(self, reqs):
         reqs = np.ascontiguousarray(reqs, BIDIR_REQ)

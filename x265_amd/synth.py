@@ -10,7 +10,7 @@ Nothing here is timed; bench.py uploads the result once and keeps it resident in
 """
 import numpy as np
 
-from .abi import COST_REQ, LOWRES_REF, ME_JOB, MAX_MVC, SATD
+from .abi import COST_REQ, LOWRES_REF, ME_JOB, MAX_MVC, SA8D, SATD
 
 MARGIN_X = 96
 MARGIN_Y = 80
@@ -221,12 +221,17 @@ def subpel_requests(w, h, cur, refs, motions):
 
 
 def satd_lane_ops(reqs):
-    """Algorithmic 32-bit lane-ops of a request list: SATD 111 per 4x4 tile; hpp / vpp
-    8 MAC + 3 per pixel; diagonal 8 (H + 7) / H + 8 MAC + 3 per pixel."""
-    px = reqs["pu_w"].astype(np.float64) * reqs["pu_h"]
-    hgt = reqs["pu_h"].astype(np.float64)
+    """Algorithmic 32-bit lane-ops of a request list (SURVEY.md 8(d)): the comparison (SATD 111 per 4x4 tile;
+    sa8d 575 per 8x8 block = 64 differences, sixteen 8-point transforms of 24 butterflies, 64 absolute values,
+    63 additions; sse and sad 3 per pixel) plus the interpolation: hpp / vpp 8 MAC + 3 per pixel; diagonal
+    8 (H + 7) / H + 8 MAC + 3 per pixel."""
+    w, hgt = reqs["pu_w"].astype(np.float64), reqs["pu_h"].astype(np.float64)
+    px = w * hgt
     fx, fy = (reqs["qmv_x"] & 3) != 0, (reqs["qmv_y"] & 3) != 0
-    per_px = 111.0 / 16 + np.where(fx & fy, 8 * (hgt + 7) / hgt + 8 + 3, np.where(fx | fy, 11.0, 0.0))
+    metric = reqs["metric"]
+    blocks8 = ((reqs["pu_w"] | reqs["pu_h"]) & 7) == 0  # sa8d_inter falls back to satd elsewhere
+    cmp_px = np.where(metric == SATD, 111.0 / 16, np.where(metric == SA8D, np.where(blocks8, 575.0 / 64, 111.0 / 16), 3.0))
+    per_px = cmp_px + np.where(fx & fy, 8 * (hgt + 7) / hgt + 8 + 3, np.where(fx | fy, 11.0, 0.0))
     return float((px * per_px).sum())
 
 
