@@ -41,6 +41,16 @@ int fail(int code, const char *fmt, ...)
                         hipGetErrorString(e_));                                                         \
     } while (0)
 
+// A kernel launch reports failure only through hipGetLastError(), which also returns whatever an earlier,
+// unrelated runtime call of this thread (the caller's, a framework's) left behind: drop that first.
+#define LAUNCH(call)                    \
+    do                                  \
+    {                                   \
+        (void)hipGetLastError();        \
+        call;                           \
+        HIP_TRY(hipGetLastError());     \
+    } while (0)
+
 const uint8_t k_part_w[X265_HIP_NUM_LUMA_PARTITIONS] = { 4, 8, 8, 4, 16, 16, 8, 16, 12, 16, 4, 32, 32, 16, 32,
                                                          24, 32, 8, 64, 64, 32, 64, 48, 64, 16 };
 const uint8_t k_part_h[X265_HIP_NUM_LUMA_PARTITIONS] = { 4, 8, 4, 8, 16, 8, 16, 12, 16, 4, 16, 32, 16, 32, 24,
@@ -352,8 +362,7 @@ int x265_hip_lowres_init(x265_hip_ctx *c, int src_plane, int width, int height, 
         if (r)
             return r;
     }
-    launch_lowres_init(a, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_lowres_init(a, c->stream));
     return X265_HIP_OK;
 }
 
@@ -393,8 +402,7 @@ int x265_hip_plane_extend_border(x265_hip_ctx *c, int id, int width, int height,
     int r = border_args(c, "plane_extend_border", id, id, width, height, mx, my, a);
     if (r)
         return r;
-    launch_plane_border(a, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_plane_border(a, c->stream));
     return X265_HIP_OK;
 }
 
@@ -429,8 +437,7 @@ int x265_hip_plane_weight(x265_hip_ctx *c, int src, int dst, int width, int heig
     a.round = round << 6;
     a.shift = log2_denom + 6;
     a.offset = offset;
-    launch_plane_border(a, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_plane_border(a, c->stream));
     return X265_HIP_OK;
 }
 
@@ -547,8 +554,7 @@ int x265_hip_me_batch_device(x265_hip_ctx *c, const void *d_jobs, int n, void *d
     int r = push_tabs(c);
     if (r)
         return r;
-    launch_me(c->dev_tabs, (const x265_hip_me_job *)d_jobs, n, (x265_hip_me_result *)d_results, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)d_jobs, n, (x265_hip_me_result *)d_results, c->stream));
     return X265_HIP_OK;
 }
 
@@ -567,8 +573,7 @@ int x265_hip_me_batch(x265_hip_ctx *c, const x265_hip_me_job *jobs, int n, x265_
     // straight from the caller's memory: the runtime pipelines its own staging, which beats a copy into the
     // pinned mirror followed by one DMA
     HIP_TRY(hipMemcpyAsync(c->in.d, jobs, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
-    launch_me(c->dev_tabs, (const x265_hip_me_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, c->stream));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(*results), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(results, c->out.h, (size_t)n * sizeof(*results));
@@ -584,8 +589,7 @@ int x265_hip_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void 
     int r = push_tabs(c);
     if (r)
         return r;
-    launch_cost(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_cost(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream));
     return X265_HIP_OK;
 }
 
@@ -611,8 +615,7 @@ int x265_hip_cost_batch(x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n, i
         return r;
     memcpy(c->in.h, reqs, (size_t)n * sizeof(*reqs));
     HIP_TRY(hipMemcpyAsync(c->in.d, c->in.h, (size_t)n * sizeof(*reqs), hipMemcpyHostToDevice, c->stream));
-    launch_cost(c->dev_tabs, (const x265_hip_cost_req *)c->in.d, n, (int32_t *)c->out.d, c->batch_counter, c->batch_parity ^= 1, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_cost(c->dev_tabs, (const x265_hip_cost_req *)c->in.d, n, (int32_t *)c->out.d, c->batch_counter, c->batch_parity ^= 1, c->stream));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(costs, c->out.h, (size_t)n * sizeof(int32_t));
@@ -628,8 +631,7 @@ int x265_hip_dist_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void 
     int r = push_tabs(c);
     if (r)
         return r;
-    launch_dist(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_dist(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream));
     return X265_HIP_OK;
 }
 
@@ -654,8 +656,7 @@ int x265_hip_dist_batch(x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n, i
         (r = ensure(c, c->out, (size_t)n * sizeof(int32_t))))
         return r;
     HIP_TRY(hipMemcpyAsync(c->in.d, reqs, (size_t)n * sizeof(*reqs), hipMemcpyHostToDevice, c->stream));
-    launch_dist(c->dev_tabs, (const x265_hip_cost_req *)c->in.d, n, (int32_t *)c->out.d, c->batch_counter, c->batch_parity ^= 1, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_dist(c->dev_tabs, (const x265_hip_cost_req *)c->in.d, n, (int32_t *)c->out.d, c->batch_counter, c->batch_parity ^= 1, c->stream));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(costs, c->out.h, (size_t)n * sizeof(int32_t));
@@ -671,8 +672,7 @@ int x265_hip_bidir_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n,
     int r = push_tabs(c);
     if (r)
         return r;
-    launch_bidir_cost(c->dev_tabs, (const x265_hip_bidir_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_bidir_cost(c->dev_tabs, (const x265_hip_bidir_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream));
     return X265_HIP_OK;
 }
 
@@ -697,8 +697,7 @@ int x265_hip_bidir_cost_batch(x265_hip_ctx *c, const x265_hip_bidir_req *reqs, i
         (r = ensure(c, c->out, (size_t)n * sizeof(int32_t))))
         return r;
     HIP_TRY(hipMemcpyAsync(c->in.d, reqs, (size_t)n * sizeof(*reqs), hipMemcpyHostToDevice, c->stream));
-    launch_bidir_cost(c->dev_tabs, (const x265_hip_bidir_req *)c->in.d, n, (int32_t *)c->out.d, c->batch_counter, c->batch_parity ^= 1, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_bidir_cost(c->dev_tabs, (const x265_hip_bidir_req *)c->in.d, n, (int32_t *)c->out.d, c->batch_counter, c->batch_parity ^= 1, c->stream));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(costs, c->out.h, (size_t)n * sizeof(int32_t));
@@ -714,8 +713,7 @@ int x265_hip_fullsearch_device(x265_hip_ctx *c, const void *d_jobs, int n, void 
     int r = push_tabs(c);
     if (r)
         return r;
-    launch_fullsearch2(c->dev_tabs, (const x265_hip_ctu_job *)d_jobs, n, (x265_hip_me_result *)d_results, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_fullsearch2(c->dev_tabs, (const x265_hip_ctu_job *)d_jobs, n, (x265_hip_me_result *)d_results, c->stream));
     return X265_HIP_OK;
 }
 
@@ -746,8 +744,7 @@ int x265_hip_fullsearch(x265_hip_ctx *c, const x265_hip_ctu_job *jobs, int n, x2
         return r;
     memcpy(c->in.h, jobs, (size_t)n * sizeof(*jobs));
     HIP_TRY(hipMemcpyAsync(c->in.d, c->in.h, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
-    launch_fullsearch2(c->dev_tabs, (const x265_hip_ctu_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_fullsearch2(c->dev_tabs, (const x265_hip_ctu_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, c->stream));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(results, c->out.h, ob);
@@ -849,8 +846,7 @@ int prim_cmp(int part, int metric, const uint8_t *fenc, intptr_t fstride, const 
         a.rstride = w;
     }
     HIP_TRY(hipMemcpyAsync(ds, hs, used, hipMemcpyHostToDevice, c->stream));
-    launch_prim_cmp(a, (int32_t *)c->prim_b.d, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_prim_cmp(a, (int32_t *)c->prim_b.d, c->stream));
     HIP_TRY(hipMemcpyAsync(c->prim_b.h, c->prim_b.d, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(res, c->prim_b.h, nref * sizeof(int32_t));
@@ -904,8 +900,7 @@ int prim_filter(int part, int kind, const void *src, intptr_t sstride, void *dst
         a.src = (const uint8_t *)c->prim_a.d + ((size_t)pre_r * sw + pre_c) * ses;
         a.sstride = sw;
     }
-    launch_prim_filter(a, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_prim_filter(a, c->stream));
     HIP_TRY(hipMemcpyAsync(c->prim_b.h, c->prim_b.d, dbytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int y = 0; y < rows; y++)
@@ -1020,8 +1015,7 @@ int prim_avg(int part, uint8_t *dst, intptr_t ds, const uint8_t *s0, intptr_t ss
         (r = stage_rows(c, c->prim_a, 0, s0, ss0, w, h, w)) || (r = stage_rows(c, c->prim_a, blk, s1, ss1, w, h, w)))
         return r;
     PrimAvgArgs a = { (const uint8_t *)c->prim_a.d, (const uint8_t *)c->prim_a.d + blk, (uint8_t *)c->prim_b.d, w, w, w, w, h };
-    launch_prim_avg(a, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_prim_avg(a, c->stream));
     HIP_TRY(hipMemcpyAsync(c->prim_b.h, c->prim_b.d, blk, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int y = 0; y < h; y++)
@@ -1057,8 +1051,7 @@ int prim_weight(const uint8_t *src, uint8_t *dst, intptr_t ss, intptr_t ds, int 
     a.round = round;
     a.shift = shift;
     a.offset = offset;
-    launch_plane_border(a, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_plane_border(a, c->stream));
     HIP_TRY(hipMemcpyAsync(c->prim_b.h, c->prim_b.d, blk, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int y = 0; y < height; y++)
@@ -1095,8 +1088,7 @@ int prim_lowres(const uint8_t *src0, uint8_t *const dst[4], intptr_t ss, intptr_
     a.margin_x = a.margin_y = 0;
     for (int k = 0; k < 4; k++)
         a.dst[k] = (uint8_t *)c->prim_b.d + k * dblk;
-    launch_lowres_init(a, c->stream);
-    HIP_TRY(hipGetLastError());
+    LAUNCH(launch_lowres_init(a, c->stream));
     HIP_TRY(hipMemcpyAsync(c->prim_b.h, c->prim_b.d, 4 * dblk, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int k = 0; k < 4; k++)

@@ -1150,10 +1150,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void me
 }
 
 // Cost requests in batches of 32 per wave.  Batches differ sevenfold in work when block sizes are mixed, so a
-// fixed stride leaves SIMDs idle at the end; instead the batches are dealt round-robin to up to COST_PARTS
-// parts (so a list sorted by size loads every part alike), part p is served by the blocks p, p + parts, ...,
-// and their waves take the part's batches in order from its counter in device memory (one counter for all
-// waves would serialise: about 12 ns per atomic on one address).  A wave fetches
+// fixed stride leaves SIMDs idle at the end; instead the batches are dealt in chunks of COST_CHUNK, round-robin,
+// to up to COST_PARTS parts (so a list sorted by size loads every part alike), part p is served by the blocks
+// p, p + parts, ..., and their waves take the part's batches in order from its counter in device memory (one
+// counter for all waves would serialise: about 12 ns per atomic on one address).  The blocks of a part run on
+// one XCD (blocks go round-robin over the eight, and parts is a multiple of eight whenever it matters), so the
+// neighbouring requests of a chunk, which mostly read the same pixels, meet in one L2.  A wave fetches
 // the next batch's request records while it computes the current one (the plane directory sits in LDS), so
 // the only memory latency in front of a batch's arithmetic is that of its pixel loads.  Two sets of counters
 // alternate between launches: a launch counts in set `parity` and clears the other one for its successor.
@@ -1167,6 +1169,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void me
 #define COST_BATCH 32
 #define COST_MAX_BLOCKS (256 * 6)
 #define COST_PARTS 64 // counters are 64 bytes apart
+#define COST_CHUNK 8
 
 struct CostLds
 {
@@ -1229,21 +1232,24 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
     const int nbatch = (n + COST_BATCH - 1) / COST_BATCH;
     const int parts = min((int)gridDim.x, COST_PARTS), part = blockIdx.x % parts;
     const int nwaves = 4 * (((int)gridDim.x - part + parts - 1) / parts); // waves serving this part
-    const int hi = (nbatch - part + parts - 1) / parts; // batches of this part: part + j * parts, j < hi
+    // batch number j of this part is batch_of(j); hi = the first j whose batch lies past the list for sure
+    auto batch_of = [&](int j) { return ((j / COST_CHUNK) * parts + part) * COST_CHUNK + j % COST_CHUNK; };
+    const int nchunk = (nbatch + COST_CHUNK - 1) / COST_CHUNK;
+    const int hi = ((nchunk - part + parts - 1) / parts) * COST_CHUNK;
     uint32_t *const counter = counters + (parity * COST_PARTS + part) * 16;
     if (blockIdx.x == 0 && threadIdx.x < COST_PARTS)
         counters[((parity ^ 1) * COST_PARTS + threadIdx.x) * 16] = 0;
     int b = (blockIdx.x / parts) * 4 + (threadIdx.x >> 6);
     Req cur = {};
-    if (lane < COST_BATCH && (long)(part + b * parts) * COST_BATCH + lane < n)
-        cur = reqs[(part + b * parts) * COST_BATCH + lane];
+    if (lane < COST_BATCH && b < hi && (long)batch_of(b) * COST_BATCH + lane < n)
+        cur = reqs[batch_of(b) * COST_BATCH + lane];
     while (b < hi)
     {
         int nb = 0;
         if (lane == 0)
             nb = (int)atomicAdd(counter, 1u);
         nb = nwaves + uniform(nb);
-        const int base = (part + b * parts) * COST_BATCH;
+        const int base = batch_of(b) * COST_BATCH;
         const bool have = lane < COST_BATCH && base + lane < n;
         int ni = 0, nunits = 0;
         if (have)
@@ -1309,7 +1315,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
         }
         // next batch's records: in flight during this batch's arithmetic
         {
-            const int nid = (part + nb * parts) * COST_BATCH + lane;
+            const int nid = batch_of(nb) * COST_BATCH + lane;
             if (lane < COST_BATCH && nb < hi && nid < n)
                 cur = reqs[nid];
         }
