@@ -89,6 +89,19 @@ __device__ __forceinline__ int clip_pixel(int v)
     return min(max(v, 0), 255); // v_med3_i32
 }
 
+// Blocks are dealt round-robin to the eight XCDs, each with an L2 of its own, while neighbours in a work list
+// (the PUs of one CTU, the same PU against another candidate) mostly read the same pixels.  This maps block b of
+// n to a list position so that runs of `chunk` consecutive positions land on one XCD; the mapping is a
+// permutation of [0, n) (identity on the ragged end).
+__device__ __forceinline__ int xcd_chunked(int b, int n, int chunk)
+{
+    const int span = 8 * chunk;
+    if (b >= n - n % span)
+        return b;
+    const int xcd = b & 7, local = b >> 3;
+    return ((local / chunk) * 8 + xcd) * chunk + local % chunk;
+}
+
 // make LDS traffic of this wave visible to its other lanes (single-wave scope)
 __device__ __forceinline__ void wave_sync()
 {
