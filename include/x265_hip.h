@@ -228,6 +228,26 @@ typedef struct x265_hip_bidir_req
 int x265_hip_bidir_cost_batch(x265_hip_ctx *ctx, const x265_hip_bidir_req *reqs, int n, int32_t *costs);
 int x265_hip_bidir_cost_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs);
 
+/* Motion-compensated luma prediction, TComPrediction::xPredInterUni / xPredInterBi for
+ * luma (source/Lib/TLibCommon/TComPrediction.cpp:330-387).  Uni-directional: xPredInterLumaBlk to pixels
+ * (:400-433: luma_copy_pp / luma_hpp / luma_vpp / luma_hps + luma_vsp).  Bi-directional: both lists to 14-bit
+ * intermediates (:436-473: luma_p2s / luma_hps / luma_vps / luma_hps + luma_vss; ipfilter.cpp:38-54, 117-160,
+ * 204-239, 285-317) and luma_addAvg (common/pixel.cpp:819-839).  Weighted bi-prediction (xWeightedPredictionBi)
+ * is not covered.  pu_w x pu_h samples are written at (pu_x, pu_y) of dst_plane, which must not be one of the
+ * request's references; requests of one batch whose destination blocks overlap race. */
+typedef struct x265_hip_pred_req
+{
+    int32_t dst_plane;
+    int32_t ref0_plane, ref1_plane; /* ref1_plane < 0: uni-directional prediction from ref0 */
+    int16_t pu_x, pu_y;
+    uint8_t pu_w, pu_h; /* one of the 25 partitions */
+    uint8_t pad[2];
+    int16_t qmv0_x, qmv0_y, qmv1_x, qmv1_y;
+} x265_hip_pred_req;
+
+int x265_hip_predict_batch(x265_hip_ctx *ctx, const x265_hip_pred_req *reqs, int n);
+int x265_hip_predict_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n);
+
 /* one call of MotionEstimate::motionEstimate (motion.h:93; motion.cpp:526-1124), non-lowres branch */
 typedef struct x265_hip_me_job
 {

@@ -157,6 +157,23 @@ def gen_dist(R):
     np.savez_compressed(os.path.join(OUT, "dist.npz"), reqs=reqs, costs=costs)
 
 
+def gen_pred(R):
+    """motion-compensated predictions (uni- and bi-directional) written into a 0x5A-filled plane: CRC32 of the
+    whole destination buffer after each of ten batches"""
+    from conftest import random_pred_reqs
+    planes = golden_sequence()
+    p0 = planes[0]
+    dst = np.full_like(p0.buf, 0x5A)
+    rng = np.random.default_rng(81)
+    batches, crcs = [], []
+    for _ in range(10):
+        reqs = random_pred_reqs(rng, p0.w, p0.h, pyoracle.PRED_REQ, pyoracle.PARTS, dst_plane=3)
+        R.predict_batch([p.as_tuple() for p in planes] + [(dst, p0.origin, p0.stride)], reqs)
+        batches.append(reqs)
+        crcs.append(crc(dst))
+    np.savez_compressed(os.path.join(OUT, "pred.npz"), reqs=np.stack(batches), crc=np.array(crcs, np.uint32))
+
+
 def main():
     if not pyoracle.have_ref():
         sys.exit("oracle/_ref/libx265ref.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -167,6 +184,7 @@ def main():
     gen_me(R)
     gen_lowres(R)
     gen_dist(R)
+    gen_pred(R)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

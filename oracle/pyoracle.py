@@ -48,6 +48,15 @@ BIDIR_REQ = np.dtype([
 assert BIDIR_REQ.itemsize == 28
 
 
+PRED_REQ = np.dtype([
+    ("dst_plane", "<i4"), ("ref0_plane", "<i4"), ("ref1_plane", "<i4"),
+    ("pu_x", "<i2"), ("pu_y", "<i2"),
+    ("pu_w", "u1"), ("pu_h", "u1"), ("pad", "u1", (2,)),
+    ("qmv0_x", "<i2"), ("qmv0_y", "<i2"), ("qmv1_x", "<i2"), ("qmv1_y", "<i2"),
+])
+assert PRED_REQ.itemsize == 28
+
+
 class _Plane(C.Structure):
     _fields_ = [("origin", C.c_void_p), ("stride", C.c_ssize_t)]
 
@@ -215,6 +224,30 @@ class Checker:
         out = np.zeros(len(reqs), np.int32)
         self._f("bidir_cost_batch")(self._planes(planes), _ptr(reqs), C.c_int(len(reqs)), _ptr(out))
         return out
+
+    def predict_batch(self, planes, reqs):
+        """writes the predictions into the buffers of the planes the requests name as destination"""
+        reqs = np.ascontiguousarray(reqs, dtype=PRED_REQ)
+        self._f("predict_batch")(self._planes(planes), _ptr(reqs), C.c_int(len(reqs)))
+
+    def luma_p2s(self, src, soff, sstride, dst, doff, width, height):
+        self._f("luma_p2s")(_ptr(src, soff), C.c_ssize_t(sstride), _ptr(dst, 2 * doff), C.c_int(width), C.c_int(height))
+
+    def luma_vps(self, part, src, soff, sstride, dst, doff, dstride, coeff):
+        self._f("luma_vps")(C.c_int(part), _ptr(src, soff), C.c_ssize_t(sstride), _ptr(dst, 2 * doff), C.c_ssize_t(dstride),
+                            C.c_int(coeff))
+
+    def luma_vss(self, part, src, soff, sstride, dst, doff, dstride, coeff):
+        self._f("luma_vss")(C.c_int(part), _ptr(src, 2 * soff), C.c_ssize_t(sstride), _ptr(dst, 2 * doff), C.c_ssize_t(dstride),
+                            C.c_int(coeff))
+
+    def luma_hvpp(self, part, src, soff, sstride, dst, doff, dstride, idx_x, idx_y):
+        self._f("luma_hvpp")(C.c_int(part), _ptr(src, soff), C.c_ssize_t(sstride), _ptr(dst, doff), C.c_ssize_t(dstride),
+                             C.c_int(idx_x), C.c_int(idx_y))
+
+    def luma_addavg(self, part, src0, o0, src1, o1, dst, doff, sstride0, sstride1, dstride):
+        self._f("luma_addavg")(C.c_int(part), _ptr(src0, 2 * o0), _ptr(src1, 2 * o1), _ptr(dst, doff), C.c_ssize_t(sstride0),
+                               C.c_ssize_t(sstride1), C.c_ssize_t(dstride))
 
     def ctu_fullsearch(self, fenc, ref, costtab, ctu_x, ctu_y, mvmin, mvmax, qmvp):
         out = np.zeros(85, ME_RESULT)

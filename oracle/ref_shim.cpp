@@ -261,6 +261,97 @@ void x265r_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *re
     }
 }
 
+void x265r_luma_p2s(const uint8_t *src, intptr_t sstride, int16_t *dst, int width, int height)
+{
+    init();
+    g_c.luma_p2s((pixel *)src, sstride, dst, width, height);
+}
+
+void x265r_luma_vps(int part, const uint8_t *src, intptr_t sstride, int16_t *dst, intptr_t dstride, int coeffIdx)
+{
+    init();
+    g_c.luma_vps[part]((pixel *)src, sstride, dst, dstride, coeffIdx);
+}
+
+void x265r_luma_vss(int part, const int16_t *src, intptr_t sstride, int16_t *dst, intptr_t dstride, int coeffIdx)
+{
+    init();
+    g_c.luma_vss[part]((int16_t *)src, sstride, dst, dstride, coeffIdx);
+}
+
+void x265r_luma_hvpp(int part, const uint8_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int idxX, int idxY)
+{
+    init();
+    g_c.luma_hvpp[part]((pixel *)src, sstride, dst, dstride, idxX, idxY);
+}
+
+void x265r_luma_addavg(int part, const int16_t *src0, const int16_t *src1, uint8_t *dst, intptr_t sstride0, intptr_t sstride1,
+                       intptr_t dstride)
+{
+    init();
+    g_c.luma_addAvg[part]((int16_t *)src0, (int16_t *)src1, dst, sstride0, sstride1, dstride);
+}
+
+/* the call sequence of TComPrediction::xPredInterLumaBlk to a ShortYuv (TComPrediction.cpp:436-473) */
+static void ref_predict_luma_short(int part, int w, int h, pixel *p, intptr_t stride, int qx, int qy, int16_t *dst)
+{
+    int xf = qx & 3, yf = qy & 3;
+    p += (qx >> 2) + (qy >> 2) * stride;
+    if (!(xf | yf))
+        g_c.luma_p2s(p, stride, dst, w, h);
+    else if (!yf)
+        g_c.luma_hps[part](p, stride, dst, 64, xf, 0);
+    else if (!xf)
+        g_c.luma_vps[part](p, stride, dst, 64, yf);
+    else
+    {
+        static thread_local int16_t immed[64 * (64 + 8)];
+        g_c.luma_hps[part](p, stride, immed, w, xf, 1);
+        g_c.luma_vss[part](immed + 3 * w, w, dst, 64, yf);
+    }
+}
+
+/* TComPrediction::xPredInterUni / xPredInterBi for luma (TComPrediction.cpp:330-387), on the reference's primitives */
+void x265r_predict_batch(const x265o_plane *planes, const x265o_pred_req *reqs, int n)
+{
+    init();
+    static thread_local int16_t s0[64 * 64], s1[64 * 64];
+    for (int i = 0; i < n; i++)
+    {
+        const x265o_pred_req *r = &reqs[i];
+        const x265o_plane &d = planes[r->dst_plane], &a = planes[r->ref0_plane];
+        int part = partitionFromSizes(r->pu_w, r->pu_h);
+        pixel *dst = (pixel *)d.origin + r->pu_x + (intptr_t)r->pu_y * d.stride;
+        pixel *pa = (pixel *)a.origin + r->pu_x + (intptr_t)r->pu_y * a.stride;
+        if (r->ref1_plane < 0)
+        {
+            /* xPredInterLumaBlk with the destination's own stride */
+            int xf = r->qmv0_x & 3, yf = r->qmv0_y & 3;
+            pixel *p = pa + (r->qmv0_x >> 2) + (r->qmv0_y >> 2) * a.stride;
+            if (!(xf | yf))
+                g_c.luma_copy_pp[part](dst, d.stride, p, a.stride);
+            else if (!yf)
+                g_c.luma_hpp[part](p, a.stride, dst, d.stride, xf);
+            else if (!xf)
+                g_c.luma_vpp[part](p, a.stride, dst, d.stride, yf);
+            else
+            {
+                static thread_local int16_t immed[64 * (64 + 8)];
+                g_c.luma_hps[part](p, a.stride, immed, r->pu_w, xf, 1);
+                g_c.luma_vsp[part](immed + 3 * r->pu_w, r->pu_w, dst, d.stride, yf);
+            }
+        }
+        else
+        {
+            const x265o_plane &b = planes[r->ref1_plane];
+            pixel *pb = (pixel *)b.origin + r->pu_x + (intptr_t)r->pu_y * b.stride;
+            ref_predict_luma_short(part, r->pu_w, r->pu_h, pa, a.stride, r->qmv0_x, r->qmv0_y, s0);
+            ref_predict_luma_short(part, r->pu_w, r->pu_h, pb, b.stride, r->qmv1_x, r->qmv1_y, s1);
+            g_c.luma_addAvg[part](s0, s1, dst, 64, 64, d.stride);
+        }
+    }
+}
+
 void x265r_pixelavg_pp(int part, uint8_t *dst, intptr_t dstride, const uint8_t *src0, intptr_t sstride0,
                        const uint8_t *src1, intptr_t sstride1)
 {

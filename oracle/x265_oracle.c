@@ -1156,6 +1156,117 @@ int x265o_bidir_cost(const x265o_plane *fenc, const x265o_plane *ref0, const x26
     return metric ? x265o_satd(part, f, fenc->stride, avg, 64) : sad_wh(w, h, f, fenc->stride, avg, 64);
 }
 
+/* ------------------------------------------------------------------------- */
+/* motion-compensated luma prediction: the 14-bit intermediates of bi-prediction and luma_addAvg       */
+
+/* luma_p2s, ref: filterConvertPelToShort_c<MAX_CU_SIZE>, common/ipfilter.cpp:37-54, 510 (dst stride 64) */
+void x265o_luma_p2s(const uint8_t *src, intptr_t sstride, int16_t *dst, int width, int height)
+{
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++)
+            dst[y * 64 + x] = (int16_t)((src[y * sstride + x] << 6) - 8192);
+}
+
+/* luma_vps[part], ref: interp_vert_ps_c<8, W, H>, common/ipfilter.cpp:203-239: shift 0, offset -8192 */
+void x265o_luma_vps(int part, const uint8_t *src, intptr_t sstride, int16_t *dst, intptr_t dstride, int coeffIdx)
+{
+    int w = k_part_w[part], h = k_part_h[part];
+    const int16_t *c = k_luma_taps[coeffIdx];
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            int sum = 0;
+            for (int k = 0; k < 8; k++)
+                sum += src[(y + k - 3) * sstride + x] * c[k];
+            dst[y * dstride + x] = (int16_t)(sum - 8192);
+        }
+}
+
+/* luma_vss[part], ref: interp_vert_ss_c<8, W, H>, common/ipfilter.cpp:284-317: shift 6, no offset */
+void x265o_luma_vss(int part, const int16_t *src, intptr_t sstride, int16_t *dst, intptr_t dstride, int coeffIdx)
+{
+    int w = k_part_w[part], h = k_part_h[part];
+    const int16_t *c = k_luma_taps[coeffIdx];
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            int sum = 0;
+            for (int k = 0; k < 8; k++)
+                sum += src[(y + k - 3) * sstride + x] * c[k];
+            dst[y * dstride + x] = (int16_t)(sum >> 6);
+        }
+}
+
+/* luma_hvpp[part], ref: interp_hv_pp_c<8, W, H>, common/ipfilter.cpp:362-369 */
+void x265o_luma_hvpp(int part, const uint8_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int idxX, int idxY)
+{
+    int16_t immed[(64 + 8) * (64 + 8)];
+    int w = k_part_w[part];
+    x265o_luma_hps(part, src, sstride, immed, w, idxX, 1);
+    x265o_luma_vsp(part, immed + 3 * w, w, dst, dstride, idxY);
+}
+
+/* luma_addAvg[part], ref: addAvg<W, H>, common/pixel.cpp:819-839: shift 7, offset 64 + 2 * 8192 */
+void x265o_luma_addavg(int part, const int16_t *src0, const int16_t *src1, uint8_t *dst, intptr_t sstride0, intptr_t sstride1,
+                       intptr_t dstride)
+{
+    int w = k_part_w[part], h = k_part_h[part];
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            int v = (src0[y * sstride0 + x] + src1[y * sstride1 + x] + 64 + 2 * 8192) >> 7;
+            dst[y * dstride + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+}
+
+/* ref: TComPrediction::xPredInterLumaBlk to a ShortYuv (stride 64), TComPrediction.cpp:436-473 */
+static void predict_luma_short(int part, int w, int h, const uint8_t *p, intptr_t stride, int qx, int qy, int16_t *dst)
+{
+    int xf = qx & 3, yf = qy & 3;
+    p += (qx >> 2) + (qy >> 2) * stride;
+    if (!(xf | yf))
+        x265o_luma_p2s(p, stride, dst, w, h);
+    else if (!yf)
+        x265o_luma_hps(part, p, stride, dst, 64, xf, 0);
+    else if (!xf)
+        x265o_luma_vps(part, p, stride, dst, 64, yf);
+    else
+    {
+        int16_t immed[64 * (64 + 8)];
+        x265o_luma_hps(part, p, stride, immed, w, xf, 1);
+        x265o_luma_vss(part, immed + 3 * w, w, dst, 64, yf);
+    }
+}
+
+/* ref: TComPrediction::xPredInterUni / xPredInterBi for luma, TComPrediction.cpp:330-387 (no weighted prediction) */
+void x265o_predict_batch(const x265o_plane *planes, const x265o_pred_req *reqs, int n)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const x265o_pred_req *r = &reqs[i];
+        const x265o_plane *d = &planes[r->dst_plane], *a = &planes[r->ref0_plane];
+        int part = x265o_partition_from_sizes(r->pu_w, r->pu_h);
+        uint8_t *dst = (uint8_t *)d->origin + r->pu_x + (intptr_t)r->pu_y * d->stride;
+        uint8_t tmp[64 * 64];
+        if (r->ref1_plane < 0)
+        {
+            predict_luma(part, r->pu_w, a->origin + r->pu_x + (intptr_t)r->pu_y * a->stride, a->stride, r->qmv0_x, r->qmv0_y, tmp);
+            for (int y = 0; y < r->pu_h; y++)
+                memcpy(dst + y * d->stride, tmp + y * 64, r->pu_w);
+        }
+        else
+        {
+            const x265o_plane *b = &planes[r->ref1_plane];
+            int16_t s0[64 * 64], s1[64 * 64];
+            predict_luma_short(part, r->pu_w, r->pu_h, a->origin + r->pu_x + (intptr_t)r->pu_y * a->stride, a->stride, r->qmv0_x,
+                               r->qmv0_y, s0);
+            predict_luma_short(part, r->pu_w, r->pu_h, b->origin + r->pu_x + (intptr_t)r->pu_y * b->stride, b->stride, r->qmv1_x,
+                               r->qmv1_y, s1);
+            x265o_luma_addavg(part, s0, s1, dst, 64, 64, d->stride);
+        }
+    }
+}
+
 void x265o_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *reqs, int n, int32_t *out)
 {
     for (int i = 0; i < n; i++)

@@ -124,6 +124,26 @@ int  x265o_bidir_cost(const x265o_plane *fenc, const x265o_plane *ref0, const x2
                       int h, int qmv0x, int qmv0y, int qmv1x, int qmv1y, int metric);
 void x265o_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *reqs, int n, int32_t *out);
 
+/* motion-compensated luma prediction (TComPrediction.cpp:330-473): the remaining interpolation primitives
+ * (ipfilter.cpp:37-54, 203-239, 284-317, 362-369), luma_addAvg (pixel.cpp:819-839) and the batch that writes
+ * predictions into planes[dst_plane] (uni-directional when ref1_plane < 0) */
+typedef struct x265o_pred_req
+{
+    int32_t dst_plane;
+    int32_t ref0_plane, ref1_plane;
+    int16_t pu_x, pu_y;
+    uint8_t pu_w, pu_h;
+    uint8_t pad[2];
+    int16_t qmv0_x, qmv0_y, qmv1_x, qmv1_y;
+} x265o_pred_req;
+void x265o_luma_p2s(const uint8_t *src, intptr_t sstride, int16_t *dst, int width, int height);
+void x265o_luma_vps(int part, const uint8_t *src, intptr_t sstride, int16_t *dst, intptr_t dstride, int coeffIdx);
+void x265o_luma_vss(int part, const int16_t *src, intptr_t sstride, int16_t *dst, intptr_t dstride, int coeffIdx);
+void x265o_luma_hvpp(int part, const uint8_t *src, intptr_t sstride, uint8_t *dst, intptr_t dstride, int idxX, int idxY);
+void x265o_luma_addavg(int part, const int16_t *src0, const int16_t *src1, uint8_t *dst, intptr_t sstride0, intptr_t sstride1,
+                       intptr_t dstride);
+void x265o_predict_batch(const x265o_plane *planes, const x265o_pred_req *reqs, int n);
+
 /* lookahead planes: frame_init_lowres_core (pixel.cpp:595-618) and extendPicBorder (pixel.cpp:893-911) */
 void x265o_frame_init_lowres(const uint8_t *src0, uint8_t *dst0, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc,
                              intptr_t src_stride, intptr_t dst_stride, int width, int height);

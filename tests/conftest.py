@@ -131,3 +131,19 @@ def random_cost_reqs(rng, n, W, H, dtype, parts, metrics=(0, 1), planes=(1, (0, 
         r["qmv_x"] = int(rng.integers(-90, 90)) if rng.integers(4) else 4 * int(rng.integers(-20, 20))
         r["qmv_y"] = int(rng.integers(-90, 90)) if rng.integers(4) else 4 * int(rng.integers(-20, 20))
     return reqs
+
+
+def random_pred_reqs(rng, W, H, dtype, parts, dst_plane=5, refs=(0, 2), cell=64):
+    """one prediction request per 64x64 cell of the picture (destination blocks of a batch must not overlap):
+    every partition, uni- and bi-directional, all fractions"""
+    cells = [(cx, cy) for cy in range(0, H - cell + 1, cell) for cx in range(0, W - cell + 1, cell)]
+    reqs = np.zeros(len(cells), dtype)
+    for r, (cx, cy) in zip(reqs, cells):
+        w, h = parts[int(rng.integers(0, 25))]
+        r["dst_plane"], r["ref0_plane"] = dst_plane, int(rng.choice(refs))
+        r["ref1_plane"] = int(rng.choice(refs)) if rng.integers(3) else -1
+        r["pu_x"], r["pu_y"] = cx + int(rng.integers(0, cell - w + 1)), cy + int(rng.integers(0, cell - h + 1))
+        r["pu_w"], r["pu_h"] = w, h
+        for k in ("qmv0_x", "qmv0_y", "qmv1_x", "qmv1_y"):
+            r[k] = int(rng.integers(-90, 90)) if rng.integers(4) else 4 * int(rng.integers(-20, 20))
+    return reqs

@@ -142,6 +142,20 @@ def test_distortions_reproduce_reference_fixtures(gpu_ctx):
     assert len(bad) == 0, (g["reqs"][bad[0]], got[bad[0]], g["costs"][bad[0]])
 
 
+def test_predictions_reproduce_reference_fixtures(gpu_ctx, small_seq):
+    """pred.npz: CRC32 of the destination plane (whole buffer) after each batch of uni- / bi-directional
+    predictions, computed by the reference build"""
+    import zlib
+    from x265_amd import abi
+    g = np.load(os.path.join(GOLD, "pred.npz"))
+    p0 = small_seq[0]
+    gpu_ctx.plane_upload(3, np.full_like(p0.buf, 0x5A), p0.stride, p0.origin)
+    for reqs, want in zip(g["reqs"], g["crc"]):
+        gpu_ctx.predict_batch(reqs.view(abi.PRED_REQ))
+        assert zlib.crc32(gpu_ctx.plane_download(3, p0.buf.size).tobytes()) & 0xffffffff == int(want)
+    gpu_ctx.plane_release(3)
+
+
 def test_bad_arguments_are_rejected(gpu_ctx):
     from x265_amd import abi, lib
     jobs = np.zeros(1, abi.ME_JOB)

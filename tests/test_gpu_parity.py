@@ -326,3 +326,25 @@ def test_primitive_table_distortions(oracle):
                 pa, pb = C.c_void_p(a.ctypes.data + fo), C.c_void_p(b.ctypes.data + ro)
                 assert t.sa8d_inter[part](pa, 64, pb, rs) == oracle.sa8d_inter(part, a, fo, 64, b, ro, rs), part
                 assert t.sse_pp[part](pa, 64, pb, rs) == oracle.sse_pp(part, a, fo, 64, b, ro, rs), part
+
+
+def test_predict_batch(gpu_ctx, oracle, small_seq):
+    """x265_hip_predict_batch against the oracle: whole destination buffers (nothing outside the blocks may change),
+    every partition, uni- and bi-directional, all fraction pairs"""
+    from conftest import random_pred_reqs
+    from x265_amd import abi
+    rng = np.random.default_rng(62)
+    p0 = small_seq[0]
+    planes = [p.as_tuple() for p in small_seq]
+    want = np.full_like(p0.buf, 0x5A)
+    gpu_ctx.plane_upload(5, want, p0.stride, p0.origin)
+    for _ in range(40):
+        reqs = random_pred_reqs(rng, p0.w, p0.h, abi.PRED_REQ, oracle_parts(), dst_plane=5)
+        gpu_ctx.predict_batch(reqs)
+        reqs_o = reqs.copy()
+        reqs_o["dst_plane"] = 3
+        oracle.predict_batch(planes + [(want, p0.origin, p0.stride)], reqs_o)
+        got = gpu_ctx.plane_download(5, want.size)
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (len(bad), divmod(int(bad[0]) - p0.origin, p0.stride))
+    gpu_ctx.plane_release(5)

@@ -162,3 +162,17 @@ def test_distortions_match_reference_fixtures(oracle):
     got = oracle.cost_batch([p.as_tuple() for p in golden_planes()], g["reqs"])
     assert set(g["reqs"]["metric"]) == {0, 1, 2, 3}
     assert np.array_equal(got, g["costs"])
+
+
+def test_predictions_match_reference_fixtures(oracle):
+    """pred.npz: CRC32 of the destination plane after each batch of uni- / bi-directional predictions, by the
+    reference build"""
+    import zlib
+    from oracle import pyoracle
+    g = np.load(os.path.join(GOLD, "pred.npz"))
+    planes = golden_planes()
+    p0 = planes[0]
+    dst = np.full_like(p0.buf, 0x5A)
+    for reqs, want in zip(g["reqs"], g["crc"]):
+        oracle.predict_batch([p.as_tuple() for p in planes] + [(dst, p0.origin, p0.stride)], reqs.view(pyoracle.PRED_REQ))
+        assert zlib.crc32(dst.tobytes()) & 0xffffffff == int(want)

@@ -3,7 +3,7 @@ Skipped where oracle/_ref/libx265ref.so is absent (it is built only where /root/
 import numpy as np
 import pytest
 
-from conftest import random_bidir_reqs, random_lowres_jobs, random_me_jobs
+from conftest import random_bidir_reqs, random_lowres_jobs, random_me_jobs, random_pred_reqs
 from oracle import pyoracle
 
 pytestmark = pytest.mark.skipif(not pyoracle.have_ref(), reason="reference build not present")
@@ -155,3 +155,47 @@ def test_cost_requests_all_metrics(oracle, ref, small_seq):
     a, b = oracle.cost_batch(planes, reqs), ref.cost_batch(planes, reqs)
     bad = np.nonzero(a != b)[0]
     assert len(bad) == 0, (reqs[bad[0]], a[bad[0]], b[bad[0]])
+
+
+def test_mc_primitives(oracle, ref):
+    """luma_p2s, luma_vps, luma_vss, luma_hvpp, luma_addAvg: whole destination buffers compared"""
+    rng = np.random.default_rng(44)
+    src = rng.integers(0, 256, 200 * 200, dtype=np.uint8)
+    s16a = rng.integers(-12000, 14000, 200 * 200).astype(np.int16)
+    s16b = rng.integers(-12000, 14000, 200 * 200).astype(np.int16)
+    for (w, h) in ((4, 4), (16, 12), (64, 64), (24, 32)):
+        d1, d2 = np.full(80 * 80, 77, np.int16), np.full(80 * 80, 77, np.int16)
+        oracle.luma_p2s(src, 811, 150, d1, 5, w, h)
+        ref.luma_p2s(src, 811, 150, d2, 5, w, h)
+        assert np.array_equal(d1, d2)
+    for part in range(25):
+        for coeff in range(4):
+            d1, d2 = np.full(200 * 200, 77, np.int16), np.full(200 * 200, 77, np.int16)
+            oracle.luma_vps(part, src, 1807, 150, d1, 9, 71, coeff)
+            ref.luma_vps(part, src, 1807, 150, d2, 9, 71, coeff)
+            assert np.array_equal(d1, d2), (part, coeff)
+            oracle.luma_vss(part, s16a, 1807, 150, d1, 9, 71, coeff)
+            ref.luma_vss(part, s16a, 1807, 150, d2, 9, 71, coeff)
+            assert np.array_equal(d1, d2), (part, coeff)
+            p1, p2 = np.full(200 * 200, 0x5A, np.uint8), np.full(200 * 200, 0x5A, np.uint8)
+            oracle.luma_hvpp(part, src, 1807, 150, p1, 9, 71, coeff, 3 - coeff)
+            ref.luma_hvpp(part, src, 1807, 150, p2, 9, 71, coeff, 3 - coeff)
+            assert np.array_equal(p1, p2), (part, coeff)
+        p1, p2 = np.full(200 * 200, 0x5A, np.uint8), np.full(200 * 200, 0x5A, np.uint8)
+        oracle.luma_addavg(part, s16a, 3, s16b, 11, p1, 9, 64, 70, 81)
+        ref.luma_addavg(part, s16a, 3, s16b, 11, p2, 9, 64, 70, 81)
+        assert np.array_equal(p1, p2), part
+
+
+def test_predict_batch(oracle, ref, small_seq):
+    """xPredInterUni / xPredInterBi for luma into a destination plane: every partition and fraction pair"""
+    rng = np.random.default_rng(45)
+    p0 = small_seq[0]
+    planes = [p.as_tuple() for p in small_seq]
+    d1, d2 = np.full_like(p0.buf, 0x5A), np.full_like(p0.buf, 0x5A)
+    for _ in range(60):
+        reqs = random_pred_reqs(rng, p0.w, p0.h, pyoracle.PRED_REQ, pyoracle.PARTS, dst_plane=3)
+        oracle.predict_batch(planes + [(d1, p0.origin, p0.stride)], reqs)
+        ref.predict_batch(planes + [(d2, p0.origin, p0.stride)], reqs)
+        assert np.array_equal(d1, d2)
+    assert (d1 != 0x5A).any()

@@ -663,6 +663,45 @@ int x265_hip_dist_batch(x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n, i
     return X265_HIP_OK;
 }
 
+int x265_hip_predict_batch_device(x265_hip_ctx *c, const void *d_reqs, int n)
+{
+    if (!c || n < 0 || (n && !d_reqs))
+        return fail(X265_HIP_EINVAL, "predict_batch_device: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = push_tabs(c);
+    if (r)
+        return r;
+    LAUNCH(launch_predict(c->dev_tabs, (const x265_hip_pred_req *)d_reqs, n, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    return X265_HIP_OK;
+}
+
+int x265_hip_predict_batch(x265_hip_ctx *c, const x265_hip_pred_req *reqs, int n)
+{
+    if (!c || n < 0 || (n && !reqs))
+        return fail(X265_HIP_EINVAL, "predict_batch: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++)
+    {
+        const x265_hip_pred_req &q = reqs[i];
+        int r = check_block(c, q.dst_plane, q.ref0_plane, q.pu_w, q.pu_h, "pred_req", i);
+        if (r || (q.ref1_plane >= 0 && (r = check_block(c, q.dst_plane, q.ref1_plane, q.pu_w, q.pu_h, "pred_req", i))))
+            return r;
+        if (q.dst_plane == q.ref0_plane || q.dst_plane == q.ref1_plane)
+            return fail(X265_HIP_EINVAL, "pred_req[%d]: the destination plane is one of the references", i);
+    }
+    int r;
+    if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))))
+        return r;
+    HIP_TRY(hipMemcpyAsync(c->in.d, reqs, (size_t)n * sizeof(*reqs), hipMemcpyHostToDevice, c->stream));
+    LAUNCH(launch_predict(c->dev_tabs, (const x265_hip_pred_req *)c->in.d, n, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream)); // `reqs` is read by the copy until here
+    return X265_HIP_OK;
+}
+
 int x265_hip_bidir_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void *d_costs)
 {
     if (!c || n < 0 || (n && (!d_reqs || !d_costs)))

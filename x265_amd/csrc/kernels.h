@@ -62,6 +62,7 @@ void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x26
 #define X265HIP_COST_COUNTER_BYTES (2 * 64 * 64)
 void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, uint32_t *counters, int parity,
                  hipStream_t st);
+void launch_predict(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int n, uint32_t *counters, int parity, hipStream_t st);
 void launch_dist(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, uint32_t *counters, int parity,
                  hipStream_t st);
 void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out, uint32_t *counters, int parity,

@@ -191,7 +191,14 @@ __device__ __forceinline__ uint32_t pack2(int lo, int hi) { return (uint32_t)lo 
 // `diag` sends a half-fractional position through the diagonal path as well: with the tap row {0,0,0,64,...}
 // for the integer direction that path gives (64 S + 2048) >> 12 = (S + 32) >> 6, the hpp / vpp result, bit for
 // bit.  A wave whose lanes hold positions of different kinds then runs one path instead of three.
-template <int NT>
+//
+// SH = true produces the 14-bit intermediates of bi-prediction instead of pixels, as packed int16 pairs
+// (TComPrediction::xPredInterLumaBlk to a ShortYuv, TComPrediction.cpp:436-473): luma_p2s = (p << 6) - 8192,
+// luma_hps = sum - 8192, luma_vps = sum - 8192, luma_hps + luma_vss = (sum of intermediates * taps) >> 6
+// (ipfilter.cpp:38-54, 117-160, 204-239, 285-317); `diag` is not used with it.
+__device__ __forceinline__ uint32_t pack_s16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100); }
+
+template <int NT, bool SH = false>
 __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf, int yf, uint32_t P[4 * NT][2],
                                           bool diag = false)
 {
@@ -206,6 +213,12 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
             const uint32_t d = ld4g(r_ + y * stride);
             P[y][0] = __builtin_amdgcn_perm(0, d, 0x0c010c00);
             P[y][1] = __builtin_amdgcn_perm(0, d, 0x0c030c02);
+            if (SH)
+            {
+                const s16x2 offs = { 8192, 8192 };
+                P[y][0] = as_u32(as_s2(P[y][0] << 6) - offs);
+                P[y][1] = as_u32(as_s2(P[y][1] << 6) - offs);
+            }
         }
     }
     else if (yf == 0 && !diag)
@@ -220,6 +233,13 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
             uint32_t d0, d1, d2;
             ld12g(p, d0, d1, d2);
             p += stride;
+            if (SH)
+            {
+                tap8x4<0>(d0 ^ bias, d1 ^ bias, d2 ^ bias, tlo, thi, h);
+                P[y][0] = pack_s16(h[0], h[1]);
+                P[y][1] = pack_s16(h[2], h[3]);
+                continue;
+            }
             tap8x4<8192 + 32>(d0 ^ bias, d1 ^ bias, d2 ^ bias, tlo, thi, h);
 #pragma unroll
             for (int x = 0; x < 4; x++)
@@ -264,16 +284,21 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
 #pragma unroll
             for (int x = 0; x < 4; x++)
             {
-                tap8x4<8192 + 32>(c[x][t], c[x][t + 1], c[x][t + 2], tlo, thi, v[x]);
+                if (SH)
+                    tap8x4<0>(c[x][t], c[x][t + 1], c[x][t + 2], tlo, thi, v[x]);
+                else
+                {
+                    tap8x4<8192 + 32>(c[x][t], c[x][t + 1], c[x][t + 2], tlo, thi, v[x]);
 #pragma unroll
-                for (int y = 0; y < 4; y++)
-                    v[x][y] = clip_pixel(v[x][y] >> 6);
+                    for (int y = 0; y < 4; y++)
+                        v[x][y] = clip_pixel(v[x][y] >> 6);
+                }
             }
 #pragma unroll
             for (int y = 0; y < 4; y++)
             {
-                P[4 * t + y][0] = pack2(v[0][y], v[1][y]);
-                P[4 * t + y][1] = pack2(v[2][y], v[3][y]);
+                P[4 * t + y][0] = SH ? pack_s16(v[0][y], v[1][y]) : pack2(v[0][y], v[1][y]);
+                P[4 * t + y][1] = SH ? pack_s16(v[2][y], v[3][y]) : pack2(v[2][y], v[3][y]);
             }
         }
     }
@@ -287,7 +312,7 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
         const uint4 ve = *(const uint4 *)&k_vtaps_s16[yf][0], vo = *(const uint4 *)&k_vtaps_s16[yf][4];
         const uint32_t vo4 = k_vtaps_s16[yf][8];
         gptr_t p = r_ - 3 * stride - 3;
-        const int seed = 2048 + (8192 << 6);
+        constexpr int seed = SH ? 0 : 2048 + (8192 << 6);
         uint32_t q[NP][4];
         // pairs are produced in order and a pair of output rows is emitted as soon as its five pairs exist,
         // so only a window of five pairs is live at a time
@@ -318,6 +343,14 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
                     e[x] = sdot2(q[k + 3][x], ve.w, sdot2(q[k + 2][x], ve.z, sdot2(q[k + 1][x], ve.y, sdot2_first<seed>(q[k][x], ve.x))));
                     o[x] = sdot2(q[k + 4][x], vo4, sdot2(q[k + 3][x], vo.w, sdot2(q[k + 2][x], vo.z, sdot2(q[k + 1][x], vo.y, sdot2_first<seed>(q[k][x], vo.x)))));
                 }
+                if (SH)
+                {
+                    P[y][0] = pack_s16(e[0] >> 6, e[1] >> 6);
+                    P[y][1] = pack_s16(e[2] >> 6, e[3] >> 6);
+                    P[y + 1][0] = pack_s16(o[0] >> 6, o[1] >> 6);
+                    P[y + 1][1] = pack_s16(o[2] >> 6, o[3] >> 6);
+                    continue;
+                }
                 P[y][0] = pack2(clip_pixel(e[0] >> 12), clip_pixel(e[1] >> 12));
                 P[y][1] = pack2(clip_pixel(e[2] >> 12), clip_pixel(e[3] >> 12));
                 P[y + 1][0] = pack2(clip_pixel(o[0] >> 12), clip_pixel(o[1] >> 12));
@@ -325,6 +358,16 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
             }
         }
     }
+}
+
+// luma_addAvg (reference common/pixel.cpp:819-839) of two packed pairs of 14-bit intermediates: two pixels,
+// clip((a + b + 64 + 2 * 8192) >> 7), as a packed pair of pixels
+__device__ __forceinline__ uint32_t add_avg_pair(uint32_t a, uint32_t b)
+{
+    const uint32_t sel_lo = 0x00000001u, sel_hi = 0x00010000u; // (1, 0) and (0, 1) as int16 pairs
+    const int lo = sdot2(b, sel_lo, sdot2_first<64 + 2 * 8192>(a, sel_lo));
+    const int hi = sdot2(b, sel_hi, sdot2_first<64 + 2 * 8192>(a, sel_hi));
+    return pack2(clip_pixel(lo >> 7), clip_pixel(hi >> 7));
 }
 
 // one 4x4 tile

@@ -19,6 +19,8 @@
 // fetches or interpolates its reference tile in registers (me_device.h: full-pel, hpp, vpp, or
 // hps -> vsp over an 11x11 footprint), takes SAD or the 4x4 Hadamard against the PU's source tile
 // (LDS) and adds into the candidate's LDS slot.  Lane c meanwhile fetches candidate c's mv rate.
+#include <type_traits>
+
 #include "kernels.h"
 #include "me_device.h"
 
@@ -1200,6 +1202,19 @@ __device__ __forceinline__ int req_qy0(const x265_hip_cost_req &r) { return r.qm
 __device__ __forceinline__ int req_ref1(const x265_hip_cost_req &) { return 0; }
 __device__ __forceinline__ int req_qx1(const x265_hip_cost_req &) { return 0; }
 __device__ __forceinline__ int req_qy1(const x265_hip_cost_req &) { return 0; }
+__device__ __forceinline__ int req_fenc(const x265_hip_cost_req &r) { return r.fenc_plane; }
+__device__ __forceinline__ int req_fenc(const x265_hip_bidir_req &r) { return r.fenc_plane; }
+__device__ __forceinline__ int req_metric(const x265_hip_cost_req &r) { return r.metric; }
+__device__ __forceinline__ int req_metric(const x265_hip_bidir_req &r) { return r.metric; }
+// prediction requests: the "source" plane is the destination, there is no metric
+__device__ __forceinline__ int req_fenc(const x265_hip_pred_req &r) { return r.dst_plane; }
+__device__ __forceinline__ int req_metric(const x265_hip_pred_req &) { return 0; }
+__device__ __forceinline__ int req_ref0(const x265_hip_pred_req &r) { return r.ref0_plane; }
+__device__ __forceinline__ int req_qx0(const x265_hip_pred_req &r) { return r.qmv0_x; }
+__device__ __forceinline__ int req_qy0(const x265_hip_pred_req &r) { return r.qmv0_y; }
+__device__ __forceinline__ int req_ref1(const x265_hip_pred_req &r) { return r.ref1_plane; }
+__device__ __forceinline__ int req_qx1(const x265_hip_pred_req &r) { return r.qmv1_x; }
+__device__ __forceinline__ int req_qy1(const x265_hip_pred_req &r) { return r.qmv1_y; }
 __device__ __forceinline__ int req_ref0(const x265_hip_bidir_req &r) { return r.ref0_plane; }
 __device__ __forceinline__ int req_qx0(const x265_hip_bidir_req &r) { return r.qmv0_x; }
 __device__ __forceinline__ int req_qy0(const x265_hip_bidir_req &r) { return r.qmv0_y; }
@@ -1212,13 +1227,16 @@ __device__ __forceinline__ int req_qy1(const x265_hip_bidir_req &r) { return r.q
 // 1117-1141).  sa8d rounds once per 8x8 or once per 16x16 block, so those blocks' raw sums meet in a per-request
 // array of LDS accumulators (`units`) and are rounded when the batch is written out; a request's items start on
 // an even slot so that the two halves of an 8x8 block sit in lanes 2j and 2j + 1 (sa8d_strip).
-enum { MODE_COST = 0, MODE_BIDIR = 1, MODE_DIST = 2 };
+// MODE_PRED: requests are x265_hip_pred_req; nothing is compared, the predicted strips are stored into the
+// destination plane (uni-directional: the pixels of the other modes; bi-directional: luma_addAvg of the two
+// lists' 14-bit intermediates, info bit 19).
+enum { MODE_COST = 0, MODE_BIDIR = 1, MODE_DIST = 2, MODE_PRED = 3 };
 #define DIST_UNITS 16 // 64x64: sixteen 16x16 blocks; 32x24 / 24x32: twelve 8x8 blocks
 
 template <int MODE, typename Req>
 __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *reqs, int n, int32_t *out, uint32_t *counters, int parity)
 {
-    constexpr bool BIDIR = MODE == MODE_BIDIR, DIST = MODE == MODE_DIST;
+    constexpr bool BIDIR = MODE == MODE_BIDIR, DIST = MODE == MODE_DIST, PRED = MODE == MODE_PRED;
     __shared__ CostLds lds[4];
     __shared__ int count_lds[4][COST_BATCH];                              // items of a request (pre[] holds the padded count)
     __shared__ int units_lds[DIST ? 4 : 1][COST_BATCH * DIST_UNITS];
@@ -1257,7 +1275,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
         int ni = 0, nunits = 0;
         if (have)
         {
-            const PlaneDesc fp = planes[cur.fenc_plane], rp = planes[req_ref0(cur)];
+            const PlaneDesc fp = planes[req_fenc(cur)], rp = planes[req_ref0(cur)];
             const int tall = (cur.pu_h & 7) == 0;
             const int qx = req_qx0(cur), qy = req_qy0(cur);
             ni = (cur.pu_w >> 2) * (cur.pu_h >> (2 + tall));
@@ -1265,8 +1283,8 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
             L.ref[lane] = rp.origin + (long)(cur.pu_y + (qy >> 2)) * rp.stride + cur.pu_x + (qx >> 2);
             L.fstride[lane] = fp.stride;
             L.rstride[lane] = rp.stride;
-            int info = (cur.pu_w >> 2) | ((qx & 3) << 8) | ((qy & 3) << 10) | (cur.metric << 12) | (tall << 14);
-            if (DIST && cur.metric == X265_HIP_SA8D)
+            int info = (cur.pu_w >> 2) | ((qx & 3) << 8) | ((qy & 3) << 10) | (req_metric(cur) << 12) | (tall << 14);
+            if (DIST && req_metric(cur) == X265_HIP_SA8D)
             {
                 // the table of pixel.cpp:1117-1141: sa8d16<> / sa8d8<> / satd by the block's divisibility
                 const int kind = ((cur.pu_w | cur.pu_h) & 15) == 0 ? 2 : ((cur.pu_w | cur.pu_h) & 7) == 0 ? 1 : 0;
@@ -1277,8 +1295,10 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                     info |= (kind << 19) | (nux << 21);
                 }
             }
-            if (BIDIR)
+            if (BIDIR || (PRED && req_ref1(cur) >= 0))
             {
+                if (PRED)
+                    info |= 1 << 19;
                 const PlaneDesc rp1 = planes[req_ref1(cur)];
                 const int qx1 = req_qx1(cur), qy1 = req_qy1(cur);
                 L.ref1[lane] = rp1.origin + (long)(cur.pu_y + (qy1 >> 2)) * rp1.stride + cur.pu_x + (qx1 >> 2);
@@ -1346,6 +1366,42 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
             const int info = L.info[k], ntx = info & 255, fstride = L.fstride[k], rstride = L.rstride[k];
             const int xf = (info >> 8) & 3, yf = (info >> 10) & 3, metric = (info >> 12) & (DIST ? 3 : 1);
             const int ty = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)ntx)), tx = t - ty * ntx; // exact: t < 256, ntx <= 16
+            if (PRED)
+            {
+                // store a strip of the prediction: NT tiles of 4 rows
+                auto emit = [&](auto nt_tag) {
+                    constexpr int NT = decltype(nt_tag)::value, R = 4 * NT;
+                    uint8_t *dst = const_cast<uint8_t *>(L.fenc[k]) + R * ty * fstride + 4 * tx;
+                    const uint8_t *r0 = L.ref[k] + R * ty * rstride + 4 * tx;
+                    uint32_t pix[R][2];
+                    if ((info >> 19) & 1)
+                    {
+                        const int rs1 = L.rstride1[k];
+                        uint32_t pix1[R][2];
+                        ref_strip<NT, true>(r0, rstride, xf, yf, pix);
+                        ref_strip<NT, true>(L.ref1[k] + R * ty * rs1 + 4 * tx, rs1, (info >> 15) & 3, (info >> 17) & 3, pix1);
+#pragma unroll
+                        for (int y = 0; y < R; y++)
+                        {
+                            pix[y][0] = add_avg_pair(pix[y][0], pix1[y][0]);
+                            pix[y][1] = add_avg_pair(pix[y][1], pix1[y][1]);
+                        }
+                    }
+                    else
+                        ref_strip<NT>(r0, rstride, xf, yf, pix);
+#pragma unroll
+                    for (int y = 0; y < R; y++)
+                    {
+                        const uint32_t four = __builtin_amdgcn_perm(pix[y][1], pix[y][0], 0x06040200);
+                        __builtin_memcpy(dst + y * fstride, &four, 4);
+                    }
+                };
+                if ((info >> 14) & 1)
+                    emit(std::integral_constant<int, 2>());
+                else
+                    emit(std::integral_constant<int, 1>());
+                continue;
+            }
             int v;
             if ((info >> 14) & 1)
             {
@@ -1405,7 +1461,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
             atomicAdd(&L.cost[k], v);
         }
         wave_sync();
-        if (have)
+        if (have && !PRED)
         {
             int c = L.cost[lane];
             if (DIST)
@@ -1430,6 +1486,13 @@ __global__ __launch_bounds__(256) void bidir_cost_kernel(const DeviceTables *tab
     cost_body<MODE_BIDIR>(tabs, reqs, n, out, counters, parity);
 }
 
+// motion-compensated prediction into a destination plane (x265_hip_predict_batch)
+__global__ __launch_bounds__(256) void predict_kernel(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int n, uint32_t *counters,
+                                                      int parity)
+{
+    cost_body<MODE_PRED>(tabs, reqs, n, nullptr, counters, parity);
+}
+
 // cost requests whose metric may be any of sad, satd, sa8d_inter, sse_pp (x265_hip_dist_batch)
 __global__ __launch_bounds__(256) void dist_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out,
                                                    uint32_t *counters, int parity)
@@ -1449,6 +1512,15 @@ void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs,
     {
         const int blocks = ((n + COST_BATCH - 1) / COST_BATCH + 3) / 4;
         hipLaunchKernelGGL(bidir_cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity);
+    }
+}
+
+void launch_predict(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int n, uint32_t *counters, int parity, hipStream_t st)
+{
+    if (n > 0)
+    {
+        const int blocks = ((n + COST_BATCH - 1) / COST_BATCH + 3) / 4;
+        hipLaunchKernelGGL(predict_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, counters, parity);
     }
 }
 

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from .abi import BIDIR_REQ, COST_REQ, ME_JOB, ME_RESULT, NUM_PARTS
+from .abi import BIDIR_REQ, COST_REQ, ME_JOB, ME_RESULT, NUM_PARTS, PRED_REQ
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libx265_hip.so")
@@ -34,7 +34,7 @@ EXPORTS = [
     "x265_hip_plane_download", "x265_hip_lowres_geometry_of", "x265_hip_lowres_init",
     "x265_hip_plane_extend_border", "x265_hip_plane_weight",
     "x265_hip_bidir_cost_batch", "x265_hip_bidir_cost_batch_device",
-    "x265_hip_dist_batch", "x265_hip_dist_batch_device",
+    "x265_hip_dist_batch", "x265_hip_dist_batch_device", "x265_hip_predict_batch", "x265_hip_predict_batch_device",
 ]
 
 
@@ -195,6 +195,13 @@ class Context:
 
     def dist_batch_device(self, d_reqs, n, d_costs):
         _check(load().x265_hip_dist_batch_device(self._h, C.c_void_p(d_reqs), C.c_int(n), C.c_void_p(d_costs)))
+
+    def predict_batch(self, reqs):
+        reqs = np.ascontiguousarray(reqs, PRED_REQ)
+        _check(load().x265_hip_predict_batch(self._h, _p(reqs), C.c_int(len(reqs))))
+
+    def predict_batch_device(self, d_reqs, n):
+        _check(load().x265_hip_predict_batch_device(self._h, C.c_void_p(d_reqs), C.c_int(n)))
 
     def bidir_cost_batch(self, reqs):
         reqs = np.ascontiguousarray(reqs, BIDIR_REQ)
