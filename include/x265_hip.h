@@ -96,6 +96,14 @@ typedef void (*x265_hip_weightp_pp_t)(uint8_t *src, uint8_t *dst, intptr_t srcSt
 typedef void (*x265_hip_downscale_t)(uint8_t *src0, uint8_t *dstf, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc,
                                      intptr_t src_stride, intptr_t dst_stride, int width, int height);
 
+/* primitives.h:167, 169-171, 180 */
+typedef void (*x265_hip_filter_ps_t)(uint8_t *src, intptr_t srcStride, int16_t *dst, intptr_t dstStride, int coeffIdx);
+typedef void (*x265_hip_filter_ss_t)(int16_t *src, intptr_t srcStride, int16_t *dst, intptr_t dstStride, int coeffIdx);
+typedef void (*x265_hip_filter_hv_pp_t)(uint8_t *src, intptr_t srcStride, uint8_t *dst, intptr_t dstStride, int idxX, int idxY);
+typedef void (*x265_hip_filter_p2s_t)(uint8_t *src, intptr_t srcStride, int16_t *dst, int width, int height);
+typedef void (*x265_hip_addAvg_t)(int16_t *src0, int16_t *src1, uint8_t *dst, intptr_t src0Stride, intptr_t src1Stride,
+                                  intptr_t dstStride);
+
 /* the slice of EncoderPrimitives this library replaces; member names are the reference's */
 typedef struct x265_hip_primitives
 {
@@ -114,6 +122,12 @@ typedef struct x265_hip_primitives
     /* the distortions mode decision takes of a prediction */
     x265_hip_pixelcmp_t    sa8d_inter[X265_HIP_NUM_LUMA_PARTITIONS];  /* primitives.h:200; C: pixel.cpp:290-376, 1117-1141 */
     x265_hip_pixelcmp_t    sse_pp[X265_HIP_NUM_LUMA_PARTITIONS];      /* primitives.h:196; C: pixel.cpp:158-177, 1095 */
+    /* the rest of luma motion compensation (TComPrediction.cpp:400-473) */
+    x265_hip_filter_ps_t    luma_vps[X265_HIP_NUM_LUMA_PARTITIONS];    /* primitives.h:224; C: ipfilter.cpp:203-239 */
+    x265_hip_filter_ss_t    luma_vss[X265_HIP_NUM_LUMA_PARTITIONS];    /* primitives.h:226; C: ipfilter.cpp:284-317 */
+    x265_hip_filter_hv_pp_t luma_hvpp[X265_HIP_NUM_LUMA_PARTITIONS];   /* primitives.h:227; C: ipfilter.cpp:362-369 */
+    x265_hip_filter_p2s_t   luma_p2s;                                  /* primitives.h:228; C: ipfilter.cpp:37-54, 510 */
+    x265_hip_addAvg_t       luma_addAvg[X265_HIP_NUM_LUMA_PARTITIONS]; /* primitives.h:235; C: pixel.cpp:819-839 */
 } x265_hip_primitives;
 
 /* Replaces the assignments Setup_C_PixelPrimitives / Setup_C_IPFilterPrimitives make for these

@@ -45,8 +45,13 @@ void Setup_HIP_Primitives(EncoderPrimitives &p, x265_param *param, int device)
         p.pixelavg_pp[i] = (pixelavg_pp_t)t.pixelavg_pp[i];
         p.sa8d_inter[i] = (pixelcmp_t)t.sa8d_inter[i];
         p.sse_pp[i] = (pixelcmp_t)t.sse_pp[i];
+        p.luma_vps[i] = (filter_ps_t)t.luma_vps[i];
+        p.luma_vss[i] = (filter_ss_t)t.luma_vss[i];
+        p.luma_hvpp[i] = (filter_hv_pp_t)t.luma_hvpp[i];
+        p.luma_addAvg[i] = (addAvg_t)t.luma_addAvg[i];
     }
     /* the plane producers either side of the path (primitives.h:232, 257) */
+    p.luma_p2s = (filter_p2s_t)t.luma_p2s;
     p.weight_pp = (weightp_pp_t)t.weight_pp;
     p.frame_init_lowres_core = (downscale_t)t.frame_init_lowres_core;
 }

@@ -348,3 +348,40 @@ def test_predict_batch(gpu_ctx, oracle, small_seq):
         bad = np.nonzero(got != want)[0]
         assert len(bad) == 0, (len(bad), divmod(int(bad[0]) - p0.origin, p0.stride))
     gpu_ctx.plane_release(5)
+
+
+def test_primitive_table_mc_entries(oracle):
+    """luma_vps / luma_vss / luma_hvpp / luma_p2s / luma_addAvg of the function-pointer table: host pointers, odd
+    strides; whole destination buffers compared"""
+    import ctypes as C
+    from x265_amd import lib
+    t = lib.setup_primitives(0)
+    rng = np.random.default_rng(46)
+    src = rng.integers(0, 256, 200 * 200, dtype=np.uint8)
+    s16a = rng.integers(-12000, 14000, 200 * 200).astype(np.int16)
+    s16b = rng.integers(-12000, 14000, 200 * 200).astype(np.int16)
+
+    def addr(x, off=0):
+        return C.c_void_p(x.ctypes.data + off * x.itemsize)
+
+    for (w, h) in ((4, 4), (16, 12), (64, 64), (24, 32)):
+        d1, d2 = np.full(80 * 80, 77, np.int16), np.full(80 * 80, 77, np.int16)
+        t.luma_p2s(addr(src, 811), 150, addr(d1, 5), w, h)
+        oracle.luma_p2s(src, 811, 150, d2, 5, w, h)
+        assert np.array_equal(d1, d2), (w, h)
+    for part in range(25):
+        coeff = part % 4
+        d1, d2 = np.full(200 * 200, 77, np.int16), np.full(200 * 200, 77, np.int16)
+        t.luma_vps[part](addr(src, 1807), 150, addr(d1, 9), 71, coeff)
+        oracle.luma_vps(part, src, 1807, 150, d2, 9, 71, coeff)
+        assert np.array_equal(d1, d2), part
+        t.luma_vss[part](addr(s16a, 1807), 150, addr(d1, 9), 71, coeff)
+        oracle.luma_vss(part, s16a, 1807, 150, d2, 9, 71, coeff)
+        assert np.array_equal(d1, d2), part
+        p1, p2 = np.full(200 * 200, 0x5A, np.uint8), np.full(200 * 200, 0x5A, np.uint8)
+        t.luma_hvpp[part](addr(src, 1807), 150, addr(p1, 9), 71, 1 + coeff % 3, 3 - coeff % 3)
+        oracle.luma_hvpp(part, src, 1807, 150, p2, 9, 71, 1 + coeff % 3, 3 - coeff % 3)
+        assert np.array_equal(p1, p2), part
+        t.luma_addAvg[part](addr(s16a, 3), addr(s16b, 11), addr(p1, 9), 64, 70, 81)
+        oracle.luma_addavg(part, s16a, 3, s16b, 11, p2, 9, 64, 70, 81)
+        assert np.array_equal(p1, p2), part

@@ -893,24 +893,25 @@ int prim_cmp(int part, int metric, const uint8_t *fenc, intptr_t fstride, const 
 }
 
 // kind: PRIM_HPP / PRIM_VPP / PRIM_HPS / PRIM_VSP.  Writes exactly w x rows elements of dst.
-int prim_filter(int part, int kind, const void *src, intptr_t sstride, void *dst, intptr_t dstride, int coeff, int row_ext)
+int prim_filter_wh(int w, int rows, int kind, const void *src, intptr_t sstride, void *dst, intptr_t dstride, int coeff, int row_ext)
 {
     x265_hip_ctx *c = g_prim_ctx;
     if (!c)
         return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
     if (coeff < 0 || coeff > 3)
         return fail(X265_HIP_EINVAL, "coeffIdx %d out of range", coeff);
-    const int w = k_part_w[part];
-    int rows = k_part_h[part];
-    const int ses = kind == PRIM_VSP ? 2 : 1, des = kind == PRIM_HPS ? 2 : 1;
+    if (w <= 0 || rows <= 0)
+        return 0;
+    const int ses = kind == PRIM_VSP || kind == PRIM_VSS ? 2 : 1;
+    const int des = kind == PRIM_HPS || kind == PRIM_VPS || kind == PRIM_VSS || kind == PRIM_P2S ? 2 : 1;
     const uint8_t *sp = (const uint8_t *)src;
     if (kind == PRIM_HPS && row_ext)
     {
         sp -= 3 * sstride * ses; // luma_hps with isRowExt starts three rows up (ipfilter.cpp:128-132)
         rows += 7;
     }
-    const bool horiz = kind == PRIM_HPP || kind == PRIM_HPS;
-    const int pre_c = horiz ? 3 : 0, post_c = horiz ? 4 : 0, pre_r = horiz ? 0 : 3, post_r = horiz ? 0 : 4;
+    const bool horiz = kind == PRIM_HPP || kind == PRIM_HPS, vert = !horiz && kind != PRIM_P2S;
+    const int pre_c = horiz ? 3 : 0, post_c = horiz ? 4 : 0, pre_r = vert ? 3 : 0, post_r = vert ? 4 : 0;
     const int sw = w + pre_c + post_c, sr = rows + pre_r + post_r;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
@@ -945,6 +946,11 @@ int prim_filter(int part, int kind, const void *src, intptr_t sstride, void *dst
     for (int y = 0; y < rows; y++)
         memcpy((uint8_t *)dst + (size_t)y * dstride * des, (uint8_t *)c->prim_b.h + (size_t)y * w * des, (size_t)w * des);
     return 0;
+}
+
+int prim_filter(int part, int kind, const void *src, intptr_t sstride, void *dst, intptr_t dstride, int coeff, int row_ext)
+{
+    return prim_filter_wh(k_part_w[part], k_part_h[part], kind, src, sstride, dst, dstride, coeff, row_ext);
 }
 
 template <int P>
@@ -1031,6 +1037,37 @@ void t_vsp(int16_t *src, intptr_t ss, uint8_t *dst, intptr_t ds, int coeff)
         prim_fatal("luma_vsp");
 }
 
+template <int P>
+void t_vps(uint8_t *src, intptr_t ss, int16_t *dst, intptr_t ds, int coeff)
+{
+    if (prim_filter(P, PRIM_VPS, src, ss, dst, ds, coeff, 0))
+        prim_fatal("luma_vps");
+}
+
+template <int P>
+void t_vss(int16_t *src, intptr_t ss, int16_t *dst, intptr_t ds, int coeff)
+{
+    if (prim_filter(P, PRIM_VSS, src, ss, dst, ds, coeff, 0))
+        prim_fatal("luma_vss");
+}
+
+// luma_hvpp = luma_hps with the row extension into a block-wide buffer, then luma_vsp (ipfilter.cpp:362-369)
+template <int P>
+void t_hvpp(uint8_t *src, intptr_t ss, uint8_t *dst, intptr_t ds, int idx_x, int idx_y)
+{
+    static thread_local int16_t immed[64 * (64 + 8)];
+    const int w = k_part_w[P];
+    if (prim_filter(P, PRIM_HPS, src, ss, immed, w, idx_x, 1) || prim_filter(P, PRIM_VSP, immed + 3 * w, w, dst, ds, idx_y, 0))
+        prim_fatal("luma_hvpp");
+}
+
+// luma_p2s: the destination stride is MAX_CU_SIZE (filterConvertPelToShort_c<MAX_CU_SIZE>, ipfilter.cpp:510)
+void t_p2s(uint8_t *src, intptr_t ss, int16_t *dst, int width, int height)
+{
+    if (prim_filter_wh(width, height, PRIM_P2S, src, ss, dst, 64, 0, 0))
+        prim_fatal("luma_p2s");
+}
+
 // rows of `rowbytes` from host memory into the pinned mirror at `pitch`, then to the device
 int stage_rows(x265_hip_ctx *c, Buf &b, size_t off, const uint8_t *src, long sstride, int rowbytes, int rows, int pitch)
 {
@@ -1060,6 +1097,36 @@ int prim_avg(int part, uint8_t *dst, intptr_t ds, const uint8_t *s0, intptr_t ss
     for (int y = 0; y < h; y++)
         memcpy(dst + (long)y * ds, (uint8_t *)c->prim_b.h + (size_t)y * w, w);
     return 0;
+}
+
+int prim_addavg(int part, const int16_t *s0, const int16_t *s1, uint8_t *dst, intptr_t ss0, intptr_t ss1, intptr_t ds)
+{
+    x265_hip_ctx *c = g_prim_ctx;
+    if (!c)
+        return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
+    const int w = k_part_w[part], h = k_part_h[part];
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    const size_t blk = (size_t)w * h;
+    if ((r = ensure(c, c->prim_a, 4 * blk + 64)) || (r = ensure(c, c->prim_b, blk + 64)) ||
+        (r = stage_rows(c, c->prim_a, 0, (const uint8_t *)s0, 2 * ss0, 2 * w, h, 2 * w)) ||
+        (r = stage_rows(c, c->prim_a, 2 * blk, (const uint8_t *)s1, 2 * ss1, 2 * w, h, 2 * w)))
+        return r;
+    PrimAddAvgArgs a = { (const int16_t *)c->prim_a.d, (const int16_t *)c->prim_a.d + blk, (uint8_t *)c->prim_b.d, w, w, w, w, h };
+    LAUNCH(launch_prim_addavg(a, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->prim_b.h, c->prim_b.d, blk, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int y = 0; y < h; y++)
+        memcpy(dst + (long)y * ds, (uint8_t *)c->prim_b.h + (size_t)y * w, w);
+    return 0;
+}
+
+template <int P>
+void t_addavg(int16_t *s0, int16_t *s1, uint8_t *dst, intptr_t ss0, intptr_t ss1, intptr_t ds)
+{
+    if (prim_addavg(P, s0, s1, dst, ss0, ss1, ds))
+        prim_fatal("luma_addAvg");
 }
 
 int prim_weight(const uint8_t *src, uint8_t *dst, intptr_t ss, intptr_t ds, int width, int height, int w0, int round, int shift,
@@ -1167,6 +1234,10 @@ void fill(x265_hip_primitives *t)
     t->satd[P] = t_satd<P>;
     t->sa8d_inter[P] = t_sa8d_inter<P>;
     t->sse_pp[P] = t_sse_pp<P>;
+    t->luma_vps[P] = t_vps<P>;
+    t->luma_vss[P] = t_vss<P>;
+    t->luma_hvpp[P] = t_hvpp<P>;
+    t->luma_addAvg[P] = t_addavg<P>;
     t->luma_hpp[P] = t_hpp<P>;
     t->luma_hps[P] = t_hps<P>;
     t->luma_vpp[P] = t_vpp<P>;
@@ -1193,6 +1264,7 @@ int x265_hip_setup_primitives(x265_hip_primitives *table, int device)
         g_prim_ctx = c;
     }
     fill<0>(table);
+    table->luma_p2s = t_p2s;
     table->weight_pp = t_weight;
     table->frame_init_lowres_core = t_lowres;
     return X265_HIP_OK;

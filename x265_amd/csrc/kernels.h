@@ -10,7 +10,7 @@ namespace x265hip {
 
 struct DeviceTables;
 
-enum { PRIM_HPP = 0, PRIM_VPP = 1, PRIM_HPS = 2, PRIM_VSP = 3 };
+enum { PRIM_HPP = 0, PRIM_VPP = 1, PRIM_HPS = 2, PRIM_VSP = 3, PRIM_VPS = 4, PRIM_VSS = 5, PRIM_P2S = 6 };
 
 struct PrimCmpArgs
 {
@@ -22,8 +22,8 @@ struct PrimCmpArgs
 
 struct PrimFilterArgs
 {
-    const void *src; // uint8 for hpp/vpp/hps, int16 for vsp; points at output sample (0,0)'s source
-    void *dst;       // uint8 for hpp/vpp/vsp, int16 for hps
+    const void *src; // uint8 for hpp/vpp/hps/vps/p2s, int16 for vsp/vss; points at output sample (0,0)'s source
+    void *dst;       // uint8 for hpp/vpp/vsp, int16 for hps/vps/vss/p2s
     int sstride, dstride; // in elements
     int w, rows, coeff, kind;
 };
@@ -56,6 +56,15 @@ struct PrimAvgArgs
 };
 
 void launch_prim_avg(const PrimAvgArgs &a, hipStream_t st);
+
+struct PrimAddAvgArgs
+{
+    const int16_t *src0, *src1;
+    uint8_t *dst;
+    int sstride0, sstride1, dstride, w, h;
+};
+
+void launch_prim_addavg(const PrimAddAvgArgs &a, hipStream_t st);
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st);
 // `counters`: X265HIP_COST_COUNTER_BYTES of zeroed device memory owned by the context (two alternating sets of
 // batch counters); `parity` flips with every launch that shares them, and such launches are ordered on one stream

@@ -90,6 +90,29 @@ __global__ __launch_bounds__(256) void prim_filter_kernel(PrimFilterArgs a)
             acc += p[(long)k * a.sstride] * c[k];
         ((uint8_t *)a.dst)[(long)y * a.dstride + x] = (uint8_t)clip_pixel((acc + 32) >> 6);
     }
+    else if (a.kind == PRIM_VPS)
+    {
+        // luma_vps (ipfilter.cpp:203-239): shift 0, offset -8192
+        const uint8_t *p = (const uint8_t *)a.src + (long)(y - 3) * a.sstride + x;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            acc += p[(long)k * a.sstride] * c[k];
+        ((int16_t *)a.dst)[(long)y * a.dstride + x] = (int16_t)(acc - 8192);
+    }
+    else if (a.kind == PRIM_VSS)
+    {
+        // luma_vss (ipfilter.cpp:284-317): shift 6, no offset, narrowed to int16 as the reference does
+        const int16_t *p = (const int16_t *)a.src + (long)(y - 3) * a.sstride + x;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            acc += p[(long)k * a.sstride] * c[k];
+        ((int16_t *)a.dst)[(long)y * a.dstride + x] = (int16_t)(acc >> 6);
+    }
+    else if (a.kind == PRIM_P2S)
+    {
+        // luma_p2s (ipfilter.cpp:37-54)
+        ((int16_t *)a.dst)[(long)y * a.dstride + x] = (int16_t)((((const uint8_t *)a.src)[(long)y * a.sstride + x] << 6) - 8192);
+    }
     else // PRIM_VSP
     {
         const int16_t *p = (const int16_t *)a.src + (long)(y - 3) * a.sstride + x;
@@ -113,6 +136,21 @@ __global__ __launch_bounds__(256) void prim_avg_kernel(PrimAvgArgs a)
         return;
     const int y = idx / a.w, x = idx - y * a.w;
     a.dst[(long)y * a.dstride + x] = (uint8_t)((a.src0[(long)y * a.sstride0 + x] + a.src1[(long)y * a.sstride1 + x] + 1) >> 1);
+}
+
+// luma_addAvg on raw device pointers (reference common/pixel.cpp:819-839), one thread per sample
+__global__ __launch_bounds__(256) void prim_addavg_kernel(PrimAddAvgArgs a)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.w * a.h)
+        return;
+    const int y = idx / a.w, x = idx - y * a.w;
+    a.dst[(long)y * a.dstride + x] = (uint8_t)clip_pixel((a.src0[(long)y * a.sstride0 + x] + a.src1[(long)y * a.sstride1 + x] + 64 + 2 * 8192) >> 7);
+}
+
+void launch_prim_addavg(const PrimAddAvgArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(prim_addavg_kernel, dim3((a.w * a.h + 255) / 256), dim3(256), 0, st, a);
 }
 
 void launch_prim_avg(const PrimAvgArgs &a, hipStream_t st)

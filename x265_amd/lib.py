@@ -76,6 +76,10 @@ class Primitives(C.Structure):
     _avg = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int)
     _wpp = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
     _down = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int)
+    _ps = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int)
+    _hv = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int)
+    _p2s = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_int, C.c_int)
+    _aavg = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_ssize_t)
     _hps = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int)
     _fields_ = [
         ("sad", _cmp * NUM_PARTS), ("sad_x3", _x3 * NUM_PARTS), ("sad_x4", _x4 * NUM_PARTS),
@@ -83,6 +87,8 @@ class Primitives(C.Structure):
         ("luma_vpp", _pp * NUM_PARTS), ("luma_vsp", _pp * NUM_PARTS),
         ("pixelavg_pp", _avg * NUM_PARTS), ("weight_pp", _wpp), ("frame_init_lowres_core", _down),
         ("sa8d_inter", _cmp * NUM_PARTS), ("sse_pp", _cmp * NUM_PARTS),
+        ("luma_vps", _ps * NUM_PARTS), ("luma_vss", _ps * NUM_PARTS), ("luma_hvpp", _hv * NUM_PARTS), ("luma_p2s", _p2s),
+        ("luma_addAvg", _aavg * NUM_PARTS),
     ]
 
 
