@@ -46,7 +46,9 @@ with open(os.path.join(DST, f"{tag}_pmc_sq.csv"), "w") as f:
 fe, _ = pmc("pmc_fetch/**/*counter_collection.csv")
 wr, _ = pmc("pmc_write/**/*counter_collection.csv")
 traffic = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/prof_me.py (one 1080p picture: "
-                   "510 CTU full searches with one reference; 128700 motionEstimate calls, HEX subme 2, 3 references), mean per "
+                   "510 CTU full searches with one reference; 128700 motionEstimate calls, HEX subme 2, 3 references; the "
+                   "picture's 2.06 M sub-pel SATD candidates through cost_kernel and as sa8d through dist_kernel; one "
+                   "bi-directional prediction of the picture in 16x16 blocks), mean per "
                    "launch, KiB as reported.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane "
                    "streaming reads; fullsearch2_kernel stages with 16-B loads, so fetch_kib_corrected = 2 x raw for it; "
                    "me_kernel / cost_kernel read 4 B per lane (uncalibrated width): raw and 2 x raw are both given."}

@@ -11,6 +11,7 @@ Everything is resident in HBM before the timed region; times are HIP events on t
 import json
 import os
 import sys
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -24,8 +25,13 @@ PX_PEAK = 1.34e14    # measured byte-SAD pixel rate (profiles/r01_ubench_valu.tx
 
 
 def timed(ext, ctx, fn, reps):
-    fn()
-    ctx.sync()
+    # warm up for 30 ms of work: the clocks ramp under sustained load, a single call measures the ramp
+    t0 = time.perf_counter()
+    while True:
+        fn()
+        ctx.sync()
+        if time.perf_counter() - t0 > 0.03:
+            break
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(ext)
     for _ in range(reps):
@@ -174,6 +180,28 @@ def run(w, h, tag):
         ops = synth.satd_lane_ops(sel)
         res["dist_candidates"][name] = {"requests": len(sel), "ms": ms, "candidates_per_s": len(sel) / ms * 1e3,
                                         "frac_of_valu_peak": ops / ms * 1e3 / LANE_PEAK}
+    # motion-compensated prediction of a whole picture: x265_hip_predict_batch, the picture
+    # tiled by PUs of one size, quarter-pel diagonal vectors; destination = plane 8
+    dstp = synth.Plane(np.zeros((h, w), np.uint8))
+    ctx.plane_upload(8, dstp.buf, dstp.stride, dstp.origin)
+    res["predict"] = {}
+    for size in (8, 16, 64):
+        xs, ys = np.meshgrid(np.arange(0, w - size + 1, size), np.arange(0, h - size + 1, size))
+        pr = np.zeros(xs.size, abi.PRED_REQ)
+        pr["dst_plane"], pr["ref0_plane"], pr["ref1_plane"] = 8, 2, -1
+        pr["pu_x"], pr["pu_y"], pr["pu_w"], pr["pu_h"] = xs.ravel(), ys.ravel(), size, size
+        pr["qmv0_x"], pr["qmv0_y"], pr["qmv1_x"], pr["qmv1_y"] = 4 * mot[0][0] + 1, 4 * mot[0][1] + 3, 4 * mot[1][0] + 2, 4 * mot[1][1] + 1
+        for name, ref1 in (("uni", -1), ("bi", 1)):
+            pr["ref1_plane"] = ref1
+            d = torch.from_numpy(pr.view(np.uint8).copy()).to(dev)
+            ms = timed(ext, ctx, lambda: ctx.predict_batch_device(d.data_ptr(), len(pr)), 10)
+            px = float(len(pr)) * size * size
+            nref = 2 if ref1 >= 0 else 1
+            # interpolation lane-ops as in satd_lane_ops (diagonal) per list, + 4 per pixel for addAvg
+            ops = px * (nref * (8 * (size + 7) / size + 8 + 3) + (4 if nref == 2 else 0))
+            res["predict"][f"{name}_{size}x{size}"] = {"requests": len(pr), "us_per_picture": ms * 1e3, "pixels_per_s": px / ms * 1e3,
+                                                       "frac_of_valu_peak": ops / ms * 1e3 / LANE_PEAK,
+                                                       "hbm_GBps": (nref + 1) * px / ms * 1e3 / 1e9}
     ctx.close()
     return res
 

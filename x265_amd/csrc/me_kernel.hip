@@ -1154,8 +1154,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void me
     motion_estimate(wv, j, &out[id]);
 }
 
-// Cost requests in batches of 32 per wave.  Batches differ sevenfold in work when block sizes are mixed, so a
-// fixed stride leaves SIMDs idle at the end; instead the batches are dealt in chunks of COST_CHUNK, round-robin,
+// Cost requests in batches of `rb` (at most 32, see batch_requests) per wave.  Batches differ sevenfold in
+// work when block sizes are mixed, so a fixed stride leaves SIMDs idle at the end; instead the batches are dealt in chunks of COST_CHUNK, round-robin,
 // to up to COST_PARTS parts (so a list sorted by size loads every part alike), part p is served by the blocks
 // p, p + parts, ..., and their waves take the part's batches in order from its counter in device memory (one
 // counter for all waves would serialise: about 12 ns per atomic on one address).  The blocks of a part run on
@@ -1234,7 +1234,7 @@ enum { MODE_COST = 0, MODE_BIDIR = 1, MODE_DIST = 2, MODE_PRED = 3 };
 #define DIST_UNITS 16 // 64x64: sixteen 16x16 blocks; 32x24 / 24x32: twelve 8x8 blocks
 
 template <int MODE, typename Req>
-__device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *reqs, int n, int32_t *out, uint32_t *counters, int parity)
+__device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *reqs, int n, int32_t *out, uint32_t *counters, int parity, int rb)
 {
     constexpr bool BIDIR = MODE == MODE_BIDIR, DIST = MODE == MODE_DIST, PRED = MODE == MODE_PRED;
     __shared__ CostLds lds[4];
@@ -1250,7 +1250,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
     int *const count = count_lds[threadIdx.x >> 6];
     int *const units = units_lds[DIST ? threadIdx.x >> 6 : 0];
     const int lane = threadIdx.x & 63;
-    const int nbatch = (n + COST_BATCH - 1) / COST_BATCH;
+    const int nbatch = (n + rb - 1) / rb;
     const int parts = min((int)gridDim.x, COST_PARTS), part = blockIdx.x % parts;
     const int nwaves = 4 * (((int)gridDim.x - part + parts - 1) / parts); // waves serving this part
     // batch number j of this part is batch_of(j); hi = the first j whose batch lies past the list for sure
@@ -1262,16 +1262,16 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
         counters[((parity ^ 1) * COST_PARTS + threadIdx.x) * 16] = 0;
     int b = (blockIdx.x / parts) * 4 + (threadIdx.x >> 6);
     Req cur = {};
-    if (lane < COST_BATCH && b < hi && (long)batch_of(b) * COST_BATCH + lane < n)
-        cur = reqs[batch_of(b) * COST_BATCH + lane];
+    if (lane < rb && b < hi && (long)batch_of(b) * rb + lane < n)
+        cur = reqs[batch_of(b) * rb + lane];
     while (b < hi)
     {
         int nb = 0;
         if (lane == 0)
             nb = (int)atomicAdd(counter, 1u);
         nb = nwaves + uniform(nb);
-        const int base = batch_of(b) * COST_BATCH;
-        const bool have = lane < COST_BATCH && base + lane < n;
+        const int base = batch_of(b) * rb;
+        const bool have = lane < rb && base + lane < n;
         int ni = 0, nunits = 0;
         if (have)
         {
@@ -1338,12 +1338,12 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
         }
         // next batch's records: in flight during this batch's arithmetic
         {
-            const int nid = batch_of(nb) * COST_BATCH + lane;
-            if (lane < COST_BATCH && nb < hi && nid < n)
+            const int nid = batch_of(nb) * rb + lane;
+            if (lane < rb && nb < hi && nid < n)
                 cur = reqs[nid];
         }
         wave_sync();
-        const int total = small ? 64 : L.pre[COST_BATCH];
+        const int total = small ? 2 * rb : L.pre[COST_BATCH];
         for (int i = lane; i < total; i += 64)
         {
             int k, t;
@@ -1475,29 +1475,39 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void cost_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
-                                                                                           int32_t *out, uint32_t *counters, int parity)
+                                                                                           int32_t *out, uint32_t *counters, int parity, int rb)
 {
-    cost_body<MODE_COST>(tabs, reqs, n, out, counters, parity);
+    cost_body<MODE_COST>(tabs, reqs, n, out, counters, parity, rb);
 }
 
 __global__ __launch_bounds__(256) void bidir_cost_kernel(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out,
-                                                         uint32_t *counters, int parity)
+                                                         uint32_t *counters, int parity, int rb)
 {
-    cost_body<MODE_BIDIR>(tabs, reqs, n, out, counters, parity);
+    cost_body<MODE_BIDIR>(tabs, reqs, n, out, counters, parity, rb);
 }
 
 // motion-compensated prediction into a destination plane (x265_hip_predict_batch)
-__global__ __launch_bounds__(256) void predict_kernel(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int n, uint32_t *counters,
-                                                      int parity)
+__global__ __launch_bounds__(256) void predict_kernel(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int n, uint32_t *counters, int parity, int rb)
 {
-    cost_body<MODE_PRED>(tabs, reqs, n, nullptr, counters, parity);
+    cost_body<MODE_PRED>(tabs, reqs, n, nullptr, counters, parity, rb);
 }
 
 // cost requests whose metric may be any of sad, satd, sa8d_inter, sse_pp (x265_hip_dist_batch)
 __global__ __launch_bounds__(256) void dist_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out,
-                                                   uint32_t *counters, int parity)
+                                                   uint32_t *counters, int parity, int rb)
 {
-    cost_body<MODE_DIST>(tabs, reqs, n, out, counters, parity);
+    cost_body<MODE_DIST>(tabs, reqs, n, out, counters, parity, rb);
+}
+
+// Requests per batch: 32 for long lists; short lists get smaller batches so that there are still a couple of
+// thousand of them (a 1080p picture tiled by 64x64 blocks is 510 requests: sixteen waves' worth at 32 per batch,
+// while a batch of one such block is already two full passes of a wave).
+static int batch_requests(int n)
+{
+    int rb = COST_BATCH;
+    while (rb > 1 && (n + rb - 1) / rb < 2048)
+        rb >>= 1;
+    return rb;
 }
 
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st)
@@ -1510,8 +1520,8 @@ void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs,
 {
     if (n > 0)
     {
-        const int blocks = ((n + COST_BATCH - 1) / COST_BATCH + 3) / 4;
-        hipLaunchKernelGGL(bidir_cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity);
+        const int rb = batch_requests(n), blocks = ((n + rb - 1) / rb + 3) / 4;
+        hipLaunchKernelGGL(bidir_cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity, rb);
     }
 }
 
@@ -1519,8 +1529,8 @@ void launch_predict(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int
 {
     if (n > 0)
     {
-        const int blocks = ((n + COST_BATCH - 1) / COST_BATCH + 3) / 4;
-        hipLaunchKernelGGL(predict_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, counters, parity);
+        const int rb = batch_requests(n), blocks = ((n + rb - 1) / rb + 3) / 4;
+        hipLaunchKernelGGL(predict_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, counters, parity, rb);
     }
 }
 
@@ -1528,8 +1538,8 @@ void launch_dist(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
 {
     if (n > 0)
     {
-        const int blocks = ((n + COST_BATCH - 1) / COST_BATCH + 3) / 4;
-        hipLaunchKernelGGL(dist_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity);
+        const int rb = batch_requests(n), blocks = ((n + rb - 1) / rb + 3) / 4;
+        hipLaunchKernelGGL(dist_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity, rb);
     }
 }
 
@@ -1537,8 +1547,8 @@ void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
 {
     if (n > 0)
     {
-        const int blocks = ((n + COST_BATCH - 1) / COST_BATCH + 3) / 4;
-        hipLaunchKernelGGL(cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity);
+        const int rb = batch_requests(n), blocks = ((n + rb - 1) / rb + 3) / 4;
+        hipLaunchKernelGGL(cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity, rb);
     }
 }
 
