@@ -72,8 +72,8 @@ def valid_pus_per_ctu():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10)  # the clocks ramp under sustained load
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=100)  # the clocks ramp under sustained load: tens of ms
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames", type=int, default=4, help="pictures per rank kept resident (steps cycle over them)")
     args = ap.parse_args()

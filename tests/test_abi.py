@@ -83,14 +83,16 @@ def test_synth_search_range_matches_reference_rule():
 def test_hot_kernels_use_no_scratch(tmp_path):
     """the ME and full-search kernels must keep their state in registers: a struct that slips into scratch memory
     costs several KB of HBM writes per motionEstimate call (seen once: 120 bytes per lane, caught by WRITE_SIZE).
-    me_kernel and cost_kernel are built for six waves per SIMD (80 VGPRs) and may spill a handful of dwords, nothing more."""
+    me_kernel is built for six waves per SIMD (80 VGPRs) and may spill a handful of dwords, nothing more; the cost
+    kernels spill nothing (cost_kernel at six waves spilled 14 dwords, 100 MB of scratch writes per 1080p launch,
+    and was 8 % slower than at five waves without spills)."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     src = os.path.join(ROOT, "x265_amd", "csrc")
-    allowed = {"cost_kernel": 32, "me_kernel": 48}
+    allowed = {"me_kernel": 48}
     seen = set()
     for name in ("me_kernel.hip", "fullsearch.hip"):
         out = tmp_path / (name + ".s")
@@ -98,8 +100,8 @@ def test_hot_kernels_use_no_scratch(tmp_path):
                                os.path.join(src, name)], stderr=subprocess.DEVNULL)
         text = out.read_text()
         for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s*(\d+)", text):
-            kernel = next((k for k in ("me_kernel", "cost_kernel", "fullsearch2_kernel") if k in m.group(1)), None)
+            kernel = next((k for k in ("me_kernel", "cost_kernel", "dist_kernel", "predict_kernel", "fullsearch2_kernel") if k in m.group(1)), None)
             if kernel:
                 seen.add(kernel)
                 assert int(m.group(2)) <= allowed.get(kernel, 0), (kernel, m.group(2))
-    assert seen == {"me_kernel", "cost_kernel", "fullsearch2_kernel"}
+    assert seen == {"me_kernel", "cost_kernel", "dist_kernel", "predict_kernel", "fullsearch2_kernel"}

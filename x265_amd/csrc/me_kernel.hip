@@ -1474,7 +1474,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void cost_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void cost_kernel(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
                                                                                            int32_t *out, uint32_t *counters, int parity, int rb)
 {
     cost_body<MODE_COST>(tabs, reqs, n, out, counters, parity, rb);
