@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
-from conftest import random_bidir_reqs, random_lowres_jobs, random_me_jobs
+from conftest import random_bidir_reqs, random_cost_reqs, random_lowres_jobs, random_me_jobs, random_pred_reqs
 from oracle import pyoracle
 from x265_amd import abi, lib, synth
 
@@ -81,6 +81,22 @@ report("cost_batch", ctx.cost_batch(reqs), O.cost_batch(pl, reqs, nthreads=16), 
 
 br = random_bidir_reqs(rng, 2 * N, W, H, abi.BIDIR_REQ, abi.PARTS, planes=(1, 0, 2, 4))
 report("bidir_cost_batch", ctx.bidir_cost_batch(br), O.bidir_cost_batch(pl, br), br)
+# mode-decision distortions: all four comparisons, natural / flat / noise planes
+dr = random_cost_reqs(rng, 4 * N, W, H, abi.COST_REQ, abi.PARTS, metrics=(0, 1, 2, 2, 3, 3), planes=(1, (0, 2, 3, 4)))
+dr["fenc_plane"] = rng.choice([1, 4], len(dr))
+report("dist_batch", ctx.dist_batch(dr), O.cost_batch(pl, dr, nthreads=16), dr)
+# motion-compensated prediction: batches of non-overlapping blocks into plane 5, the whole plane compared
+dst = np.full_like(planes[0].buf, 0x5A)
+ctx.plane_upload(5, dst, planes[0].stride, planes[0].origin)
+npred, nbad = 0, 0
+for _ in range(max(10, N // 200)):
+    pr = random_pred_reqs(rng, W, H, abi.PRED_REQ, abi.PARTS, dst_plane=5, refs=(0, 2, 4))
+    ctx.predict_batch(pr)
+    O.predict_batch(pl + [(dst, planes[0].origin, planes[0].stride)], pr)
+    nbad += int((ctx.plane_download(5, dst.size) != dst).sum())
+    npred += len(pr)
+bad_total += nbad
+print(f"{'predict_batch (bytes of the plane)':34s} n={npred:7d} mismatches={nbad}", flush=True)
 # CTU full search: random windows (every width / height up to 132), predictors and QPs; natural, flat, noise
 from concurrent.futures import ThreadPoolExecutor
 nctu = max(50, N // 400)
