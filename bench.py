@@ -12,6 +12,9 @@ in HBM.  Two more timed legs (reported in extra keys) run on the same pictures: 
 replay (HEX, subme 2, merange 57, 3 references: configs[2]) and the SATD sub-pel candidate set (every
 square PU x 3 references x 16 half-/quarter-pel candidates through 8-tap interpolation + SATD).
 
+Unless --no-4k is given the same three legs are also run on one 4K picture (configs[3]) and reported under
+`uhd` (kernel times, per GPU; not part of `value`).
+
 For N > 1 the driver launches one rank per GPU; ranks take disjoint GOP segments of the
 sequence (no collective on the data path) and the job-wide rate is units / max-over-ranks time.
 """
@@ -33,8 +36,9 @@ LANE_PEAK = 3.93e13   # integer VALU lane-ops/s: 256 CU x 4 SIMD x 16 lanes x 2.
 HBM_PEAK = 8000.0     # GB/s
 
 
-def build_ctu_jobs(seq, cur, ref, fenc_plane, ref_plane, qp=30):
+def build_ctu_jobs(seq, cur, ref, fenc_plane, ref_plane, qp=30, size=None):
     from x265_amd import lib, synth
+    W, H = size or (globals()["W"], globals()["H"])
     ncx, ncy = synth.ctu_grid(W, H)
     dx, dy = seq.global_motion(cur, ref)
     jobs = np.zeros(ncx * ncy, lib.CTU_JOB)
@@ -53,9 +57,10 @@ def build_ctu_jobs(seq, cur, ref, fenc_plane, ref_plane, qp=30):
     return jobs
 
 
-def valid_pus_per_ctu():
+def valid_pus_per_ctu(size=None):
     """number of square PUs wholly inside the picture, per CTU in raster order"""
     from x265_amd import synth
+    W, H = size or (globals()["W"], globals()["H"])
     ncx, ncy = synth.ctu_grid(W, H)
     out = np.zeros(ncx * ncy, np.int64)
     for cy in range(ncy):
@@ -75,6 +80,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=100)  # the clocks ramp under sustained load: tens of ms
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-4k", action="store_true", help="skip the extra 4K legs (reported under the key uhd)")
     ap.add_argument("--frames", type=int, default=4, help="pictures per rank kept resident (steps cycle over them)")
     args = ap.parse_args()
 
@@ -197,6 +203,57 @@ def main():
     sp_cands = sum(a[0] for a in acc_sp)
     sp_lane_ops = sum(a[1] for a in acc_sp)
 
+    # ---- the same three legs on one 4K picture (BASELINE configs[3]); extra information, outside `value` ----
+    uhd = None
+    if not args.no_4k:
+        UW, UH = 3840, 2160
+        useq = synth.Sequence(UW, UH, seed=0x265)
+        ubase = 16  # plane ids 16 .. 19
+        for i in range(4):
+            p = synth.Plane(useq.frame(first + i))
+            ctx.plane_upload(ubase + i, p.buf, p.stride, p.origin)
+        urefs = [2, 1, 0]
+        umot = [useq.global_motion(first + 3, first + r) for r in urefs]
+        uvp = valid_pus_per_ctu((UW, UH))
+        uj = build_ctu_jobs(useq, first + 3, first + 2, ubase + 3, ubase + 2, size=(UW, UH))
+        unpos = (uj["mvmax_x"].astype(np.int64) - uj["mvmin_x"] + 1) * (uj["mvmax_y"].astype(np.int64) - uj["mvmin_y"] + 1)
+        umj = synth.me_jobs(UW, UH, 3, urefs, umot, method=abi.HEX, subme=2, merange=57, seed=first + 3)
+        urq = synth.subpel_requests(UW, UH, 3, urefs, umot)
+        for a in (umj, urq):
+            a["fenc_plane"] += ubase
+            a["ref_plane"] += ubase
+        d_fs, d_me, d_sp = (torch.from_numpy(a.view(np.uint8).copy()).to(dev) for a in (uj, umj, urq))
+        o_fs = torch.empty(len(uj) * lib.PUS_PER_CTU * 8, dtype=torch.uint8, device=dev)
+        o_me = torch.empty(len(umj) * 8, dtype=torch.uint8, device=dev)
+        o_sp = torch.empty(len(urq), dtype=torch.int32, device=dev)
+
+        def leg(fn, reps=20):
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.05:  # warm-up by time: the clocks ramp under sustained load
+                fn()
+                ctx.sync()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(ext)
+            for _ in range(reps):
+                fn()
+            e1.record(ext)
+            ctx.sync()
+            return e0.elapsed_time(e1) / reps
+
+        ms_fs = leg(lambda: ctx.fullsearch_device(d_fs.data_ptr(), len(uj), o_fs.data_ptr()))
+        ms_me = leg(lambda: ctx.me_batch_device(d_me.data_ptr(), len(umj), o_me.data_ptr()))
+        ms_sp = leg(lambda: ctx.cost_batch_device(d_sp.data_ptr(), len(urq), o_sp.data_ptr()))
+        uops = synth.satd_lane_ops(urq)
+        uhd = {"workload": "configs[3]: one 3840x2160 picture per step and GPU, same three legs, 3 references for the ME legs; "
+                           "kernel time (HIP events), per GPU",
+               "fullsearch": {"candidates_per_s": float((unpos * uvp).sum()) / ms_fs * 1e3, "ms_per_picture_per_ref": ms_fs,
+                              "frac_of_sad_roof": float(unpos.sum()) * 4096 / (ms_fs * 1e-3) / PX_PEAK},
+               "me_stage": {"frames_per_s": 1e3 / ms_me, "ms_per_frame": ms_me, "me_calls_per_s": len(umj) / ms_me * 1e3},
+               "satd_candidates": {"candidates_per_s": len(urq) / ms_sp * 1e3, "ms_per_frame": ms_sp,
+                                   "frac_of_valu_peak": uops / (ms_sp * 1e-3) / LANE_PEAK}}
+        for i in range(4):
+            ctx.plane_release(ubase + i)
+
     # ---- CPU baseline: the reference's own C primitives (oracle/_ref) when present, else the port ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -276,6 +333,8 @@ def main():
                          "hbm": {"achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
                                  "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK}},
         }
+        if uhd:
+            line["uhd"] = uhd
         if cpu:
             line["cpu_baseline"] = cpu
             line["me_stage"]["cpu_baseline"] = cpu_me
