@@ -145,7 +145,12 @@ int x265_hip_partition_from_sizes(int width, int height);
 int x265_hip_register_host_plane(const uint8_t *host_base, size_t bytes);
 int x265_hip_unregister_host_plane(const uint8_t *host_base);
 
-/* ---- (2) batched level ------------------------------------------------------------------------ */
+/* ---- (2) batched level ------------------------------------------------------------------------
+ * The entry points that take host arrays validate every record before anything is launched: plane ids,
+ * partition sizes, metric / method / QP, and that every sample a request can reach (block, displacement or
+ * search window, the 8-tap filters' margins) lies inside the plane's buffer; X265_HIP_EINVAL / X265_HIP_ERANGE
+ * name the first offending record.  The `_device` forms cannot look at the records: for them the same
+ * conditions are the caller's contract (a record that reaches outside a buffer faults the GPU). */
 
 /* A plane is a padded luma picture in the layout of the reference's TComPicYuv
  * (source/Lib/TLibCommon/TComPicYuv.cpp:78-97): `origin_offset` is the byte offset of picture

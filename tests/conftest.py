@@ -72,8 +72,9 @@ def random_me_jobs(rng, n, method, subme, W, H, dtype, search_range, parts, mera
         else:
             px, py = 4 * int(rng.integers(-8, 8)), 4 * int(rng.integers(-8, 8))
         j["qmvp_x"], j["qmvp_y"] = px, py
-        cx, cy = (x // 64) * 64, (y // 64) * 64
-        lox, loy, hix, hiy = search_range(np.int64(px), np.int64(py), mer, cx, cy, W, H)
+        # clipMv is relative to the block searched (TComDataCU.cpp:2502-2514), which keeps every candidate inside
+        # the reference's margins; ranges taken relative to a CTU origin would let blocks low in the CTU leave them
+        lox, loy, hix, hiy = search_range(np.int64(px), np.int64(py), mer, x, y, W, H)
         j["mvmin_x"], j["mvmin_y"], j["mvmax_x"], j["mvmax_y"] = lox, loy, hix, hiy
         nm = int(rng.integers(0, 6))
         j["num_mvc"] = nm

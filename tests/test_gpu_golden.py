@@ -182,3 +182,22 @@ def test_bad_arguments_are_rejected(gpu_ctx):
     rq["metric"] = 4
     with pytest.raises(lib.X265HipError):
         gpu_ctx.dist_batch(rq)
+    # requests that would read outside a plane's buffer are refused on the host (they would fault the GPU)
+    rq["metric"] = abi.SAD
+    rq["qmv_y"] = -4 * 200
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.cost_batch(rq)
+    rq["qmv_y"], rq["pu_x"] = 0, 3000
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.cost_batch(rq)
+    jobs["qp"], jobs["mvmin_y"], jobs["mvmax_y"] = 30, -500, 4
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.me_batch(jobs)
+    cj["mvmax_x"], cj["mvmin_y"], cj["mvmax_y"] = 3, -120, 3
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.fullsearch(cj)  # CTU (0, 0) with a window 120 rows up: above the 80-row margin, outside the buffer
+    pr = np.zeros(1, abi.PRED_REQ)
+    pr["dst_plane"], pr["ref0_plane"], pr["ref1_plane"], pr["pu_w"], pr["pu_h"] = 2, 0, -1, 16, 16
+    pr["pu_y"] = 400
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.predict_batch(pr)  # destination block below the padded plane

@@ -5,6 +5,7 @@
 // The primitive-level thunks share one process-wide context and serialise on its mutex.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <math.h>
 #include <mutex>
 #include <new>
@@ -512,6 +513,39 @@ static int check_block(const x265_hip_ctx *c, int fp, int rp, int w, int h, cons
     return 0;
 }
 
+// Every byte a kernel may read for picture samples [x0, x1) x [y0, y1) of plane `id` (the caller has added the
+// displacement; this adds the 8-tap filters' 3 before / 4 after and the aligned 16-byte loads' overhang) must lie
+// inside the plane's buffer (+ the 16 readable bytes behind it, see x265_hip_plane_bind).  A request that
+// reaches outside would fault the GPU, so it is refused here.
+static int check_reach(const x265_hip_ctx *c, int id, long x0, long y0, long x1, long y1, const char *what, int i)
+{
+    const PlaneDesc &p = c->host_tabs.planes[id];
+    const long first = c->plane_origin[id] + (y0 - 3) * p.stride + (x0 - 3 - 3);
+    const long last = c->plane_origin[id] + (y1 + 4 - 1) * p.stride + (x1 + 4 + 12);
+    if (first < 0 || last > (long)c->plane_bytes[id] + 16)
+        return fail(X265_HIP_ERANGE, "%s[%d]: samples [%ld, %ld) x [%ld, %ld) of plane %d (with filter margins) lie outside its buffer",
+                    what, i, x0, x1, y0, y1, id);
+    return 0;
+}
+
+// the block itself, exactly (source blocks, prediction destinations)
+static int check_inside(const x265_hip_ctx *c, int id, int x, int y, int w, int h, const char *what, int i)
+{
+    const PlaneDesc &p = c->host_tabs.planes[id];
+    const long first = c->plane_origin[id] + (long)y * p.stride + x;
+    const long last = c->plane_origin[id] + (long)(y + h - 1) * p.stride + x + w;
+    if (first < 0 || last > (long)c->plane_bytes[id] || x + w > p.stride)
+        return fail(X265_HIP_ERANGE, "%s[%d]: block %dx%d at (%d, %d) lies outside plane %d", what, i, w, h, x, y, id);
+    return 0;
+}
+
+// a cost / distortion / prediction operand: the block displaced by a quarter-pel vector
+static int check_displaced(const x265_hip_ctx *c, int id, int x, int y, int w, int h, int qx, int qy, const char *what, int i)
+{
+    const long bx = x + (qx >> 2), by = y + (qy >> 2);
+    return check_reach(c, id, bx, by, bx + w, by + h, what, i);
+}
+
 static int check_jobs(const x265_hip_ctx *c, const x265_hip_me_job *jobs, int n)
 {
     for (int i = 0; i < n; i++)
@@ -539,6 +573,13 @@ static int check_jobs(const x265_hip_ctx *c, const x265_hip_me_job *jobs, int n)
             return fail(X265_HIP_EINVAL, "me_job[%d]: no cost table uploaded for qp %d", i, j.qp);
         if (j.mvmin_x > j.mvmax_x || j.mvmin_y > j.mvmax_y)
             return fail(X265_HIP_EINVAL, "me_job[%d]: empty search range", i);
+        // reach: the window, one sample around it for the sub-pel refinement, and the zero vector with its diamond
+        // (motion.cpp:570-578, 707-712), which the reference tests without a range check
+        const long lox = std::min<long>(j.mvmin_x, 0) - 1, hix = std::max<long>(j.mvmax_x, 0) + 1;
+        const long loy = std::min<long>(j.mvmin_y, 0) - 1, hiy = std::max<long>(j.mvmax_y, 0) + 1;
+        if ((r = check_inside(c, j.fenc_plane, j.pu_x, j.pu_y, j.pu_w, j.pu_h, "me_job", i)) ||
+            (r = check_reach(c, j.ref_plane, j.pu_x + lox, j.pu_y + loy, j.pu_x + hix + j.pu_w, j.pu_y + hiy + j.pu_h, "me_job", i)))
+            return r;
     }
     return 0;
 }
@@ -608,6 +649,10 @@ int x265_hip_cost_batch(x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n, i
             return r;
         if (reqs[i].metric > X265_HIP_SATD)
             return fail(X265_HIP_EINVAL, "cost_req[%d]: unknown metric %d", i, reqs[i].metric);
+        if ((r = check_inside(c, reqs[i].fenc_plane, reqs[i].pu_x, reqs[i].pu_y, reqs[i].pu_w, reqs[i].pu_h, "cost_req", i)) ||
+            (r = check_displaced(c, reqs[i].ref_plane, reqs[i].pu_x, reqs[i].pu_y, reqs[i].pu_w, reqs[i].pu_h, reqs[i].qmv_x,
+                                 reqs[i].qmv_y, "cost_req", i)))
+            return r;
     }
     int r;
     if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))) ||
@@ -650,6 +695,10 @@ int x265_hip_dist_batch(x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n, i
             return r;
         if (reqs[i].metric > X265_HIP_SSE)
             return fail(X265_HIP_EINVAL, "dist_req[%d]: unknown metric %d", i, reqs[i].metric);
+        if ((r = check_inside(c, reqs[i].fenc_plane, reqs[i].pu_x, reqs[i].pu_y, reqs[i].pu_w, reqs[i].pu_h, "dist_req", i)) ||
+            (r = check_displaced(c, reqs[i].ref_plane, reqs[i].pu_x, reqs[i].pu_y, reqs[i].pu_w, reqs[i].pu_h, reqs[i].qmv_x,
+                                 reqs[i].qmv_y, "dist_req", i)))
+            return r;
     }
     int r;
     if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))) ||
@@ -692,6 +741,11 @@ int x265_hip_predict_batch(x265_hip_ctx *c, const x265_hip_pred_req *reqs, int n
             return r;
         if (q.dst_plane == q.ref0_plane || q.dst_plane == q.ref1_plane)
             return fail(X265_HIP_EINVAL, "pred_req[%d]: the destination plane is one of the references", i);
+        if ((r = check_inside(c, q.dst_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, "pred_req", i)) ||
+            (r = check_displaced(c, q.ref0_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv0_x, q.qmv0_y, "pred_req", i)) ||
+            (q.ref1_plane >= 0 &&
+             (r = check_displaced(c, q.ref1_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv1_x, q.qmv1_y, "pred_req", i))))
+            return r;
     }
     int r;
     if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))))
@@ -730,6 +784,11 @@ int x265_hip_bidir_cost_batch(x265_hip_ctx *c, const x265_hip_bidir_req *reqs, i
             return r;
         if (reqs[i].metric > X265_HIP_SATD)
             return fail(X265_HIP_EINVAL, "bidir_req[%d]: unknown metric %d", i, reqs[i].metric);
+        const x265_hip_bidir_req &q = reqs[i];
+        if ((r = check_inside(c, q.fenc_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, "bidir_req", i)) ||
+            (r = check_displaced(c, q.ref0_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv0_x, q.qmv0_y, "bidir_req", i)) ||
+            (r = check_displaced(c, q.ref1_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv1_x, q.qmv1_y, "bidir_req", i)))
+            return r;
     }
     int r;
     if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))) ||
@@ -776,6 +835,10 @@ int x265_hip_fullsearch(x265_hip_ctx *c, const x265_hip_ctu_job *jobs, int n, x2
             return fail(X265_HIP_EINVAL, "ctu_job[%d]: empty search range", i);
         if (j.mvmax_x - j.mvmin_x > 131 || j.mvmax_y - j.mvmin_y > 131)
             return fail(X265_HIP_ERANGE, "ctu_job[%d]: window wider than 132 positions", i);
+        if ((r = check_inside(c, j.fenc_plane, j.ctu_x, j.ctu_y, 64, 64, "ctu_job", i)) ||
+            (r = check_reach(c, j.ref_plane, j.ctu_x + j.mvmin_x, j.ctu_y + j.mvmin_y, j.ctu_x + j.mvmax_x + 64,
+                             j.ctu_y + j.mvmax_y + 64, "ctu_job", i)))
+            return r;
     }
     const size_t ob = (size_t)n * X265_HIP_PUS_PER_CTU * sizeof(*results);
     int r;
