@@ -239,10 +239,14 @@ typedef struct x265_hip_bidir_req
     int32_t ref0_plane, ref1_plane;
     int16_t pu_x, pu_y;
     uint8_t pu_w, pu_h; /* one of the 25 partitions */
-    uint8_t metric;     /* X265_HIP_SAD / X265_HIP_SATD */
+    uint8_t metric;     /* X265_HIP_SAD / X265_HIP_SATD, optionally | X265_HIP_LOWRES_REF (below) */
     uint8_t pad;
     int16_t qmv0_x, qmv0_y, qmv1_x, qmv1_y;
 } x265_hip_bidir_req;
+/* With X265_HIP_LOWRES_REF in `metric` the request is the lookahead's bidirectional cost (EstimateRow::
+ * estimateCUCost, source/encoder/slicetype.cpp:1585-1603): ref0_plane .. +3 and ref1_plane .. +3 are the
+ * lowresPlane[0..3] of two Lowres references, the block is an 8x8 CU of the lowres source picture, the two
+ * predictions are ReferencePlanes::lowresMC (common/lowres.h:53-73) and the average is pixelavg_pp[LUMA_8x8]. */
 
 int x265_hip_bidir_cost_batch(x265_hip_ctx *ctx, const x265_hip_bidir_req *reqs, int n, int32_t *costs);
 int x265_hip_bidir_cost_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs);

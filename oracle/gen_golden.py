@@ -143,6 +143,10 @@ def gen_lowres(R):
     p = planes[0]
     wcrc = np.array([crc(R.weighted_plane(p.buf, p.origin, p.stride, p.w, p.h, int(a), int(b), int(c))) for a, b, c in wcases],
                     np.uint32)
+    # the lookahead's bidirectional cost on the lowres planes (slicetype.cpp:1585-1603)
+    from conftest import random_lowres_bidir_reqs
+    lbr = random_lowres_bidir_reqs(np.random.default_rng(82), 400, size[0], size[1], pyoracle.BIDIR_REQ)
+    np.savez_compressed(os.path.join(OUT, "lowres_bidir.npz"), reqs=lbr, costs=R.bidir_cost_batch(low, lbr))
     np.savez_compressed(os.path.join(OUT, "lowres.npz"), jobs=jobs, results=res, size=np.array(size, np.int32),
                         plane_crc=np.array([crc(b) for (b, _, _) in low], np.uint32), weight_cases=wcases, weight_crc=wcrc, bidir_reqs=breqs, bidir_costs=bres)
 

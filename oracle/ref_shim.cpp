@@ -252,6 +252,26 @@ void x265r_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *re
     {
         const x265o_bidir_req *r = &reqs[i];
         const x265o_plane &f = planes[r->fenc_plane], &a = planes[r->ref0_plane], &b = planes[r->ref1_plane];
+        if (r->metric & X265O_LOWRES_REF)
+        {
+            /* EstimateRow::estimateCUCost, slicetype.cpp:1585-1595, on the reference's ReferencePlanes::lowresMC */
+            ReferencePlanes r0, r1;
+            for (int k = 0; k < 4; k++)
+            {
+                r0.lowresPlane[k] = (pixel *)planes[r->ref0_plane + k].origin;
+                r1.lowresPlane[k] = (pixel *)planes[r->ref1_plane + k].origin;
+            }
+            r0.lumaStride = (int)a.stride;
+            r1.lumaStride = (int)b.stride;
+            pixel buf0[64], buf1[64], ref[64];
+            intptr_t s0 = 8, s1 = 8;
+            pixel *src0 = r0.lowresMC(r->pu_x + (intptr_t)r->pu_y * a.stride, MV(r->qmv0_x, r->qmv0_y), buf0, s0);
+            pixel *src1 = r1.lowresMC(r->pu_x + (intptr_t)r->pu_y * b.stride, MV(r->qmv1_x, r->qmv1_y), buf1, s1);
+            g_c.pixelavg_pp[LUMA_8x8](ref, 8, src0, s0, src1, s1, 32);
+            pixel *fe8 = (pixel *)f.origin + r->pu_x + (intptr_t)r->pu_y * f.stride;
+            out[i] = (r->metric & 1) ? g_c.satd[LUMA_8x8](fe8, f.stride, ref, 8) : g_c.sad[LUMA_8x8](fe8, f.stride, ref, 8);
+            continue;
+        }
         int part = partitionFromSizes(r->pu_w, r->pu_h);
         ref_predict_luma(part, r->pu_w, (pixel *)a.origin + r->pu_x + (intptr_t)r->pu_y * a.stride, a.stride, r->qmv0_x, r->qmv0_y, p0);
         ref_predict_luma(part, r->pu_w, (pixel *)b.origin + r->pu_x + (intptr_t)r->pu_y * b.stride, b.stride, r->qmv1_x, r->qmv1_y, p1);

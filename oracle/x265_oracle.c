@@ -1267,11 +1267,53 @@ void x265o_predict_batch(const x265o_plane *planes, const x265o_pred_req *reqs, 
     }
 }
 
+/* ref: ReferencePlanes::lowresMC, common/lowres.h:53-73: the half-pel plane the vector selects, or the rounded
+ * average of two of them for quarter-pel vectors (always an 8x8 block) */
+static const uint8_t *lowres_mc(const x265o_plane *four, int x, int y, int qx, int qy, uint8_t *buf, intptr_t *stride)
+{
+    intptr_t ls = four[0].stride;
+    intptr_t off = x + (intptr_t)y * ls;
+    if ((qx | qy) & 1)
+    {
+        int hpelA = (qy & 2) | ((qx & 2) >> 1);
+        const uint8_t *a = four[hpelA].origin + off + (qx >> 2) + (qy >> 2) * ls;
+        int bx = s16(qx + (qx & 1) * 2), by = s16(qy + (qy & 1) * 2);
+        int hpelB = (by & 2) | ((bx & 2) >> 1);
+        const uint8_t *b = four[hpelB].origin + off + (bx >> 2) + (by >> 2) * ls;
+        for (int r = 0; r < 8; r++)
+            for (int c = 0; c < 8; c++)
+                buf[r * 8 + c] = (uint8_t)((a[r * ls + c] + b[r * ls + c] + 1) >> 1);
+        *stride = 8;
+        return buf;
+    }
+    *stride = ls;
+    return four[(qy & 2) | ((qx & 2) >> 1)].origin + off + (qx >> 2) + (qy >> 2) * ls;
+}
+
+/* The lookahead's bidirectional cost, ref: EstimateRow::estimateCUCost, encoder/slicetype.cpp:1585-1603:
+ * lowresMC of both lists, pixelavg_pp[LUMA_8x8], satd[LUMA_8x8] against the lowres source block */
+static int lowres_bidir_cost(const x265o_plane *planes, const x265o_bidir_req *r)
+{
+    uint8_t b0[64], b1[64], avg[64];
+    intptr_t s0, s1;
+    const uint8_t *p0 = lowres_mc(&planes[r->ref0_plane], r->pu_x, r->pu_y, r->qmv0_x, r->qmv0_y, b0, &s0);
+    const uint8_t *p1 = lowres_mc(&planes[r->ref1_plane], r->pu_x, r->pu_y, r->qmv1_x, r->qmv1_y, b1, &s1);
+    x265o_pixelavg_pp(1 /* LUMA_8x8 */, avg, 8, p0, s0, p1, s1);
+    const x265o_plane *f = &planes[r->fenc_plane];
+    const uint8_t *fe = f->origin + r->pu_x + (intptr_t)r->pu_y * f->stride;
+    return (r->metric & 1) ? x265o_satd(1, fe, f->stride, avg, 8) : sad_wh(8, 8, fe, f->stride, avg, 8);
+}
+
 void x265o_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *reqs, int n, int32_t *out)
 {
     for (int i = 0; i < n; i++)
     {
         const x265o_bidir_req *r = &reqs[i];
+        if (r->metric & X265O_LOWRES_REF)
+        {
+            out[i] = lowres_bidir_cost(planes, r);
+            continue;
+        }
         out[i] = x265o_bidir_cost(&planes[r->fenc_plane], &planes[r->ref0_plane], &planes[r->ref1_plane], r->pu_x, r->pu_y,
                                   r->pu_w, r->pu_h, r->qmv0_x, r->qmv0_y, r->qmv1_x, r->qmv1_y, r->metric);
     }

@@ -148,3 +148,21 @@ def random_pred_reqs(rng, W, H, dtype, parts, dst_plane=5, refs=(0, 2), cell=64)
         for k in ("qmv0_x", "qmv0_y", "qmv1_x", "qmv1_y"):
             r[k] = int(rng.integers(-90, 90)) if rng.integers(4) else 4 * int(rng.integers(-20, 20))
     return reqs
+
+
+def random_lowres_bidir_reqs(rng, n, lw, ll, dtype, fenc_plane=4, ref_planes=(0, 8), metric=1):
+    """the lookahead's bidirectional cost (slicetype.cpp:1585-1603): 8x8 CUs of a lowres picture against two Lowres
+    references at quarter-pel vectors inside the lookahead's search bounds; metric carries the lowres flag"""
+    wcu, hcu = lw // 8, ll // 8
+    reqs = np.zeros(n, dtype)
+    for r in reqs:
+        cux, cuy = int(rng.integers(0, wcu)), int(rng.integers(0, hcu))
+        r["fenc_plane"], r["ref0_plane"], r["ref1_plane"] = fenc_plane, int(rng.choice(ref_planes)), int(rng.choice(ref_planes))
+        r["pu_x"], r["pu_y"], r["pu_w"], r["pu_h"] = 8 * cux, 8 * cuy, 8, 8
+        r["metric"] = metric | 0x80
+        lox, loy = 4 * (-cux * 8 - 8), 4 * (-cuy * 8 - 8)
+        hix, hiy = 4 * ((wcu - cux - 1) * 8 + 8), 4 * ((hcu - cuy - 1) * 8 + 8)
+        for kx, ky in (("qmv0_x", "qmv0_y"), ("qmv1_x", "qmv1_y")):
+            r[kx] = int(np.clip(rng.integers(-70, 70), lox, hix)) if rng.integers(5) else 0
+            r[ky] = int(np.clip(rng.integers(-70, 70), loy, hiy)) if rng.integers(5) else 0
+    return reqs

@@ -123,6 +123,11 @@ def test_lookahead_planes_and_search_reproduce_reference_fixtures():
     for k in ("fenc_plane", "ref0_plane", "ref1_plane"):
         br[k] += 20
     assert np.array_equal(ctx.bidir_cost_batch(br), g["bidir_costs"])
+    # the lookahead's bidirectional cost on the lowres planes made above (plane ids 0..11 as in the fixture)
+    lb = np.load(os.path.join(GOLD, "lowres_bidir.npz"))
+    got = ctx.bidir_cost_batch(lb["reqs"])
+    bad = np.nonzero(got != lb["costs"])[0]
+    assert len(bad) == 0, (lb["reqs"][bad[0]], got[bad[0]], lb["costs"][bad[0]])
     # weighted reference planes: the fixture's CRCs cover whole buffers; 416 is not a multiple of 64, so the 32
     # columns between the right margin and the stride are never written by either side (zero in both)
     p = golden_planes()[0]

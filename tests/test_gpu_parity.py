@@ -385,3 +385,34 @@ def test_primitive_table_mc_entries(oracle):
         t.luma_addAvg[part](addr(s16a, 3), addr(s16b, 11), addr(p1, 9), 64, 70, 81)
         oracle.luma_addavg(part, s16a, 3, s16b, 11, p2, 9, 64, 70, 81)
         assert np.array_equal(p1, p2), part
+
+
+def test_lowres_bidir_cost(oracle, small_seq):
+    """the lookahead's bidirectional cost: lowres planes made on the device, random 8x8 CUs and vector pairs, sad and
+    satd, a ragged count; mixed into one list with full-resolution bidirectional requests"""
+    from conftest import random_bidir_reqs, random_lowres_bidir_reqs
+    from x265_amd import abi, lib
+    ctx = lib.Context(0)
+    low = []
+    for i, p in enumerate(small_seq):
+        ctx.plane_upload(20 + i, p.buf, p.stride, p.origin)
+        geo = ctx.lowres_init(20 + i, p.w, p.h, 4 * i)
+        four, _ = oracle.lowres_planes(p.buf, p.origin, p.stride, p.w, p.h)
+        low += four
+    full = [p.as_tuple() for p in small_seq]
+    rng = np.random.default_rng(63)
+    for metric, n in ((1, 2000), (0, 777)):
+        br = random_lowres_bidir_reqs(rng, n, geo.width, geo.lines, abi.BIDIR_REQ, metric=metric)
+        got, want = ctx.bidir_cost_batch(br), oracle.bidir_cost_batch(low, br)
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (br[bad[0]], got[bad[0]], want[bad[0]])
+    # one list holding both kinds: planes 0..11 lowres, 20..22 full resolution
+    a = random_lowres_bidir_reqs(rng, 300, geo.width, geo.lines, abi.BIDIR_REQ)
+    b = random_bidir_reqs(rng, 300, small_seq[0].w, small_seq[0].h, abi.BIDIR_REQ, oracle_parts())
+    want = np.concatenate([oracle.bidir_cost_batch(low, a), oracle.bidir_cost_batch(full, b)])
+    for k in ("fenc_plane", "ref0_plane", "ref1_plane"):
+        b[k] += 20
+    mixed = np.concatenate([a, b])
+    perm = rng.permutation(len(mixed))
+    assert np.array_equal(ctx.bidir_cost_batch(mixed[perm]), want[perm])
+    ctx.close()

@@ -176,3 +176,13 @@ def test_predictions_match_reference_fixtures(oracle):
     for reqs, want in zip(g["reqs"], g["crc"]):
         oracle.predict_batch([p.as_tuple() for p in planes] + [(dst, p0.origin, p0.stride)], reqs.view(pyoracle.PRED_REQ))
         assert zlib.crc32(dst.tobytes()) & 0xffffffff == int(want)
+
+
+def test_lowres_bidir_costs_match_reference_fixtures(oracle):
+    """lowres_bidir.npz: the lookahead's bidirectional cost (lowresMC x 2, pixelavg_pp, satd) by the reference build"""
+    g = np.load(os.path.join(GOLD, "lowres_bidir.npz"))
+    low = []
+    for p in golden_planes():
+        four, _ = oracle.lowres_planes(p.buf, p.origin, p.stride, p.w, p.h)
+        low += four
+    assert np.array_equal(oracle.bidir_cost_batch(low, g["reqs"]), g["costs"])

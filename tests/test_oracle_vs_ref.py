@@ -3,7 +3,7 @@ Skipped where oracle/_ref/libx265ref.so is absent (it is built only where /root/
 import numpy as np
 import pytest
 
-from conftest import random_bidir_reqs, random_lowres_jobs, random_me_jobs, random_pred_reqs
+from conftest import random_bidir_reqs, random_lowres_bidir_reqs, random_lowres_jobs, random_me_jobs, random_pred_reqs
 from oracle import pyoracle
 
 pytestmark = pytest.mark.skipif(not pyoracle.have_ref(), reason="reference build not present")
@@ -77,6 +77,11 @@ def test_lowres_planes_and_search(oracle, ref, small_seq):
         low_o += a
         low_r += b
     rng = np.random.default_rng(5)
+    for metric in (0, 1):  # the lookahead's bidirectional cost: lowresMC of two references, pixelavg_pp, satd (sad)
+        br = random_lowres_bidir_reqs(rng, 1500, size[0], size[1], pyoracle.BIDIR_REQ, metric=metric)
+        a, b = oracle.bidir_cost_batch(low_o, br), ref.bidir_cost_batch(low_r, br)
+        bad = np.nonzero(a != b)[0]
+        assert len(bad) == 0, (br[bad[0]], a[bad[0]], b[bad[0]])
     jobs = random_lowres_jobs(rng, 1500, size[0], size[1], pyoracle.ME_JOB)
     tabs = {q: oracle.bitcost_table(q) for q in (12, 20, 33)}
     a, b = oracle.me_batch(low_o, tabs, jobs), ref.me_batch(low_r, tabs, jobs)

@@ -782,9 +782,24 @@ int x265_hip_bidir_cost_batch(x265_hip_ctx *c, const x265_hip_bidir_req *reqs, i
         int r = check_block(c, reqs[i].fenc_plane, reqs[i].ref0_plane, reqs[i].pu_w, reqs[i].pu_h, "bidir_req", i);
         if (r || (r = check_block(c, reqs[i].fenc_plane, reqs[i].ref1_plane, reqs[i].pu_w, reqs[i].pu_h, "bidir_req", i)))
             return r;
-        if (reqs[i].metric > X265_HIP_SATD)
-            return fail(X265_HIP_EINVAL, "bidir_req[%d]: unknown metric %d", i, reqs[i].metric);
         const x265_hip_bidir_req &q = reqs[i];
+        if ((q.metric & ~X265_HIP_LOWRES_REF) > X265_HIP_SATD)
+            return fail(X265_HIP_EINVAL, "bidir_req[%d]: unknown metric %d", i, q.metric);
+        if (q.metric & X265_HIP_LOWRES_REF)
+        {
+            // Lowres references: the lookahead's 8x8 CU, four planes of one stride per reference
+            if (q.pu_w != 8 || q.pu_h != 8)
+                return fail(X265_HIP_EINVAL, "bidir_req[%d]: lowres references take 8x8 blocks only (lowres.h:64)", i);
+            for (int rp : { q.ref0_plane, q.ref1_plane })
+            {
+                if (rp + 3 >= X265_HIP_MAX_PLANES)
+                    return fail(X265_HIP_EINVAL, "bidir_req[%d]: lowres planes %d..%d out of range", i, rp, rp + 3);
+                for (int k = 1; k < 4; k++)
+                    if (!c->host_tabs.planes[rp + k].origin || c->host_tabs.planes[rp + k].stride != c->host_tabs.planes[rp].stride ||
+                        c->plane_bytes[rp + k] != c->plane_bytes[rp] || c->plane_origin[rp + k] != c->plane_origin[rp])
+                        return fail(X265_HIP_EINVAL, "bidir_req[%d]: lowres plane %d missing or of another layout", i, rp + k);
+            }
+        }
         if ((r = check_inside(c, q.fenc_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, "bidir_req", i)) ||
             (r = check_displaced(c, q.ref0_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv0_x, q.qmv0_y, "bidir_req", i)) ||
             (r = check_displaced(c, q.ref1_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv1_x, q.qmv1_y, "bidir_req", i)))

@@ -1240,6 +1240,8 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
     __shared__ CostLds lds[4];
     __shared__ int count_lds[4][COST_BATCH];                              // items of a request (pre[] holds the padded count)
     __shared__ int units_lds[DIST ? 4 : 1][COST_BATCH * DIST_UNITS];
+    // Lowres references of bidirectional requests: half-pel planes 1..3 of both references at the displaced block
+    __shared__ const uint8_t *low_lds[BIDIR ? 4 : 1][6][BIDIR ? COST_BATCH : 1];
     __shared__ PlaneDesc planes[X265_HIP_MAX_PLANES];
     static_assert(sizeof(PlaneDesc) == 16 && X265_HIP_MAX_PLANES * 4 <= 256, "plane directory copy below");
     if (threadIdx.x < X265_HIP_MAX_PLANES * 4)
@@ -1249,6 +1251,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
     CostLds &L = lds[threadIdx.x >> 6];
     int *const count = count_lds[threadIdx.x >> 6];
     int *const units = units_lds[DIST ? threadIdx.x >> 6 : 0];
+    auto &low = low_lds[BIDIR ? threadIdx.x >> 6 : 0];
     const int lane = threadIdx.x & 63;
     const int nbatch = (n + rb - 1) / rb;
     const int parts = min((int)gridDim.x, COST_PARTS), part = blockIdx.x % parts;
@@ -1304,6 +1307,19 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                 L.ref1[lane] = rp1.origin + (long)(cur.pu_y + (qy1 >> 2)) * rp1.stride + cur.pu_x + (qx1 >> 2);
                 L.rstride1[lane] = rp1.stride;
                 info |= ((qx1 & 3) << 15) | ((qy1 & 3) << 17);
+                if (BIDIR && (req_metric(cur) & X265_HIP_LOWRES_REF))
+                {
+                    // the lookahead's bidirectional cost (slicetype.cpp:1585-1595): both references are Lowres
+                    // (planes ref .. ref + 3, one stride each)
+                    info = (info & ~(3 << 12)) | ((req_metric(cur) & 1) << 12) | (1 << 19);
+                    const long off0 = (long)(cur.pu_y + (qy >> 2)) * rp.stride + cur.pu_x + (qx >> 2);
+                    const long off1 = (long)(cur.pu_y + (qy1 >> 2)) * rp1.stride + cur.pu_x + (qx1 >> 2);
+                    for (int k = 1; k < 4; k++)
+                    {
+                        low[k - 1][lane] = planes[req_ref0(cur) + k].origin + off0;
+                        low[k + 2][lane] = planes[req_ref1(cur) + k].origin + off1;
+                    }
+                }
             }
             L.info[lane] = info;
         }
@@ -1407,8 +1423,29 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
             {
                 const uint8_t *f = L.fenc[k] + 8 * ty * fstride + 4 * tx;
                 uint32_t pix[8][2];
-                ref_strip<2>(L.ref[k] + 8 * ty * rstride + 4 * tx, rstride, xf, yf, pix);
-                if (BIDIR)
+                if (BIDIR && ((info >> 19) & 1))
+                {
+                    // lowresMC of both lists (lowres.h:53-73), two tiles each
+                    const int rs1 = L.rstride1[k], xf1 = (info >> 15) & 3, yf1 = (info >> 17) & 3;
+                    uint32_t pix1[8][2];
+#pragma unroll
+                    for (int half = 0; half < 2; half++)
+                    {
+                        lowres_tile(L.ref[k], low[0][k], low[1][k], low[2][k], rstride, xf, yf, (8 * ty + 4 * half) * rstride + 4 * tx,
+                                    pix + 4 * half);
+                        lowres_tile(L.ref1[k], low[3][k], low[4][k], low[5][k], rs1, xf1, yf1, (8 * ty + 4 * half) * rs1 + 4 * tx,
+                                    pix1 + 4 * half);
+                    }
+#pragma unroll
+                    for (int y = 0; y < 8; y++)
+                    {
+                        pix[y][0] = avg_pairs(pix[y][0], pix1[y][0]);
+                        pix[y][1] = avg_pairs(pix[y][1], pix1[y][1]);
+                    }
+                }
+                else
+                    ref_strip<2>(L.ref[k] + 8 * ty * rstride + 4 * tx, rstride, xf, yf, pix);
+                if (BIDIR && !((info >> 19) & 1))
                 {
                     const int rs1 = L.rstride1[k];
                     uint32_t pix1[8][2];
