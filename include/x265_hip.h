@@ -57,6 +57,8 @@ enum { X265_HIP_SAD = 0, X265_HIP_SATD = 1, X265_HIP_SA8D = 2, X265_HIP_SSE = 3 
  * ref_plane .. ref_plane + 3 are lowresPlane[0..3] with one stride, the block must be the lookahead's 8x8 CU,
  * and sub-pel costs come from lowresQPelCost (lowres.h:73-93) along motion.cpp:556-557, 587-588, 1055-1080 */
 #define X265_HIP_LOWRES_REF 0x80
+/* OR-ed into x265_hip_bidir_req::metric: combine the two predictions as motion compensation does (see there) */
+#define X265_HIP_MC_AVG 0x40
 
 #define X265_HIP_MAX_MVC    12  /* AMVP + spatial candidates, <= 11 in the reference (TEncSearch.cpp:2311) */
 #define X265_HIP_MAX_PLANES 64
@@ -239,11 +241,16 @@ typedef struct x265_hip_bidir_req
     int32_t ref0_plane, ref1_plane;
     int16_t pu_x, pu_y;
     uint8_t pu_w, pu_h; /* one of the 25 partitions */
-    uint8_t metric;     /* X265_HIP_SAD / X265_HIP_SATD, optionally | X265_HIP_LOWRES_REF (below) */
+    uint8_t metric;     /* X265_HIP_SAD / SATD / SA8D / SSE, optionally | X265_HIP_MC_AVG or | X265_HIP_LOWRES_REF (below) */
     uint8_t pad;
     int16_t qmv0_x, qmv0_y, qmv1_x, qmv1_y;
 } x265_hip_bidir_req;
-/* With X265_HIP_LOWRES_REF in `metric` the request is the lookahead's bidirectional cost (EstimateRow::
+/* With X265_HIP_MC_AVG in `metric` the two predictions are combined the way TComPrediction::xPredInterBi does
+ * (14-bit intermediates + luma_addAvg, TComPrediction.cpp:330-355, 436-473; pixel.cpp:819-839) instead of
+ * pixelavg_pp: with X265_HIP_SATD that is what TEncSearch::xMergeEstimation measures on a bi-directional merge
+ * candidate (motionCompensation + bufSATD, TEncSearch.cpp:2209-2210), with X265_HIP_SA8D / X265_HIP_SSE what mode
+ * decision measures on a bi-predicted block (compress.cpp:215, 265).
+ * With X265_HIP_LOWRES_REF in `metric` the request is the lookahead's bidirectional cost (EstimateRow::
  * estimateCUCost, source/encoder/slicetype.cpp:1585-1603): ref0_plane .. +3 and ref1_plane .. +3 are the
  * lowresPlane[0..3] of two Lowres references, the block is an 8x8 CU of the lowres source picture, the two
  * predictions are ReferencePlanes::lowresMC (common/lowres.h:53-73) and the average is pixelavg_pp[LUMA_8x8]. */

@@ -159,6 +159,12 @@ def gen_dist(R):
                             metrics=(0, 1, 2, 2, 3, 3))
     costs = R.cost_batch([p.as_tuple() for p in planes], reqs)
     np.savez_compressed(os.path.join(OUT, "dist.npz"), reqs=reqs, costs=costs)
+    # bidirectional blocks as motion compensation predicts them (addAvg of 14-bit intermediates), all four comparisons;
+    # with satd this is xMergeEstimation's measurement of a bi-directional merge candidate
+    from conftest import random_bidir_reqs
+    br = random_bidir_reqs(np.random.default_rng(83), 600, planes[0].w, planes[0].h, pyoracle.BIDIR_REQ, pyoracle.PARTS,
+                           metrics=(0, 1, 1, 2, 3), flags=(0x40, 0x40, 0))
+    np.savez_compressed(os.path.join(OUT, "bidir_mc.npz"), reqs=br, costs=R.bidir_cost_batch([p.as_tuple() for p in planes], br))
 
 
 def gen_pred(R):

@@ -243,6 +243,13 @@ static void ref_predict_luma(int part, int w, pixel *p, intptr_t stride, int qx,
     }
 }
 
+static pixelcmp_t ref_cmp(int metric, int part)
+{
+    return metric == X265O_SSE ? g_c.sse_pp[part] : metric == X265O_SA8D ? g_c.sa8d_inter[part] : metric ? g_c.satd[part] : g_c.sad[part];
+}
+
+static void ref_predict_luma_short(int part, int w, int h, pixel *p, intptr_t stride, int qx, int qy, int16_t *dst);
+
 /* TEncSearch.cpp:2360-2412: pixelavg_pp of the two predictions, then satd / sad of the block */
 void x265r_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *reqs, int n, int32_t *out)
 {
@@ -269,15 +276,27 @@ void x265r_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *re
             pixel *src1 = r1.lowresMC(r->pu_x + (intptr_t)r->pu_y * b.stride, MV(r->qmv1_x, r->qmv1_y), buf1, s1);
             g_c.pixelavg_pp[LUMA_8x8](ref, 8, src0, s0, src1, s1, 32);
             pixel *fe8 = (pixel *)f.origin + r->pu_x + (intptr_t)r->pu_y * f.stride;
-            out[i] = (r->metric & 1) ? g_c.satd[LUMA_8x8](fe8, f.stride, ref, 8) : g_c.sad[LUMA_8x8](fe8, f.stride, ref, 8);
+            out[i] = ref_cmp(r->metric & 3, LUMA_8x8)(fe8, f.stride, ref, 8);
             continue;
         }
         int part = partitionFromSizes(r->pu_w, r->pu_h);
+        if (r->metric & X265O_MC_AVG)
+        {
+            /* motionCompensation of a bi-directional block + bufSATD (TEncSearch.cpp:2209-2210) */
+            static thread_local int16_t s0[64 * 64], s1[64 * 64];
+            ref_predict_luma_short(part, r->pu_w, r->pu_h, (pixel *)a.origin + r->pu_x + (intptr_t)r->pu_y * a.stride, a.stride,
+                                   r->qmv0_x, r->qmv0_y, s0);
+            ref_predict_luma_short(part, r->pu_w, r->pu_h, (pixel *)b.origin + r->pu_x + (intptr_t)r->pu_y * b.stride, b.stride,
+                                   r->qmv1_x, r->qmv1_y, s1);
+            g_c.luma_addAvg[part](s0, s1, avg, 64, 64, 64);
+            out[i] = ref_cmp(r->metric & 3, part)((pixel *)f.origin + r->pu_x + (intptr_t)r->pu_y * f.stride, f.stride, avg, 64);
+            continue;
+        }
         ref_predict_luma(part, r->pu_w, (pixel *)a.origin + r->pu_x + (intptr_t)r->pu_y * a.stride, a.stride, r->qmv0_x, r->qmv0_y, p0);
         ref_predict_luma(part, r->pu_w, (pixel *)b.origin + r->pu_x + (intptr_t)r->pu_y * b.stride, b.stride, r->qmv1_x, r->qmv1_y, p1);
         g_c.pixelavg_pp[part](avg, 64, p0, 64, p1, 64, 32);
         pixel *fe = (pixel *)f.origin + r->pu_x + (intptr_t)r->pu_y * f.stride;
-        out[i] = r->metric ? g_c.satd[part](fe, f.stride, avg, 64) : g_c.sad[part](fe, f.stride, avg, 64);
+        out[i] = ref_cmp(r->metric & 3, part)(fe, f.stride, avg, 64);
     }
 }
 

@@ -1142,18 +1142,30 @@ static void predict_luma(int part, int w, const uint8_t *p, intptr_t stride, int
     }
 }
 
+static void predict_luma_short(int part, int w, int h, const uint8_t *p, intptr_t stride, int qx, int qy, int16_t *dst);
+
 int x265o_bidir_cost(const x265o_plane *fenc, const x265o_plane *ref0, const x265o_plane *ref1, int x, int y, int w,
                      int h, int qmv0x, int qmv0y, int qmv1x, int qmv1y, int metric)
 {
     uint8_t p0[64 * 64], p1[64 * 64], avg[64 * 64];
     int part = x265o_partition_from_sizes(w, h);
+    const uint8_t *f = fenc->origin + x + (intptr_t)y * fenc->stride;
+    if (metric & X265O_MC_AVG)
+    {
+        /* the prediction motion compensation makes of the pair (xPredInterBi, TComPrediction.cpp:330-355): what
+         * xMergeEstimation compares (TEncSearch.cpp:2209-2210) */
+        int16_t s0[64 * 64], s1[64 * 64];
+        predict_luma_short(part, w, h, ref0->origin + x + (intptr_t)y * ref0->stride, ref0->stride, qmv0x, qmv0y, s0);
+        predict_luma_short(part, w, h, ref1->origin + x + (intptr_t)y * ref1->stride, ref1->stride, qmv1x, qmv1y, s1);
+        x265o_luma_addavg(part, s0, s1, avg, 64, 64, 64);
+        return block_metric(metric & 3, part, w, h, f, fenc->stride, avg, 64);
+    }
     predict_luma(part, w, ref0->origin + x + (intptr_t)y * ref0->stride, ref0->stride, qmv0x, qmv0y, p0);
     predict_luma(part, w, ref1->origin + x + (intptr_t)y * ref1->stride, ref1->stride, qmv1x, qmv1y, p1);
     for (int r = 0; r < h; r++)
         for (int c = 0; c < w; c++)
             avg[r * 64 + c] = (uint8_t)((p0[r * 64 + c] + p1[r * 64 + c] + 1) >> 1);
-    const uint8_t *f = fenc->origin + x + (intptr_t)y * fenc->stride;
-    return metric ? x265o_satd(part, f, fenc->stride, avg, 64) : sad_wh(w, h, f, fenc->stride, avg, 64);
+    return block_metric(metric & 3, part, w, h, f, fenc->stride, avg, 64);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1301,7 +1313,7 @@ static int lowres_bidir_cost(const x265o_plane *planes, const x265o_bidir_req *r
     x265o_pixelavg_pp(1 /* LUMA_8x8 */, avg, 8, p0, s0, p1, s1);
     const x265o_plane *f = &planes[r->fenc_plane];
     const uint8_t *fe = f->origin + r->pu_x + (intptr_t)r->pu_y * f->stride;
-    return (r->metric & 1) ? x265o_satd(1, fe, f->stride, avg, 8) : sad_wh(8, 8, fe, f->stride, avg, 8);
+    return block_metric(r->metric & 3, 1, 8, 8, fe, f->stride, avg, 8);
 }
 
 void x265o_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *reqs, int n, int32_t *out)

@@ -28,6 +28,7 @@ extern "C" {
 
 #define X265O_NUM_PARTS 25
 #define X265O_MAX_MVC   12
+#define X265O_MC_AVG 0x40 /* OR-ed into x265o_bidir_req::metric: luma_addAvg of 14-bit intermediates instead of pixelavg_pp */
 #define X265O_LOWRES_REF 0x80 /* OR-ed into x265o_me_job::method: the reference is a Lowres (ref->isLowres) */
 
 /* Same byte layout as x265_hip_me_job in include/x265_hip.h (declared again

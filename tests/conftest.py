@@ -108,14 +108,14 @@ def random_lowres_jobs(rng, n, lw, ll, dtype, fenc_plane=4, ref_planes=(0, 8), m
     return jobs
 
 
-def random_bidir_reqs(rng, n, W, H, dtype, parts, planes=(1, 0, 2)):
+def random_bidir_reqs(rng, n, W, H, dtype, parts, planes=(1, 0, 2), metrics=(0, 1), flags=(0,)):
     """blocks of every partition against the average of two predictions at random quarter-pel vectors"""
     reqs = np.zeros(n, dtype)
     for r in reqs:
         w, h = parts[int(rng.integers(0, 25))]
         r["fenc_plane"], r["ref0_plane"], r["ref1_plane"] = planes[0], planes[1], int(rng.choice(planes[1:]))
         r["pu_x"], r["pu_y"] = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
-        r["pu_w"], r["pu_h"], r["metric"] = w, h, int(rng.integers(0, 2))
+        r["pu_w"], r["pu_h"], r["metric"] = w, h, int(rng.choice(metrics)) | int(rng.choice(flags))
         for k in ("qmv0_x", "qmv0_y", "qmv1_x", "qmv1_y"):
             r[k] = int(rng.integers(-90, 90)) if rng.integers(4) else 4 * int(rng.integers(-20, 20))
     return reqs

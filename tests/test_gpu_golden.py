@@ -147,6 +147,15 @@ def test_distortions_reproduce_reference_fixtures(gpu_ctx):
     assert len(bad) == 0, (g["reqs"][bad[0]], got[bad[0]], g["costs"][bad[0]])
 
 
+def test_bidir_mc_costs_reproduce_reference_fixtures(gpu_ctx):
+    """bidir_mc.npz: bidirectional blocks with the motion-compensation average (the xMergeEstimation measurement) and
+    all four comparisons, computed by the reference build"""
+    g = np.load(os.path.join(GOLD, "bidir_mc.npz"))
+    got = gpu_ctx.bidir_cost_batch(g["reqs"])
+    bad = np.nonzero(got != g["costs"])[0]
+    assert len(bad) == 0, (g["reqs"][bad[0]], got[bad[0]], g["costs"][bad[0]])
+
+
 def test_predictions_reproduce_reference_fixtures(gpu_ctx, small_seq):
     """pred.npz: CRC32 of the destination plane (whole buffer) after each batch of uni- / bi-directional
     predictions, computed by the reference build"""

@@ -416,3 +416,18 @@ def test_lowres_bidir_cost(oracle, small_seq):
     perm = rng.permutation(len(mixed))
     assert np.array_equal(ctx.bidir_cost_batch(mixed[perm]), want[perm])
     ctx.close()
+
+
+def test_bidir_cost_mc_average_and_all_metrics(gpu_ctx, oracle, small_seq):
+    """bidirectional requests: pixelavg_pp or the motion-compensation average, sad / satd / sa8d / sse, every partition
+    and fraction pair, mixed in one list; a ragged count"""
+    from conftest import random_bidir_reqs
+    from x265_amd import abi
+    rng = np.random.default_rng(64)
+    planes = [p.as_tuple() for p in small_seq]
+    for n in (5000, 37):
+        reqs = random_bidir_reqs(rng, n, small_seq[0].w, small_seq[0].h, abi.BIDIR_REQ, oracle_parts(), metrics=(0, 1, 2, 3),
+                                 flags=(0, 0x40))
+        got, want = gpu_ctx.bidir_cost_batch(reqs), oracle.bidir_cost_batch(planes, reqs)
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (reqs[bad[0]], got[bad[0]], want[bad[0]])

@@ -186,3 +186,10 @@ def test_lowres_bidir_costs_match_reference_fixtures(oracle):
         four, _ = oracle.lowres_planes(p.buf, p.origin, p.stride, p.w, p.h)
         low += four
     assert np.array_equal(oracle.bidir_cost_batch(low, g["reqs"]), g["costs"])
+
+
+def test_bidir_mc_costs_match_reference_fixtures(oracle):
+    """bidir_mc.npz: bidirectional blocks with the motion-compensation average and all four comparisons, by the reference"""
+    g = np.load(os.path.join(GOLD, "bidir_mc.npz"))
+    got = oracle.bidir_cost_batch([p.as_tuple() for p in golden_planes()], g["reqs"])
+    assert np.array_equal(got, g["costs"])

@@ -204,3 +204,16 @@ def test_predict_batch(oracle, ref, small_seq):
         ref.predict_batch(planes + [(d2, p0.origin, p0.stride)], reqs)
         assert np.array_equal(d1, d2)
     assert (d1 != 0x5A).any()
+
+
+def test_bidir_cost_mc_average_and_all_metrics(oracle, ref, small_seq):
+    """bidirectional requests with the motion-compensation average (luma_addAvg of 14-bit intermediates: the
+    xMergeEstimation measurement) and with sa8d / sse beside sad / satd"""
+    rng = np.random.default_rng(47)
+    planes = [p.as_tuple() for p in small_seq]
+    reqs = random_bidir_reqs(rng, 2500, small_seq[0].w, small_seq[0].h, pyoracle.BIDIR_REQ, pyoracle.PARTS,
+                             metrics=(0, 1, 2, 3), flags=(0, 0x40))
+    a, b = oracle.bidir_cost_batch(planes, reqs), ref.bidir_cost_batch(planes, reqs)
+    bad = np.nonzero(a != b)[0]
+    assert len(bad) == 0, (reqs[bad[0]], a[bad[0]], b[bad[0]])
+    assert (reqs["metric"] & 0x40).any() and (reqs["metric"] & 3 == 2).any()

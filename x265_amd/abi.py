@@ -11,7 +11,8 @@ PARTS = [(4, 4), (8, 8), (8, 4), (4, 8), (16, 16), (16, 8), (8, 16), (16, 12), (
 
 DIA, HEX, UMH, STAR, FULL = range(5)
 SAD, SATD, SA8D, SSE = 0, 1, 2, 3
-LOWRES_REF = 0x80  # OR-ed into ME_JOB.method: the reference is a Lowres (four half-pel planes, 8x8 blocks)
+LOWRES_REF = 0x80  # OR-ed into ME_JOB.method / BIDIR_REQ.metric: the reference is a Lowres (four half-pel planes, 8x8 blocks)
+MC_AVG = 0x40  # OR-ed into BIDIR_REQ.metric: addAvg of 14-bit intermediates instead of pixelavg_pp
 
 ME_JOB = np.dtype([
     ("fenc_plane", "<i4"), ("ref_plane", "<i4"),

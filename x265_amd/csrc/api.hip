@@ -783,7 +783,8 @@ int x265_hip_bidir_cost_batch(x265_hip_ctx *c, const x265_hip_bidir_req *reqs, i
         if (r || (r = check_block(c, reqs[i].fenc_plane, reqs[i].ref1_plane, reqs[i].pu_w, reqs[i].pu_h, "bidir_req", i)))
             return r;
         const x265_hip_bidir_req &q = reqs[i];
-        if ((q.metric & ~X265_HIP_LOWRES_REF) > X265_HIP_SATD)
+        if ((q.metric & ~(X265_HIP_LOWRES_REF | X265_HIP_MC_AVG)) > X265_HIP_SSE ||
+            (q.metric & (X265_HIP_LOWRES_REF | X265_HIP_MC_AVG)) == (X265_HIP_LOWRES_REF | X265_HIP_MC_AVG))
             return fail(X265_HIP_EINVAL, "bidir_req[%d]: unknown metric %d", i, q.metric);
         if (q.metric & X265_HIP_LOWRES_REF)
         {

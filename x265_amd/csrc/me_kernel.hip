@@ -1181,11 +1181,12 @@ struct CostLds
     int pre[COST_BATCH + 1]; // exclusive prefix of item counts
     int cost[COST_BATCH];
     // per request, resolved once by lane k: block origins, strides,
-    // ntx | xf << 8 | yf << 10 | metric << 12 | (8-row strips) << 14 | sa8d kind << 19 | units per row << 21
+    // ntx | xf << 8 | yf << 10 | metric << 12 | (8-row strips) << 14 | second fraction << 15 | sa8d kind << 19 |
+    // units per row << 21 | INFO_LOWRES | INFO_MCAVG | INFO_PRED_BI
     const uint8_t *fenc[COST_BATCH];
     const uint8_t *ref[COST_BATCH];
     int fstride[COST_BATCH], rstride[COST_BATCH], info[COST_BATCH];
-    // bidirectional requests: the second prediction; its fraction sits in info bits 15..18
+    // bidirectional requests: the second prediction
     const uint8_t *ref1[COST_BATCH];
     int rstride1[COST_BATCH];
 };
@@ -1230,13 +1231,18 @@ __device__ __forceinline__ int req_qy1(const x265_hip_bidir_req &r) { return r.q
 // MODE_PRED: requests are x265_hip_pred_req; nothing is compared, the predicted strips are stored into the
 // destination plane (uni-directional: the pixels of the other modes; bi-directional: luma_addAvg of the two
 // lists' 14-bit intermediates, info bit 19).
-enum { MODE_COST = 0, MODE_BIDIR = 1, MODE_DIST = 2, MODE_PRED = 3 };
+// The modes are bits: bidir_cost_kernel is MODE_BIDIR | MODE_DIST (all four comparisons).  With INFO_MCAVG a
+// bidirectional request combines its two predictions the way motion compensation does (14-bit intermediates +
+// luma_addAvg, xPredInterBi) instead of pixelavg_pp: what xMergeEstimation measures on a bi-directional merge
+// candidate (TEncSearch.cpp:2209-2210) and mode decision on a bi-predicted block.
+enum { MODE_COST = 0, MODE_BIDIR = 1, MODE_DIST = 2, MODE_PRED = 4 };
+enum { INFO_LOWRES = 1 << 24, INFO_MCAVG = 1 << 25, INFO_PRED_BI = 1 << 26 };
 #define DIST_UNITS 16 // 64x64: sixteen 16x16 blocks; 32x24 / 24x32: twelve 8x8 blocks
 
 template <int MODE, typename Req>
 __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *reqs, int n, int32_t *out, uint32_t *counters, int parity, int rb)
 {
-    constexpr bool BIDIR = MODE == MODE_BIDIR, DIST = MODE == MODE_DIST, PRED = MODE == MODE_PRED;
+    constexpr bool BIDIR = (MODE & MODE_BIDIR) != 0, DIST = (MODE & MODE_DIST) != 0, PRED = (MODE & MODE_PRED) != 0;
     __shared__ CostLds lds[4];
     __shared__ int count_lds[4][COST_BATCH];                              // items of a request (pre[] holds the padded count)
     __shared__ int units_lds[DIST ? 4 : 1][COST_BATCH * DIST_UNITS];
@@ -1286,8 +1292,9 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
             L.ref[lane] = rp.origin + (long)(cur.pu_y + (qy >> 2)) * rp.stride + cur.pu_x + (qx >> 2);
             L.fstride[lane] = fp.stride;
             L.rstride[lane] = rp.stride;
-            int info = (cur.pu_w >> 2) | ((qx & 3) << 8) | ((qy & 3) << 10) | (req_metric(cur) << 12) | (tall << 14);
-            if (DIST && req_metric(cur) == X265_HIP_SA8D)
+            const int rmetric = req_metric(cur) & 3;
+            int info = (cur.pu_w >> 2) | ((qx & 3) << 8) | ((qy & 3) << 10) | (rmetric << 12) | (tall << 14);
+            if (DIST && rmetric == X265_HIP_SA8D)
             {
                 // the table of pixel.cpp:1117-1141: sa8d16<> / sa8d8<> / satd by the block's divisibility
                 const int kind = ((cur.pu_w | cur.pu_h) & 15) == 0 ? 2 : ((cur.pu_w | cur.pu_h) & 7) == 0 ? 1 : 0;
@@ -1301,7 +1308,9 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
             if (BIDIR || (PRED && req_ref1(cur) >= 0))
             {
                 if (PRED)
-                    info |= 1 << 19;
+                    info |= INFO_PRED_BI;
+                if (BIDIR && (req_metric(cur) & X265_HIP_MC_AVG))
+                    info |= INFO_MCAVG;
                 const PlaneDesc rp1 = planes[req_ref1(cur)];
                 const int qx1 = req_qx1(cur), qy1 = req_qy1(cur);
                 L.ref1[lane] = rp1.origin + (long)(cur.pu_y + (qy1 >> 2)) * rp1.stride + cur.pu_x + (qx1 >> 2);
@@ -1311,7 +1320,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                 {
                     // the lookahead's bidirectional cost (slicetype.cpp:1585-1595): both references are Lowres
                     // (planes ref .. ref + 3, one stride each)
-                    info = (info & ~(3 << 12)) | ((req_metric(cur) & 1) << 12) | (1 << 19);
+                    info |= INFO_LOWRES;
                     const long off0 = (long)(cur.pu_y + (qy >> 2)) * rp.stride + cur.pu_x + (qx >> 2);
                     const long off1 = (long)(cur.pu_y + (qy1 >> 2)) * rp1.stride + cur.pu_x + (qx1 >> 2);
                     for (int k = 1; k < 4; k++)
@@ -1390,7 +1399,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                     uint8_t *dst = const_cast<uint8_t *>(L.fenc[k]) + R * ty * fstride + 4 * tx;
                     const uint8_t *r0 = L.ref[k] + R * ty * rstride + 4 * tx;
                     uint32_t pix[R][2];
-                    if ((info >> 19) & 1)
+                    if (info & INFO_PRED_BI)
                     {
                         const int rs1 = L.rstride1[k];
                         uint32_t pix1[R][2];
@@ -1423,7 +1432,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
             {
                 const uint8_t *f = L.fenc[k] + 8 * ty * fstride + 4 * tx;
                 uint32_t pix[8][2];
-                if (BIDIR && ((info >> 19) & 1))
+                if (BIDIR && (info & INFO_LOWRES))
                 {
                     // lowresMC of both lists (lowres.h:53-73), two tiles each
                     const int rs1 = L.rstride1[k], xf1 = (info >> 15) & 3, yf1 = (info >> 17) & 3;
@@ -1443,9 +1452,22 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                         pix[y][1] = avg_pairs(pix[y][1], pix1[y][1]);
                     }
                 }
+                else if (BIDIR && (info & INFO_MCAVG))
+                {
+                    const int rs1 = L.rstride1[k];
+                    uint32_t pix1[8][2];
+                    ref_strip<2, true>(L.ref[k] + 8 * ty * rstride + 4 * tx, rstride, xf, yf, pix);
+                    ref_strip<2, true>(L.ref1[k] + 8 * ty * rs1 + 4 * tx, rs1, (info >> 15) & 3, (info >> 17) & 3, pix1);
+#pragma unroll
+                    for (int y = 0; y < 8; y++)
+                    {
+                        pix[y][0] = add_avg_pair(pix[y][0], pix1[y][0]);
+                        pix[y][1] = add_avg_pair(pix[y][1], pix1[y][1]);
+                    }
+                }
                 else
                     ref_strip<2>(L.ref[k] + 8 * ty * rstride + 4 * tx, rstride, xf, yf, pix);
-                if (BIDIR && !((info >> 19) & 1))
+                if (BIDIR && !(info & (INFO_LOWRES | INFO_MCAVG)))
                 {
                     const int rs1 = L.rstride1[k];
                     uint32_t pix1[8][2];
@@ -1476,8 +1498,22 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
             else
             {
                 uint32_t pix[4][2];
-                ref_strip<1>(L.ref[k] + 4 * ty * rstride + 4 * tx, rstride, xf, yf, pix);
-                if (BIDIR)
+                if (BIDIR && (info & INFO_MCAVG))
+                {
+                    const int rs1 = L.rstride1[k];
+                    uint32_t pix1[4][2];
+                    ref_strip<1, true>(L.ref[k] + 4 * ty * rstride + 4 * tx, rstride, xf, yf, pix);
+                    ref_strip<1, true>(L.ref1[k] + 4 * ty * rs1 + 4 * tx, rs1, (info >> 15) & 3, (info >> 17) & 3, pix1);
+#pragma unroll
+                    for (int y = 0; y < 4; y++)
+                    {
+                        pix[y][0] = add_avg_pair(pix[y][0], pix1[y][0]);
+                        pix[y][1] = add_avg_pair(pix[y][1], pix1[y][1]);
+                    }
+                }
+                else
+                    ref_strip<1>(L.ref[k] + 4 * ty * rstride + 4 * tx, rstride, xf, yf, pix);
+                if (BIDIR && !(info & INFO_MCAVG))
                 {
                     const int rs1 = L.rstride1[k];
                     uint32_t pix1[4][2];
@@ -1520,7 +1556,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
 __global__ __launch_bounds__(256) void bidir_cost_kernel(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out,
                                                          uint32_t *counters, int parity, int rb)
 {
-    cost_body<MODE_BIDIR>(tabs, reqs, n, out, counters, parity, rb);
+    cost_body<MODE_BIDIR | MODE_DIST>(tabs, reqs, n, out, counters, parity, rb);
 }
 
 // motion-compensated prediction into a destination plane (x265_hip_predict_batch)
