@@ -1,0 +1,264 @@
+/* enc_capture.cpp -- TEST INFRASTRUCTURE ONLY (golden capture, route 3 of SURVEY.md 8(c)).
+ *
+ * Runs the REAL reference encoder (its own sources compiled where they lie, see oracle/Makefile target
+ * `capture`) over a raw 8-bit 4:2:0 clip with the medium preset and records what the encoder itself passes to and
+ * receives from MotionEstimate::motionEstimate: every call is intercepted at link time
+ * (ld --wrap on the member function's symbol; no reference source is changed or copied), its arguments, the
+ * search state of the MotionEstimate object and the result are logged, and the planes the call reads (source
+ * picture, reconstructed / weighted reference, or the four Lowres planes of the lookahead) are snapshotted the
+ * first time each buffer content is seen.  oracle/gen_golden.py turns the two output files into
+ * tests/golden/encoder_me.npz, which the oracle and the HIP path must reproduce call for call.
+ *
+ *   enc_capture in.yuv width height frames out_dir [max_full_calls [max_lowres_calls [first_full_call]]]
+ */
+#include <map>
+#include <mutex>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+/* the interception needs the search state the object keeps (fencplane, blockOffset, searchMethod, ...) */
+#define protected public
+#define private public
+#include "common.h"
+#include "primitives.h"
+#include "lowres.h"
+#include "motion.h"
+#include "bitcost.h"
+#undef protected
+#undef private
+#include "x265.h"
+
+using namespace x265;
+
+#define ME_SYM "_ZN4x26514MotionEstimate14motionEstimateEPNS_15ReferencePlanesERKNS_2MVES5_S5_iPS4_iRS3_"
+int real_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp, int numc,
+            const MV *mvc, int merange, MV &out) asm("__real_" ME_SYM);
+int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp, int numc,
+            const MV *mvc, int merange, MV &out) asm("__wrap_" ME_SYM);
+
+namespace {
+
+#pragma pack(push, 1)
+struct CallRec /* 92 bytes, read by oracle/gen_golden.py */
+{
+    int32_t fenc_plane, ref_plane; /* snapshot ids; a Lowres reference is ref_plane .. ref_plane + 3 */
+    int16_t pu_x, pu_y;
+    uint8_t pu_w, pu_h, method, subme;
+    int16_t mvmin_x, mvmin_y, mvmax_x, mvmax_y, qmvp_x, qmvp_y;
+    int16_t merange;
+    uint8_t num_mvc, qp;
+    int16_t mvc[24];
+    uint8_t lowres, pad[3];
+    int32_t cost;
+    int16_t mvx, mvy;
+};
+struct PlaneRec /* header of one snapshot in planes.bin, followed by `bytes` bytes */
+{
+    int32_t id, stride, origin, bytes;
+};
+#pragma pack(pop)
+static_assert(sizeof(CallRec) == 92, "layout read by gen_golden.py");
+
+struct Snap
+{
+    int id;
+    uint32_t sum;
+};
+std::mutex g_mu;
+std::map<const pixel *, std::vector<Snap> > g_snaps; /* buffer base -> versions seen */
+std::vector<CallRec> g_calls;
+FILE *g_planes = nullptr;
+int g_next_plane = 0, g_width = 0, g_height = 0;
+long g_max_full = 4000, g_max_low = 2000, g_first_full = 0, g_seen_full = 0, g_n_full = 0, g_n_low = 0;
+
+/* TComPicYuv / Lowres layout: margins 80 rows, 96 columns (TComPicYuv.cpp:78-97, lowres.cpp:33-48) */
+const int MX = 96, MY = 80;
+
+uint32_t sparse_sum(const pixel *p, size_t n)
+{
+    uint32_t s = 2166136261u;
+    for (size_t i = 0; i < n; i += 29)
+        s = (s ^ p[i]) * 16777619u;
+    return s;
+}
+
+/* id of the snapshot of the padded buffer whose sample (0,0) is `origin`; rows = picture rows incl. padding */
+int snapshot(const pixel *origin, int stride, int rows)
+{
+    const pixel *base = origin - (intptr_t)MY * stride - MX;
+    const size_t bytes = (size_t)stride * (rows + 2 * MY);
+    const uint32_t sum = sparse_sum(base, bytes);
+    std::vector<Snap> &v = g_snaps[base];
+    for (const Snap &s : v)
+        if (s.sum == sum)
+            return s.id;
+    PlaneRec h = { g_next_plane, stride, MY * stride + MX, (int32_t)bytes };
+    fwrite(&h, sizeof(h), 1, g_planes);
+    fwrite(base, 1, bytes, g_planes);
+    v.push_back(Snap{ g_next_plane, sum });
+    return g_next_plane++;
+}
+
+/* four consecutive ids for lowresPlane[0..3] (they are snapshotted together the first time plane 0 is new) */
+int snapshot_lowres(pixel *const planes[4], int stride, int rows)
+{
+    const pixel *base0 = planes[0] - (intptr_t)MY * stride - MX;
+    const size_t bytes = (size_t)stride * (rows + 2 * MY);
+    uint32_t sum = 0;
+    for (int k = 0; k < 4; k++)
+        sum = sum * 31 + sparse_sum(planes[k] - (intptr_t)MY * stride - MX, bytes);
+    std::vector<Snap> &v = g_snaps[base0];
+    for (const Snap &s : v)
+        if (s.sum == sum)
+            return s.id;
+    const int id = g_next_plane;
+    for (int k = 0; k < 4; k++)
+    {
+        PlaneRec h = { g_next_plane++, stride, MY * stride + MX, (int32_t)bytes };
+        fwrite(&h, sizeof(h), 1, g_planes);
+        fwrite(planes[k] - (intptr_t)MY * stride - MX, 1, bytes, g_planes);
+    }
+    v.push_back(Snap{ id, sum });
+    return id;
+}
+
+int qp_of(const uint16_t *m_cost)
+{
+    for (int q = 0; q < BitCost::BC_MAX_QP; q++)
+        if (BitCost::s_costs[q] && (m_cost == BitCost::s_costs[q] || m_cost == BitCost::s_costs[q] + BitCost::BC_MAX_MV))
+            return q;
+    return 255;
+}
+
+} // namespace
+
+int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp, int numc,
+            const MV *mvc, int merange, MV &out)
+{
+    const int cost = real_me(self, ref, mvmin, mvmax, qmvp, numc, mvc, merange, out);
+    std::lock_guard<std::mutex> g(g_mu);
+    const bool low = ref->isLowres;
+    if (!low && g_seen_full++ < g_first_full)
+        return cost;
+    if ((low ? g_n_low >= g_max_low : g_n_full >= g_max_full) || numc > 12)
+        return cost;
+    CallRec r;
+    memset(&r, 0, sizeof(r));
+    const int stride = (int)self->fencLumaStride;
+    if (low)
+    {
+        /* Lowres::create: width / 2 and height / 2, lines rounded up to 8 (lowres.cpp:33-48) */
+        const int lines = ((g_height / 2) + 7) / 8 * 8;
+        r.fenc_plane = snapshot(self->fencplane, stride, lines);
+        r.ref_plane = snapshot_lowres(ref->lowresPlane, ref->lumaStride, lines);
+        g_n_low++;
+    }
+    else
+    {
+        const int rows = (g_height + 63) / 64 * 64;
+        r.fenc_plane = snapshot(self->fencplane, stride, rows);
+        r.ref_plane = snapshot(ref->fpelPlane, ref->lumaStride, rows);
+        g_n_full++;
+    }
+    r.pu_y = (int16_t)(self->blockOffset / stride);
+    r.pu_x = (int16_t)(self->blockOffset % stride);
+    r.pu_w = (uint8_t)self->blockwidth;
+    r.pu_h = (uint8_t)self->blockheight;
+    r.method = (uint8_t)self->searchMethod;
+    r.subme = (uint8_t)self->subpelRefine;
+    r.mvmin_x = mvmin.x, r.mvmin_y = mvmin.y, r.mvmax_x = mvmax.x, r.mvmax_y = mvmax.y;
+    r.qmvp_x = qmvp.x, r.qmvp_y = qmvp.y;
+    r.merange = (int16_t)merange;
+    r.num_mvc = (uint8_t)numc;
+    for (int i = 0; i < numc; i++)
+        r.mvc[2 * i] = mvc[i].x, r.mvc[2 * i + 1] = mvc[i].y;
+    r.qp = (uint8_t)qp_of(self->m_cost);
+    r.lowres = low;
+    r.cost = cost;
+    r.mvx = out.x, r.mvy = out.y;
+    g_calls.push_back(r);
+    return cost;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 6)
+    {
+        fprintf(stderr, "usage: %s in.yuv width height frames out_dir [max_full [max_lowres [first_full]]]\n", argv[0]);
+        return 2;
+    }
+    g_width = atoi(argv[2]);
+    g_height = atoi(argv[3]);
+    const int frames = atoi(argv[4]);
+    const std::string dir = argv[5];
+    if (argc > 6)
+        g_max_full = atol(argv[6]);
+    if (argc > 7)
+        g_max_low = atol(argv[7]);
+    if (argc > 8)
+        g_first_full = atol(argv[8]);
+    FILE *in = fopen(argv[1], "rb");
+    g_planes = fopen((dir + "/planes.bin").c_str(), "wb");
+    if (!in || !g_planes)
+    {
+        perror("open");
+        return 1;
+    }
+
+    /* BASELINE.json configs[0]: --preset medium; one frame thread so that every reference is complete (and its
+     * borders extended) before the next picture is searched, which makes the snapshots replayable */
+    x265_param *p = x265_param_alloc();
+    x265_param_default_preset(p, "medium", NULL);
+    p->sourceWidth = g_width;
+    p->sourceHeight = g_height;
+    p->fpsNum = 25;
+    p->fpsDenom = 1;
+    p->frameNumThreads = 1;
+    p->poolNumThreads = 4;
+    p->logLevel = X265_LOG_WARNING;
+    x265_encoder *enc = x265_encoder_open(p);
+    if (!enc)
+    {
+        fprintf(stderr, "x265_encoder_open failed\n");
+        return 1;
+    }
+    x265_picture pic;
+    x265_picture_init(p, &pic);
+    const size_t ysz = (size_t)g_width * g_height, csz = ysz / 4;
+    std::vector<uint8_t> buf(ysz + 2 * csz);
+    x265_nal *nal;
+    uint32_t nnal;
+    size_t bytes_out = 0;
+    for (int f = 0; f < frames; f++)
+    {
+        if (fread(buf.data(), 1, buf.size(), in) != buf.size())
+            break;
+        pic.planes[0] = buf.data();
+        pic.planes[1] = buf.data() + ysz;
+        pic.planes[2] = buf.data() + ysz + csz;
+        pic.stride[0] = g_width;
+        pic.stride[1] = pic.stride[2] = g_width / 2;
+        pic.bitDepth = 8;
+        pic.pts = f;
+        if (x265_encoder_encode(enc, &nal, &nnal, &pic, NULL) > 0)
+            for (uint32_t i = 0; i < nnal; i++)
+                bytes_out += nal[i].sizeBytes;
+    }
+    while (x265_encoder_encode(enc, &nal, &nnal, NULL, NULL) > 0)
+        for (uint32_t i = 0; i < nnal; i++)
+            bytes_out += nal[i].sizeBytes;
+    x265_encoder_close(enc);
+    x265_param_free(p);
+    x265_cleanup();
+    fclose(g_planes);
+    FILE *out = fopen((dir + "/calls.bin").c_str(), "wb");
+    fwrite(g_calls.data(), sizeof(CallRec), g_calls.size(), out);
+    fclose(out);
+    fprintf(stderr, "enc_capture: %zu bytes of bitstream, %ld full-resolution + %ld lowres motionEstimate calls recorded, %d planes\n",
+            bytes_out, g_n_full, g_n_low, g_next_plane);
+    return 0;
+}

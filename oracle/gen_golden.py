@@ -29,6 +29,7 @@ from oracle import pyoracle  # noqa: E402
 from x265_amd import synth  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
+HERE = os.path.join(ROOT, "oracle")
 
 
 def crc(a):
@@ -184,6 +185,57 @@ def gen_pred(R):
     np.savez_compressed(os.path.join(OUT, "pred.npz"), reqs=np.stack(batches), crc=np.array(crcs, np.uint32))
 
 
+CAPTURE_CALL = np.dtype([
+    ("fenc_plane", "<i4"), ("ref_plane", "<i4"), ("pu_x", "<i2"), ("pu_y", "<i2"), ("pu_w", "u1"), ("pu_h", "u1"),
+    ("method", "u1"), ("subme", "u1"), ("mvmin_x", "<i2"), ("mvmin_y", "<i2"), ("mvmax_x", "<i2"), ("mvmax_y", "<i2"),
+    ("qmvp_x", "<i2"), ("qmvp_y", "<i2"), ("merange", "<i2"), ("num_mvc", "u1"), ("qp", "u1"), ("mvc", "<i2", (24,)),
+    ("lowres", "u1"), ("pad", "u1", (3,)), ("cost", "<i4"), ("mvx", "<i2"), ("mvy", "<i2")])
+assert CAPTURE_CALL.itemsize == 92  # CallRec of oracle/enc_capture.cpp
+
+
+def gen_encoder():
+    """Route 3 of SURVEY.md 8(c), BASELINE configs[0] at fixture size: the reference ENCODER itself (--preset medium,
+    built from its own sources by `make -C oracle capture`) encodes 40 pictures of the 416x240 synthetic sequence;
+    every MotionEstimate::motionEstimate call it makes is intercepted (oracle/enc_capture.cpp) with its real
+    arguments -- AMVP predictors and candidate lists, search bounds, per-CU QPs, reconstructed reference pictures, the
+    lookahead's Lowres planes -- and its real result.  A prefix of the full-resolution calls and of the lookahead
+    calls is kept together with the planes they read."""
+    import subprocess
+    cap = os.path.join(HERE, "_ref", "capture")
+    exe = os.path.join(HERE, "_ref", "enc_capture")
+    if not os.path.exists(exe):
+        sys.exit("oracle/_ref/enc_capture missing: run `make -C oracle capture` where /root/reference exists")
+    os.makedirs(cap, exist_ok=True)
+    W, H, N = 416, 240, 40
+    seq = synth.Sequence(W, H, seed=7, n_patches=3)
+    with open(os.path.join(cap, "in.yuv"), "wb") as f:
+        for i in range(N):
+            f.write(seq.frame(i).astype(np.uint8).tobytes())
+            f.write(bytes([128]) * (W * H // 2))
+    subprocess.check_call([exe, os.path.join(cap, "in.yuv"), str(W), str(H), str(N), cap, "2400", "1200"])
+    calls = np.fromfile(os.path.join(cap, "calls.bin"), dtype=CAPTURE_CALL)
+    raw = open(os.path.join(cap, "planes.bin"), "rb").read()
+    planes, pos = [], 0
+    while pos < len(raw):
+        pid, stride, origin, nbytes = (int(v) for v in np.frombuffer(raw, dtype="<i4", count=4, offset=pos))
+        assert pid == len(planes)
+        planes.append((np.frombuffer(raw, dtype=np.uint8, count=nbytes, offset=pos + 16).copy(), origin, stride))
+        pos += 16 + nbytes
+    jobs = np.zeros(len(calls), pyoracle.ME_JOB)
+    for k in ("fenc_plane", "ref_plane", "pu_x", "pu_y", "pu_w", "pu_h", "subme", "mvmin_x", "mvmin_y", "mvmax_x", "mvmax_y",
+              "qmvp_x", "qmvp_y", "merange", "num_mvc", "qp"):
+        jobs[k] = calls[k]
+    jobs["method"] = calls["method"] | (calls["lowres"] * 0x80)
+    jobs["mvc"] = calls["mvc"]
+    res = np.zeros(len(calls), pyoracle.ME_RESULT)
+    res["cost"], res["mvx"], res["mvy"] = calls["cost"], calls["mvx"], calls["mvy"]
+    geo = np.array([(len(b), o, s) for (b, o, s) in planes], np.int32)
+    np.savez_compressed(os.path.join(OUT, "encoder_me.npz"), jobs=jobs, results=res, plane_geo=geo,
+                        plane_bytes=np.concatenate([b for (b, _, _) in planes]))
+    print("encoder_me: %d full-resolution + %d lookahead calls, %d planes" % (int((calls["lowres"] == 0).sum()),
+                                                                              int(calls["lowres"].sum()), len(planes)))
+
+
 def main():
     if not pyoracle.have_ref():
         sys.exit("oracle/_ref/libx265ref.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -195,6 +247,7 @@ def main():
     gen_lowres(R)
     gen_dist(R)
     gen_pred(R)
+    gen_encoder()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -138,6 +138,25 @@ def test_lookahead_planes_and_search_reproduce_reference_fixtures():
     ctx.close()
 
 
+def test_encoder_calls_reproduce_reference_fixture():
+    """encoder_me.npz: 3600 motionEstimate calls intercepted inside the reference encoder (--preset medium): its own
+    predictors, candidate lists, bounds, QPs, reconstructed references and lookahead planes; same (cost, mv) required"""
+    from test_oracle_golden import encoder_fixture
+    from x265_amd import abi, lib
+    planes, jobs, want = encoder_fixture()
+    jobs = jobs.view(abi.ME_JOB)
+    ctx = lib.Context(0)
+    for i, (buf, origin, stride) in enumerate(planes):
+        ctx.plane_upload(i, buf, stride, origin)
+    for q in np.unique(jobs["qp"]):
+        ctx.set_qp(int(q))
+    got = ctx.me_batch(jobs)
+    want = want.view(got.dtype)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, (len(bad), jobs[bad[0]], got[bad[0]], want[bad[0]])
+    ctx.close()
+
+
 def test_distortions_reproduce_reference_fixtures(gpu_ctx):
     """dist.npz: sa8d_inter / sse_pp / satd / sad of predictions on the golden pictures (gpu_ctx holds them as planes
     0..2), computed by the reference build"""

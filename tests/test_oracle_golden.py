@@ -193,3 +193,28 @@ def test_bidir_mc_costs_match_reference_fixtures(oracle):
     g = np.load(os.path.join(GOLD, "bidir_mc.npz"))
     got = oracle.bidir_cost_batch([p.as_tuple() for p in golden_planes()], g["reqs"])
     assert np.array_equal(got, g["costs"])
+
+
+def encoder_fixture():
+    """encoder_me.npz: motionEstimate calls intercepted inside the reference encoder (--preset medium, 416x240 synthetic
+    clip; oracle/enc_capture.cpp): planes as (buffer, origin, stride) tuples, jobs, results"""
+    g = np.load(os.path.join(GOLD, "encoder_me.npz"))
+    planes, pos = [], 0
+    for nbytes, origin, stride in g["plane_geo"]:
+        planes.append((g["plane_bytes"][pos:pos + nbytes].copy(), int(origin), int(stride)))
+        pos += int(nbytes)
+    return planes, g["jobs"], g["results"]
+
+
+def test_encoder_calls_match_reference_fixture(oracle):
+    """what the reference encoder itself asked of motionEstimate and got back: AMVP predictors and candidate lists,
+    real search bounds and QPs, reconstructed references, the lookahead's lowres searches"""
+    from oracle import pyoracle
+    planes, jobs, want = encoder_fixture()
+    jobs = jobs.view(pyoracle.ME_JOB)
+    assert (jobs["method"] & 0x80).any() and not (jobs["method"] & 0x80).all() and jobs["num_mvc"].max() >= 5
+    tabs = {int(q): oracle.bitcost_table(int(q)) for q in np.unique(jobs["qp"])}
+    got = oracle.me_batch(planes, tabs, jobs, nthreads=8)
+    want = want.view(got.dtype)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, (jobs[bad[0]], got[bad[0]], want[bad[0]])

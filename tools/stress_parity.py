@@ -79,8 +79,15 @@ for r in reqs:
     r["qmv_x"], r["qmv_y"] = int(rng.integers(-200, 200)), int(rng.integers(-200, 200))
 report("cost_batch", ctx.cost_batch(reqs), O.cost_batch(pl, reqs, nthreads=16), reqs)
 
-br = random_bidir_reqs(rng, 2 * N, W, H, abi.BIDIR_REQ, abi.PARTS, planes=(1, 0, 2, 4))
+br = random_bidir_reqs(rng, 2 * N, W, H, abi.BIDIR_REQ, abi.PARTS, planes=(1, 0, 2, 4), metrics=(0, 1, 2, 3), flags=(0, abi.MC_AVG))
 report("bidir_cost_batch", ctx.bidir_cost_batch(br), O.bidir_cost_batch(pl, br), br)
+from conftest import random_lowres_bidir_reqs
+lbr = np.concatenate([random_lowres_bidir_reqs(rng, N // 2, size[0], size[1], abi.BIDIR_REQ, metric=m) for m in (0, 1)])
+want = O.bidir_cost_batch(low, lbr)
+glbr = lbr.copy()
+for k in ("fenc_plane", "ref0_plane", "ref1_plane"):
+    glbr[k] += 8
+report("bidir_cost_batch lowres", ctx.bidir_cost_batch(glbr), want, lbr)
 # mode-decision distortions: all four comparisons, natural / flat / noise planes
 dr = random_cost_reqs(rng, 4 * N, W, H, abi.COST_REQ, abi.PARTS, metrics=(0, 1, 2, 2, 3, 3), planes=(1, (0, 2, 3, 4)))
 dr["fenc_plane"] = rng.choice([1, 4], len(dr))
