@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import torch
 from x265_amd import abi, lib
+if os.environ.get("X265_EXP_LIB"):  # experiments: another build of the library
+    lib.LIB_PATH = os.path.abspath(os.environ["X265_EXP_LIB"])
 sys.argv = [sys.argv[0], sys.argv[1], "none"]
 import importlib.util
 spec = importlib.util.spec_from_file_location("rc", os.path.join(ROOT, "tools", "replay_capture.py"))
