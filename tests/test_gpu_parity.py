@@ -431,3 +431,55 @@ def test_bidir_cost_mc_average_and_all_metrics(gpu_ctx, oracle, small_seq):
         got, want = gpu_ctx.bidir_cost_batch(reqs), oracle.bidir_cost_batch(planes, reqs)
         bad = np.nonzero(got != want)[0]
         assert len(bad) == 0, (reqs[bad[0]], got[bad[0]], want[bad[0]])
+
+
+def test_concurrent_contexts_and_table_calls(oracle, small_seq, costtabs):
+    """threading as the reference uses the path: several host threads, each with its own context,
+    search at the same time while other threads call primitive-table entries (which share the default context);
+    every result equals the oracle's"""
+    import ctypes as C
+    import threading
+    from x265_amd import abi, lib, synth
+    W, H = small_seq[0].w, small_seq[0].h
+    planes = _planes(small_seq)
+    table = lib.setup_primitives(0)
+    errors = []
+
+    def searcher(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            ctx = lib.Context(0)
+            for i, p in enumerate(small_seq):
+                ctx.plane_upload(i, p.buf, p.stride, p.origin)
+            for q, t in costtabs.items():
+                ctx.costtab_upload(q, t)
+            for rnd in range(4):
+                jobs = random_me_jobs(rng, 400, int(rng.integers(0, 4)), int(rng.integers(0, 8)), W, H, abi.ME_JOB,
+                                      synth.search_range, abi.PARTS)
+                got, want = ctx.me_batch(jobs), oracle.me_batch(planes, costtabs, jobs)
+                if not np.array_equal(got, want):
+                    errors.append(("me_batch", seed, rnd))
+            ctx.close()
+        except Exception as e:  # noqa: BLE001 - reported by the assertion below
+            errors.append(("searcher", seed, repr(e)))
+
+    def table_user(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            a = rng.integers(0, 256, 64 * 80, dtype=np.uint8)
+            b = rng.integers(0, 256, 100 * 80, dtype=np.uint8)
+            for _ in range(60):
+                part = int(rng.integers(0, 25))
+                got = table.satd[part](C.c_void_p(a.ctypes.data), 64, C.c_void_p(b.ctypes.data + 7), 100)
+                if got != oracle.satd(part, a, 0, 64, b, 7, 100):
+                    errors.append(("satd", seed, part))
+        except Exception as e:  # noqa: BLE001
+            errors.append(("table_user", seed, repr(e)))
+
+    threads = [threading.Thread(target=searcher, args=(70 + k,)) for k in range(3)]
+    threads += [threading.Thread(target=table_user, args=(80 + k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
