@@ -9,7 +9,9 @@
  * first time each buffer content is seen.  oracle/gen_golden.py turns the two output files into
  * tests/golden/encoder_me.npz, which the oracle and the HIP path must reproduce call for call.
  *
- *   enc_capture in.yuv width height frames out_dir [max_full_calls [max_lowres_calls [first_full_call]]]
+ *   enc_capture in.yuv width height frames out_dir [max_full_calls [max_lowres_calls [first_full_call
+ *               [pool_threads [frame_threads]]]]]
+ * With both call limits 0 nothing is recorded and the program is the reference encoder timed end to end.
  */
 #include <map>
 #include <mutex>
@@ -188,7 +190,7 @@ int main(int argc, char **argv)
 {
     if (argc < 6)
     {
-        fprintf(stderr, "usage: %s in.yuv width height frames out_dir [max_full [max_lowres [first_full]]]\n", argv[0]);
+        fprintf(stderr, "usage: %s in.yuv width height frames out_dir [max_full [max_lowres [first_full [pool_threads [frame_threads]]]]]\n", argv[0]);
         return 2;
     }
     g_width = atoi(argv[2]);
@@ -201,6 +203,8 @@ int main(int argc, char **argv)
         g_max_low = atol(argv[7]);
     if (argc > 8)
         g_first_full = atol(argv[8]);
+    /* timing runs: thread counts as the CLI's --threads / --frame-threads, 0 = the encoder's default */
+    const int pool_threads = argc > 9 ? atoi(argv[9]) : 4, frame_threads = argc > 10 ? atoi(argv[10]) : 1;
     FILE *in = fopen(argv[1], "rb");
     g_planes = fopen((dir + "/planes.bin").c_str(), "wb");
     if (!in || !g_planes)
@@ -217,8 +221,8 @@ int main(int argc, char **argv)
     p->sourceHeight = g_height;
     p->fpsNum = 25;
     p->fpsDenom = 1;
-    p->frameNumThreads = 1;
-    p->poolNumThreads = 4;
+    p->frameNumThreads = frame_threads;
+    p->poolNumThreads = pool_threads;
     p->logLevel = X265_LOG_WARNING;
     x265_encoder *enc = x265_encoder_open(p);
     if (!enc)

@@ -471,3 +471,55 @@ void x265r_ctu_fullsearch(const x265o_plane *fenc, const x265o_plane *ref, const
     }
 }
 }
+
+/* ns per call of one reference C primitive, TestBench-style loop with the argument shapes of
+ * test/pixelharness.cpp:1480-1521 and test/ipfilterharness.cpp:703-757 (fenc stride 64, reference stride 64 + a few).
+ * kind: 0 sad, 1 sad_x3, 2 sad_x4, 3 satd, 4 luma_hpp, 5 luma_vpp, 6 luma_hps (row extension) + luma_vsp */
+#include <time.h>
+extern "C" double x265r_time_primitive(int kind, int part, int iters)
+{
+    init();
+    static pixel fenc[64 * 64 + 64], frefbuf[80 * 200], dst[64 * 64];
+    static int16_t immed[64 * (64 + 8)];
+    static int seeded = 0;
+    if (!seeded)
+    {
+        unsigned s = 12345;
+        for (size_t i = 0; i < sizeof(fenc); i++)
+            fenc[i] = (pixel)((s = s * 1664525u + 1013904223u) >> 24);
+        for (size_t i = 0; i < sizeof(frefbuf); i++)
+            frefbuf[i] = (pixel)((s = s * 1664525u + 1013904223u) >> 24);
+        seeded = 1;
+    }
+    const intptr_t rs = 80;
+    pixel *fref = frefbuf + 8 * rs + 8;
+    int w = 0, h = 0;
+    for (int ww = 4; ww <= 64; ww += 4)
+        for (int hh = 4; hh <= 64; hh += 4)
+            if (partitionFromSizes(ww, hh) == part)
+                w = ww, h = hh;
+    (void)h;
+    ALIGN_VAR_16(int32_t, res[4]);
+    volatile int sink = 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0; i < iters; i++)
+    {
+        pixel *r = fref + (i & 7);
+        switch (kind)
+        {
+        case 0: sink += g_c.sad[part](fenc, 64, r, rs); break;
+        case 1: g_c.sad_x3[part](fenc, r, r + 1, r - 1, rs, res); sink += res[0]; break;
+        case 2: g_c.sad_x4[part](fenc, r, r + 1, r - 1, r - rs, rs, res); sink += res[0]; break;
+        case 3: sink += g_c.satd[part](fenc, 64, r, rs); break;
+        case 4: g_c.luma_hpp[part](r, rs, dst, 64, 1 + (i % 3)); sink += dst[0]; break;
+        case 5: g_c.luma_vpp[part](r, rs, dst, 64, 1 + (i % 3)); sink += dst[0]; break;
+        default:
+            g_c.luma_hps[part](r, rs, immed, w, 1 + (i % 3), 1);
+            g_c.luma_vsp[part](immed + 3 * w, w, dst, 64, 3 - (i % 3));
+            sink += dst[0];
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / iters;
+}
