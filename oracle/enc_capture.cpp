@@ -33,7 +33,11 @@
 #undef protected
 #undef private
 #include "x265.h"
+#include <time.h>
 
+namespace x265 {
+void Setup_HIP_Primitives(EncoderPrimitives &p, x265_param *param, int device); /* source/common/hip/hip-primitives.cpp */
+}
 using namespace x265;
 
 #define ME_SYM "_ZN4x26514MotionEstimate14motionEstimateEPNS_15ReferencePlanesERKNS_2MVES5_S5_iPS4_iRS3_"
@@ -230,6 +234,23 @@ int main(int argc, char **argv)
         fprintf(stderr, "x265_encoder_open failed\n");
         return 1;
     }
+#ifdef WITH_HIP
+    /* Drop-in demonstration: the reference encoder with the function-pointer table overwritten by
+     * source/common/hip/hip-primitives.cpp.  A patched x265_setup_primitives() would call Setup_HIP_Primitives before
+     * Setup_Alias_Primitives; here the table is already set up, so the aliases that function derives from the
+     * replaced entries (primitives.cpp:95-113) are refreshed by hand. */
+    if (getenv("X265_USE_HIP"))
+    {
+        Setup_HIP_Primitives(primitives, p, 0);
+        static const int sq[5] = { LUMA_4x4, LUMA_8x8, LUMA_16x16, LUMA_32x32, LUMA_64x64 };
+        for (int i = 0; i < 5; i++)
+        {
+            primitives.sad_square[i] = primitives.sad[sq[i]];
+            primitives.sa8d[i] = primitives.sa8d_inter[sq[i]];
+        }
+        fprintf(stderr, "enc_capture: HIP primitive table installed\n");
+    }
+#endif
     x265_picture pic;
     x265_picture_init(p, &pic);
     const size_t ysz = (size_t)g_width * g_height, csz = ysz / 4;
@@ -237,6 +258,18 @@ int main(int argc, char **argv)
     x265_nal *nal;
     uint32_t nnal;
     size_t bytes_out = 0;
+    uint64_t hash = 1469598103934665603ull; /* FNV-1a of the bitstream, to compare runs */
+    int fed = 0, got = 0;
+    auto take = [&]() {
+        for (uint32_t i = 0; i < nnal; i++)
+        {
+            bytes_out += nal[i].sizeBytes;
+            for (uint32_t k = 0; k < nal[i].sizeBytes; k++)
+                hash = (hash ^ nal[i].payload[k]) * 1099511628211ull;
+        }
+    };
+    struct timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
     for (int f = 0; f < frames; f++)
     {
         if (fread(buf.data(), 1, buf.size(), in) != buf.size())
@@ -248,13 +281,27 @@ int main(int argc, char **argv)
         pic.stride[1] = pic.stride[2] = g_width / 2;
         pic.bitDepth = 8;
         pic.pts = f;
+        fed++;
         if (x265_encoder_encode(enc, &nal, &nnal, &pic, NULL) > 0)
-            for (uint32_t i = 0; i < nnal; i++)
-                bytes_out += nal[i].sizeBytes;
+        {
+            got++;
+            take();
+        }
     }
-    while (x265_encoder_encode(enc, &nal, &nnal, NULL, NULL) > 0)
-        for (uint32_t i = 0; i < nnal; i++)
-            bytes_out += nal[i].sizeBytes;
+    /* flush: the first calls may return 0 while the lookahead is still handing pictures over (clips shorter than
+     * the lookahead), so stop only when every picture fed has come out */
+    for (int idle = 0; got < fed && idle < 1000;)
+    {
+        if (x265_encoder_encode(enc, &nal, &nnal, NULL, NULL) > 0)
+        {
+            got++;
+            idle = 0;
+            take();
+        }
+        else
+            idle++;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
     x265_encoder_close(enc);
     x265_param_free(p);
     x265_cleanup();
@@ -262,6 +309,8 @@ int main(int argc, char **argv)
     FILE *out = fopen((dir + "/calls.bin").c_str(), "wb");
     fwrite(g_calls.data(), sizeof(CallRec), g_calls.size(), out);
     fclose(out);
+    fprintf(stderr, "enc_capture: %d pictures in %.2f s, bitstream hash %016llx\n", got,
+            (ts1.tv_sec - ts0.tv_sec) + (ts1.tv_nsec - ts0.tv_nsec) * 1e-9, (unsigned long long)hash);
     fprintf(stderr, "enc_capture: %zu bytes of bitstream, %ld full-resolution + %ld lowres motionEstimate calls recorded, %d planes\n",
             bytes_out, g_n_full, g_n_low, g_next_plane);
     return 0;

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Drop-in demonstration: the reference encoder (oracle/_ref/enc_hip = the reference's own sources
+# + source/common/hip/hip-primitives.cpp + libx265_hip.so) encodes the same clip twice, once with its C primitives
+# and once with the HIP primitive table installed; the two bitstreams must be identical.
+#   tools/dropin_demo.sh [width height frames]
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+W=${1:-416}; H=${2:-240}; N=${3:-6}
+cd "$R" || exit 1
+python3 - "$W" "$H" "$N" <<'PY' || exit 1
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+from x265_amd import synth
+W, H, N = (int(v) for v in sys.argv[1:4])
+seq = synth.Sequence(W, H, seed=7, n_patches=3)
+with open("/tmp/dropin.yuv", "wb") as f:
+    for i in range(N):
+        f.write(seq.frame(i).astype(np.uint8).tobytes())
+        f.write(bytes([128]) * (W * H // 2))
+PY
+echo "== C primitives"
+timeout -k 10 300 oracle/_ref/enc_hip /tmp/dropin.yuv "$W" "$H" "$N" /tmp 0 0 0 4 1 2>&1 | grep -v "Assembly not supported" | tee /tmp/dropin_c.txt || exit 1
+echo "== HIP primitive table"
+X265_USE_HIP=1 timeout -k 10 900 oracle/_ref/enc_hip /tmp/dropin.yuv "$W" "$H" "$N" /tmp 0 0 0 4 1 2>&1 | grep -v "Assembly not supported" | tee /tmp/dropin_hip.txt || exit 1
+a=$(grep -o "hash [0-9a-f]*" /tmp/dropin_c.txt); b=$(grep -o "hash [0-9a-f]*" /tmp/dropin_hip.txt)
+if [ -n "$a" ] && [ "$a" == "$b" ] && grep -q "HIP primitive table installed" /tmp/dropin_hip.txt; then echo "DROP-IN OK: identical bitstreams ($a)"; else echo "DROP-IN MISMATCH: '$a' vs '$b'"; exit 1; fi
