@@ -105,3 +105,25 @@ def test_hot_kernels_use_no_scratch(tmp_path):
                 seen.add(kernel)
                 assert int(m.group(2)) <= allowed.get(kernel, 0), (kernel, m.group(2))
     assert seen == {"me_kernel", "cost_kernel", "dist_kernel", "predict_kernel", "fullsearch2_kernel"}
+
+
+def test_python_struct_layouts_match_the_header(tmp_path):
+    """the ctypes / numpy mirrors of the C structs must have the header's sizes: x265_hip_setup_primitives writes the
+    whole table, a shorter Python struct would be overrun"""
+    import ctypes
+    import shutil
+    import subprocess
+    from x265_amd import abi, lib
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        pytest.skip("no C compiler")
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "x265_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", '
+                   'sizeof(x265_hip_primitives), sizeof(x265_hip_me_job), sizeof(x265_hip_me_result), sizeof(x265_hip_cost_req), '
+                   'sizeof(x265_hip_bidir_req), sizeof(x265_hip_pred_req), sizeof(x265_hip_ctu_job)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call([cc, "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(lib.Primitives), abi.ME_JOB.itemsize, abi.ME_RESULT.itemsize, abi.COST_REQ.itemsize,
+            abi.BIDIR_REQ.itemsize, abi.PRED_REQ.itemsize, lib.CTU_JOB.itemsize]
+    assert got == want
