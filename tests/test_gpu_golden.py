@@ -234,3 +234,34 @@ def test_bad_arguments_are_rejected(gpu_ctx):
     pr["pu_y"] = 400
     with pytest.raises(lib.X265HipError):
         gpu_ctx.predict_batch(pr)  # destination block below the padded plane
+
+
+def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
+    """the drop-in itself: oracle/_ref/enc_hip is the reference encoder (its own sources) linked with
+    source/common/hip/hip-primitives.cpp and libx265_hip.so; with the table installed it must produce the bitstream
+    its C primitives produce.  Present only where the reference was available to build it (`make -C oracle dropin`)."""
+    import re
+    import subprocess
+    from x265_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "enc_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/enc_hip not built")
+    W, H, N = 208, 128, 3
+    seq = synth.Sequence(W, H, seed=7, n_patches=2)
+    clip = tmp_path / "in.yuv"
+    with open(clip, "wb") as f:
+        for i in range(N):
+            f.write(seq.frame(i).astype(np.uint8).tobytes())
+            f.write(bytes([128]) * (W * H // 2))
+    hashes = []
+    for use_hip in (False, True):
+        env = dict(os.environ)
+        if use_hip:
+            env["X265_USE_HIP"] = "1"
+        r = subprocess.run([exe, str(clip), str(W), str(H), str(N), str(tmp_path), "0", "0", "0", "2", "1"], env=env,
+                           capture_output=True, text=True, timeout=100)
+        assert r.returncode == 0, r.stderr
+        assert ("HIP primitive table installed" in r.stderr) == use_hip
+        hashes.append(re.search(r"%d pictures in .* bitstream hash ([0-9a-f]+)" % N, r.stderr).group(1))
+    assert hashes[0] == hashes[1]
