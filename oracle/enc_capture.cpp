@@ -142,11 +142,99 @@ int qp_of(const uint16_t *m_cost)
 
 } // namespace
 
+#ifdef WITH_HIP
+/* X265_USE_HIP_ME=1: every full-resolution motionEstimate call of the encoder is answered by x265_hip_me_batch (one
+ * job per call: slow, but it is the encoder's own control flow around the batched entry point).  Planes are kept
+ * on the device in an LRU of 60 slots keyed by buffer and content. */
+#include "x265_hip.h"
+namespace {
+bool g_hip_me = false;
+x265_hip_ctx *g_ctx = nullptr;
+long g_hip_calls = 0, g_hip_mismatch = 0, g_tick = 0;
+struct Slot
+{
+    const pixel *base;
+    uint32_t sum;
+    long used;
+};
+Slot g_slots[60];
+bool g_qp_set[82];
+
+int device_plane(const pixel *origin, int stride, int rows)
+{
+    const pixel *base = origin - (intptr_t)MY * stride - MX;
+    const size_t bytes = (size_t)stride * (rows + 2 * MY);
+    const uint32_t sum = sparse_sum(base, bytes);
+    int lru = 0;
+    for (int i = 0; i < 60; i++)
+    {
+        if (g_slots[i].base == base && g_slots[i].sum == sum)
+        {
+            g_slots[i].used = ++g_tick;
+            return i;
+        }
+        if (g_slots[i].used < g_slots[lru].used)
+            lru = i;
+    }
+    if (x265_hip_plane_upload(g_ctx, lru, base, bytes, stride, MY * stride + MX) != X265_HIP_OK)
+    {
+        fprintf(stderr, "plane_upload: %s\n", x265_hip_last_error());
+        abort();
+    }
+    g_slots[lru] = Slot{ base, sum, ++g_tick };
+    return lru;
+}
+} // namespace
+#endif
+
 int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp, int numc,
             const MV *mvc, int merange, MV &out)
 {
-    const int cost = real_me(self, ref, mvmin, mvmax, qmvp, numc, mvc, merange, out);
+    int cost = real_me(self, ref, mvmin, mvmax, qmvp, numc, mvc, merange, out);
     std::lock_guard<std::mutex> g(g_mu);
+#ifdef WITH_HIP
+    if (g_hip_me && !ref->isLowres && numc <= X265_HIP_MAX_MVC)
+    {
+        const int stride = (int)self->fencLumaStride, rows = (g_height + 63) / 64 * 64;
+        x265_hip_me_job j;
+        memset(&j, 0, sizeof(j));
+        j.fenc_plane = device_plane(self->fencplane, stride, rows);
+        j.ref_plane = device_plane(ref->fpelPlane, ref->lumaStride, rows);
+        if (g_slots[j.fenc_plane].base != self->fencplane - (intptr_t)MY * stride - MX) /* evicted by the second upload */
+            j.fenc_plane = device_plane(self->fencplane, stride, rows);
+        j.pu_x = (int16_t)(self->blockOffset % stride);
+        j.pu_y = (int16_t)(self->blockOffset / stride);
+        j.pu_w = (uint8_t)self->blockwidth;
+        j.pu_h = (uint8_t)self->blockheight;
+        j.method = (uint8_t)self->searchMethod;
+        j.subme = (uint8_t)self->subpelRefine;
+        j.mvmin_x = mvmin.x, j.mvmin_y = mvmin.y, j.mvmax_x = mvmax.x, j.mvmax_y = mvmax.y;
+        j.qmvp_x = qmvp.x, j.qmvp_y = qmvp.y;
+        j.merange = (int16_t)merange;
+        j.num_mvc = (uint8_t)numc;
+        for (int i = 0; i < numc; i++)
+            j.mvc[2 * i] = mvc[i].x, j.mvc[2 * i + 1] = mvc[i].y;
+        j.qp = (uint8_t)qp_of(self->m_cost);
+        if (!g_qp_set[j.qp])
+        {
+            x265_hip_costtab_set_qp(g_ctx, j.qp);
+            g_qp_set[j.qp] = true;
+        }
+        x265_hip_me_result r;
+        if (x265_hip_me_batch(g_ctx, &j, 1, &r) != X265_HIP_OK)
+        {
+            fprintf(stderr, "me_batch: %s\n", x265_hip_last_error());
+            abort();
+        }
+        g_hip_calls++;
+        if (r.cost != cost || r.mvx != out.x || r.mvy != out.y)
+            g_hip_mismatch++;
+        /* the encoder goes on with the GPU's answer */
+        cost = r.cost;
+        out.x = r.mvx;
+        out.y = r.mvy;
+    }
+#endif
     const bool low = ref->isLowres;
     if (!low && g_seen_full++ < g_first_full)
         return cost;
@@ -250,6 +338,16 @@ int main(int argc, char **argv)
         }
         fprintf(stderr, "enc_capture: HIP primitive table installed\n");
     }
+    if (getenv("X265_USE_HIP_ME"))
+    {
+        if (x265_hip_ctx_create(0, &g_ctx) != X265_HIP_OK)
+        {
+            fprintf(stderr, "x265_hip_ctx_create: %s\n", x265_hip_last_error());
+            return 1;
+        }
+        g_hip_me = true;
+        fprintf(stderr, "enc_capture: motionEstimate answered by x265_hip_me_batch\n");
+    }
 #endif
     x265_picture pic;
     x265_picture_init(p, &pic);
@@ -311,6 +409,11 @@ int main(int argc, char **argv)
     fclose(out);
     fprintf(stderr, "enc_capture: %d pictures in %.2f s, bitstream hash %016llx\n", got,
             (ts1.tv_sec - ts0.tv_sec) + (ts1.tv_nsec - ts0.tv_nsec) * 1e-9, (unsigned long long)hash);
+#ifdef WITH_HIP
+    if (g_hip_me)
+        fprintf(stderr, "enc_capture: %ld motionEstimate calls answered on the GPU, %ld differed from the reference's own answer\n",
+                g_hip_calls, g_hip_mismatch);
+#endif
     fprintf(stderr, "enc_capture: %zu bytes of bitstream, %ld full-resolution + %ld lowres motionEstimate calls recorded, %d planes\n",
             bytes_out, g_n_full, g_n_low, g_next_plane);
     return 0;

@@ -238,8 +238,8 @@ def test_bad_arguments_are_rejected(gpu_ctx):
 
 def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
     """the drop-in itself: oracle/_ref/enc_hip is the reference encoder (its own sources) linked with
-    source/common/hip/hip-primitives.cpp and libx265_hip.so; with the table installed it must produce the bitstream
-    its C primitives produce.  Present only where the reference was available to build it (`make -C oracle dropin`)."""
+    source/common/hip/hip-primitives.cpp and libx265_hip.so; with the table installed, and with every motionEstimate
+    call answered by x265_hip_me_batch instead, it must produce the bitstream its C primitives produce.  Present only where the reference was available to build it (`make -C oracle dropin`)."""
     import re
     import subprocess
     from x265_amd import synth
@@ -255,13 +255,16 @@ def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
             f.write(seq.frame(i).astype(np.uint8).tobytes())
             f.write(bytes([128]) * (W * H // 2))
     hashes = []
-    for use_hip in (False, True):
+    for mode in (None, "X265_USE_HIP", "X265_USE_HIP_ME"):  # C primitives; HIP table; motionEstimate via x265_hip_me_batch
         env = dict(os.environ)
-        if use_hip:
-            env["X265_USE_HIP"] = "1"
+        if mode:
+            env[mode] = "1"
         r = subprocess.run([exe, str(clip), str(W), str(H), str(N), str(tmp_path), "0", "0", "0", "2", "1"], env=env,
                            capture_output=True, text=True, timeout=100)
         assert r.returncode == 0, r.stderr
-        assert ("HIP primitive table installed" in r.stderr) == use_hip
+        assert ("HIP primitive table installed" in r.stderr) == (mode == "X265_USE_HIP")
+        if mode == "X265_USE_HIP_ME":
+            m = re.search(r"(\d+) motionEstimate calls answered on the GPU, (\d+) differed", r.stderr)
+            assert m and int(m.group(1)) > 100 and int(m.group(2)) == 0, r.stderr
         hashes.append(re.search(r"%d pictures in .* bitstream hash ([0-9a-f]+)" % N, r.stderr).group(1))
-    assert hashes[0] == hashes[1]
+    assert hashes[0] == hashes[1] == hashes[2]

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Drop-in demonstration: the reference encoder (oracle/_ref/enc_hip = the reference's own sources
 # + source/common/hip/hip-primitives.cpp + libx265_hip.so) encodes the same clip twice, once with its C primitives
-# and once with the HIP primitive table installed; the two bitstreams must be identical.
+# once with the HIP primitive table installed, and once with every full-resolution MotionEstimate::motionEstimate call
+# answered by x265_hip_me_batch; the three bitstreams must be identical.
 #   tools/dropin_demo.sh [width height frames]
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -23,5 +24,12 @@ echo "== C primitives"
 timeout -k 10 300 oracle/_ref/enc_hip /tmp/dropin.yuv "$W" "$H" "$N" /tmp 0 0 0 4 1 2>&1 | grep -v "Assembly not supported" | tee /tmp/dropin_c.txt || exit 1
 echo "== HIP primitive table"
 X265_USE_HIP=1 timeout -k 10 900 oracle/_ref/enc_hip /tmp/dropin.yuv "$W" "$H" "$N" /tmp 0 0 0 4 1 2>&1 | grep -v "Assembly not supported" | tee /tmp/dropin_hip.txt || exit 1
-a=$(grep -o "hash [0-9a-f]*" /tmp/dropin_c.txt); b=$(grep -o "hash [0-9a-f]*" /tmp/dropin_hip.txt)
-if [ -n "$a" ] && [ "$a" == "$b" ] && grep -q "HIP primitive table installed" /tmp/dropin_hip.txt; then echo "DROP-IN OK: identical bitstreams ($a)"; else echo "DROP-IN MISMATCH: '$a' vs '$b'"; exit 1; fi
+echo "== motionEstimate answered by x265_hip_me_batch (C primitives elsewhere)"
+X265_USE_HIP_ME=1 timeout -k 10 900 oracle/_ref/enc_hip /tmp/dropin.yuv "$W" "$H" "$N" /tmp 0 0 0 4 1 2>&1 | grep -v "Assembly not supported" | tee /tmp/dropin_me.txt || exit 1
+a=$(grep -o "hash [0-9a-f]*" /tmp/dropin_c.txt); b=$(grep -o "hash [0-9a-f]*" /tmp/dropin_hip.txt); c=$(grep -o "hash [0-9a-f]*" /tmp/dropin_me.txt)
+if [ -n "$a" ] && [ "$a" == "$b" ] && [ "$a" == "$c" ] && grep -q "HIP primitive table installed" /tmp/dropin_hip.txt &&
+   grep -q "answered on the GPU, 0 differed" /tmp/dropin_me.txt; then
+  echo "DROP-IN OK: identical bitstreams ($a)"
+else
+  echo "DROP-IN MISMATCH: '$a' vs '$b' vs '$c'"; exit 1
+fi
