@@ -3,9 +3,9 @@
 # + source/common/hip/hip-primitives.cpp + libx265_hip.so) encodes the same clip twice, once with its C primitives
 # once with the HIP primitive table installed, and once with every full-resolution MotionEstimate::motionEstimate call
 # answered by x265_hip_me_batch; the three bitstreams must be identical.
-#   tools/dropin_demo.sh [width height frames]
+#   tests/tools/dropin_demo.sh [width height frames]
 set -o pipefail
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 W=${1:-416}; H=${2:-240}; N=${3:-6}
 cd "$R" || exit 1
 python3 - "$W" "$H" "$N" <<'PY' || exit 1

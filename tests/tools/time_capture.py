@@ -1,18 +1,15 @@
 """Time x265_hip_me_batch_device on the full-resolution calls of an encoder capture (argv[1]); jobs resident in HBM."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import torch
 from x265_amd import abi, lib
 if os.environ.get("X265_EXP_LIB"):  # experiments: another build of the library
     lib.LIB_PATH = os.path.abspath(os.environ["X265_EXP_LIB"])
 sys.argv = [sys.argv[0], sys.argv[1], "none"]
-import importlib.util
-spec = importlib.util.spec_from_file_location("rc", os.path.join(ROOT, "tools", "replay_capture.py"))
-src = open(os.path.join(ROOT, "tools", "replay_capture.py")).read().split("t0 = time.time()")[0]
-ns = {"__file__": os.path.join(ROOT, "tools", "replay_capture.py")}
+src = open(os.path.join(ROOT, "tests", "tools", "replay_capture.py")).read().split("t0 = time.time()")[0]
+ns = {"__file__": os.path.join(ROOT, "tests", "tools", "replay_capture.py")}
 exec(compile(src, "replay_capture_head", "exec"), ns)
 jobs, planes, calls = ns["jobs"], ns["planes"], ns["calls"]
 assert len(planes) <= 64

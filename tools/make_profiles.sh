@@ -13,6 +13,6 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d "$O/pmc_fetch" -o fetch --output-format csv -- python3 "$R/tools/prof_me.py" all > "$O/pmc_fetch.log" 2>&1 &&
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d "$O/pmc_write" -o write --output-format csv -- python3 "$R/tools/prof_me.py" all > "$O/pmc_write.log" 2>&1 &&
 cd "$R" &&
-timeout -k 10 500 python3 tools/report_configs.py > "$O/configs.json" 2> "$O/configs.err" &&
+timeout -k 10 500 python3 tests/tools/report_configs.py > "$O/configs.json" 2> "$O/configs.err" &&
 timeout -k 10 400 python3 bench.py > "$O/bench.json" 2> "$O/bench.err" &&
 echo PROFILES_OK
