@@ -483,3 +483,70 @@ def test_concurrent_contexts_and_table_calls(oracle, small_seq, costtabs):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_device_resident_entry_points(gpu_ctx, oracle, small_seq, costtabs):
+    """the `_device` forms (records and results in HBM, asynchronous on the context's stream) against the oracle:
+    me_batch, cost_batch, dist_batch, bidir_cost_batch, predict_batch, fullsearch"""
+    import ctypes as C
+    from conftest import random_bidir_reqs, random_cost_reqs, random_pred_reqs
+    from x265_amd import abi, lib, synth
+    hip = C.CDLL("libamdhip64.so")  # plain HIP allocations: what a C host would hand over
+    rng = np.random.default_rng(65)
+    W, H = small_seq[0].w, small_seq[0].h
+    planes = _planes(small_seq)
+    held = []
+
+    def dev_alloc(nbytes):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(max(nbytes, 16))) == 0
+        held.append(p)
+        return p
+
+    def to_dev(a):
+        a = np.ascontiguousarray(a)
+        p = dev_alloc(a.nbytes)
+        assert hip.hipMemcpy(p, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), 1) == 0  # hipMemcpyHostToDevice
+        return p.value
+
+    def run(call, recs, out_dtype, n_out=None):
+        d = to_dev(recs)
+        n_out = len(recs) if n_out is None else n_out
+        out = np.zeros(n_out, out_dtype)
+        o = dev_alloc(out.nbytes)
+        call(d, len(recs), o.value)
+        gpu_ctx.sync()
+        assert hip.hipMemcpy(C.c_void_p(out.ctypes.data), o, C.c_size_t(out.nbytes), 2) == 0  # hipMemcpyDeviceToHost
+        return out
+
+    jobs = random_me_jobs(rng, 600, 1, 2, W, H, abi.ME_JOB, synth.search_range, abi.PARTS)
+    assert np.array_equal(run(gpu_ctx.me_batch_device, jobs, abi.ME_RESULT), oracle.me_batch(planes, costtabs, jobs))
+    reqs = random_cost_reqs(rng, 1500, W, H, abi.COST_REQ, abi.PARTS)
+    assert np.array_equal(run(gpu_ctx.cost_batch_device, reqs, np.int32), oracle.cost_batch(planes, reqs))
+    reqs = random_cost_reqs(rng, 1500, W, H, abi.COST_REQ, abi.PARTS, metrics=(0, 1, 2, 3))
+    assert np.array_equal(run(gpu_ctx.dist_batch_device, reqs, np.int32), oracle.cost_batch(planes, reqs))
+    br = random_bidir_reqs(rng, 1500, W, H, abi.BIDIR_REQ, abi.PARTS, metrics=(0, 1, 2, 3), flags=(0, abi.MC_AVG))
+    assert np.array_equal(run(gpu_ctx.bidir_cost_batch_device, br, np.int32), oracle.bidir_cost_batch(planes, br))
+    cj = np.zeros(3, lib.CTU_JOB)
+    for k, j in enumerate(cj):
+        j["fenc_plane"], j["ref_plane"], j["ctu_x"], j["ctu_y"], j["qp"] = 1, 0, 64 * (k + 1), 64, 30
+        j["mvmin_x"], j["mvmin_y"], j["mvmax_x"], j["mvmax_y"] = -9 - k, -7, 8, 6 + k
+        j["qmvp_x"], j["qmvp_y"] = 5 * k, -3
+    got = run(gpu_ctx.fullsearch_device, cj, abi.ME_RESULT, n_out=3 * 85).reshape(3, 85)
+    for k, j in enumerate(cj):
+        want = oracle.ctu_fullsearch(planes[1], planes[0], costtabs[30], int(j["ctu_x"]), int(j["ctu_y"]),
+                                     (int(j["mvmin_x"]), int(j["mvmin_y"])), (int(j["mvmax_x"]), int(j["mvmax_y"])),
+                                     (int(j["qmvp_x"]), int(j["qmvp_y"])))
+        assert np.array_equal(got[k], want.view(got.dtype)), k
+    p0 = small_seq[0]
+    want = np.full_like(p0.buf, 0x5A)
+    gpu_ctx.plane_upload(5, want, p0.stride, p0.origin)
+    pr = random_pred_reqs(rng, W, H, abi.PRED_REQ, abi.PARTS, dst_plane=5)
+    gpu_ctx.predict_batch_device(to_dev(pr), len(pr))
+    gpu_ctx.sync()
+    pr["dst_plane"] = 3
+    oracle.predict_batch(planes + [(want, p0.origin, p0.stride)], pr)
+    assert np.array_equal(gpu_ctx.plane_download(5, want.size), want)
+    gpu_ctx.plane_release(5)
+    for p in held:
+        hip.hipFree(p)
