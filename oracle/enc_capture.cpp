@@ -84,10 +84,13 @@ long g_max_full = 4000, g_max_low = 2000, g_first_full = 0, g_seen_full = 0, g_n
 /* TComPicYuv / Lowres layout: margins 80 rows, 96 columns (TComPicYuv.cpp:78-97, lowres.cpp:33-48) */
 const int MX = 96, MY = 80;
 
+bool g_hip_sparse = false;
+
 uint32_t sparse_sum(const pixel *p, size_t n)
 {
     uint32_t s = 2166136261u;
-    for (size_t i = 0; i < n; i += 29)
+    const size_t step = g_hip_sparse ? (n / 2048) | 1 : 29; /* in-situ runs take a sum per call: about 2048 samples */
+    for (size_t i = 0; i < n; i += step)
         s = (s ^ p[i]) * 16777619u;
     return s;
 }
@@ -143,7 +146,7 @@ int qp_of(const uint16_t *m_cost)
 } // namespace
 
 #ifdef WITH_HIP
-/* X265_USE_HIP_ME=1: every full-resolution motionEstimate call of the encoder is answered by x265_hip_me_batch (one
+/* X265_USE_HIP_ME=1: every motionEstimate call of the encoder, the lookahead's included, is answered by x265_hip_me_batch (one
  * job per call: slow, but it is the encoder's own control flow around the batched entry point).  Planes are kept
  * on the device in an LRU of 60 slots keyed by buffer and content. */
 #include "x265_hip.h"
@@ -158,7 +161,7 @@ struct Slot
     long used;
 };
 Slot g_slots[60];
-bool g_qp_set[82];
+bool g_qp_set[2][82];
 
 int device_plane(const pixel *origin, int stride, int rows)
 {
@@ -184,6 +187,65 @@ int device_plane(const pixel *origin, int stride, int rows)
     g_slots[lru] = Slot{ base, sum, ++g_tick };
     return lru;
 }
+
+/* The lookahead's calls (ReferencePlanes::isLowres) go to a second context: slots 0..15 hold source planes
+ * (lowresPlane[0] of the picture being estimated), slots 16..63 twelve groups of lowresPlane[0..3]. */
+x265_hip_ctx *g_ctx_low = nullptr;
+long g_hip_low_calls = 0, g_hip_low_mismatch = 0;
+Slot g_low_src[16], g_low_ref[12];
+
+void upload_low(int id, const pixel *origin, int stride, int lines)
+{
+    const pixel *base = origin - (intptr_t)MY * stride - MX;
+    if (x265_hip_plane_upload(g_ctx_low, id, base, (size_t)stride * (lines + 2 * MY), stride, MY * stride + MX) != X265_HIP_OK)
+    {
+        fprintf(stderr, "plane_upload (lowres): %s\n", x265_hip_last_error());
+        abort();
+    }
+}
+
+int find_slot(Slot *slots, int n, const pixel *base, uint32_t sum, bool &hit)
+{
+    int lru = 0;
+    for (int i = 0; i < n; i++)
+    {
+        if (slots[i].base == base && slots[i].sum == sum)
+        {
+            slots[i].used = ++g_tick;
+            hit = true;
+            return i;
+        }
+        if (slots[i].used < slots[lru].used)
+            lru = i;
+    }
+    slots[lru] = Slot{ base, sum, ++g_tick };
+    hit = false;
+    return lru;
+}
+
+int device_low_src(const pixel *origin, int stride, int lines)
+{
+    const pixel *base = origin - (intptr_t)MY * stride - MX;
+    bool hit;
+    const int i = find_slot(g_low_src, 16, base, sparse_sum(base, (size_t)stride * (lines + 2 * MY)), hit);
+    if (!hit)
+        upload_low(i, origin, stride, lines);
+    return i;
+}
+
+int device_low_ref(pixel *const planes[4], int stride, int lines)
+{
+    const size_t bytes = (size_t)stride * (lines + 2 * MY);
+    uint32_t sum = 0;
+    for (int k = 0; k < 4; k++)
+        sum = sum * 31 + sparse_sum(planes[k] - (intptr_t)MY * stride - MX, bytes);
+    bool hit;
+    const int g = find_slot(g_low_ref, 12, planes[0] - (intptr_t)MY * stride - MX, sum, hit);
+    if (!hit)
+        for (int k = 0; k < 4; k++)
+            upload_low(16 + 4 * g + k, planes[k], stride, lines);
+    return 16 + 4 * g;
+}
 } // namespace
 #endif
 
@@ -193,20 +255,31 @@ int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const M
     int cost = real_me(self, ref, mvmin, mvmax, qmvp, numc, mvc, merange, out);
     std::lock_guard<std::mutex> g(g_mu);
 #ifdef WITH_HIP
-    if (g_hip_me && !ref->isLowres && numc <= X265_HIP_MAX_MVC)
+    if (g_hip_me && numc <= X265_HIP_MAX_MVC)
     {
+        const bool lowref = ref->isLowres;
         const int stride = (int)self->fencLumaStride, rows = (g_height + 63) / 64 * 64;
+        x265_hip_ctx *ctx = lowref ? g_ctx_low : g_ctx;
         x265_hip_me_job j;
         memset(&j, 0, sizeof(j));
-        j.fenc_plane = device_plane(self->fencplane, stride, rows);
-        j.ref_plane = device_plane(ref->fpelPlane, ref->lumaStride, rows);
-        if (g_slots[j.fenc_plane].base != self->fencplane - (intptr_t)MY * stride - MX) /* evicted by the second upload */
+        if (lowref)
+        {
+            const int lines = ((g_height / 2) + 7) / 8 * 8; /* lowres.cpp:33-48 */
+            j.fenc_plane = device_low_src(self->fencplane, stride, lines);
+            j.ref_plane = device_low_ref(ref->lowresPlane, ref->lumaStride, lines);
+        }
+        else
+        {
             j.fenc_plane = device_plane(self->fencplane, stride, rows);
+            j.ref_plane = device_plane(ref->fpelPlane, ref->lumaStride, rows);
+            if (g_slots[j.fenc_plane].base != self->fencplane - (intptr_t)MY * stride - MX) /* evicted by the second upload */
+                j.fenc_plane = device_plane(self->fencplane, stride, rows);
+        }
         j.pu_x = (int16_t)(self->blockOffset % stride);
         j.pu_y = (int16_t)(self->blockOffset / stride);
         j.pu_w = (uint8_t)self->blockwidth;
         j.pu_h = (uint8_t)self->blockheight;
-        j.method = (uint8_t)self->searchMethod;
+        j.method = (uint8_t)(self->searchMethod | (lowref ? X265_HIP_LOWRES_REF : 0));
         j.subme = (uint8_t)self->subpelRefine;
         j.mvmin_x = mvmin.x, j.mvmin_y = mvmin.y, j.mvmax_x = mvmax.x, j.mvmax_y = mvmax.y;
         j.qmvp_x = qmvp.x, j.qmvp_y = qmvp.y;
@@ -215,20 +288,22 @@ int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const M
         for (int i = 0; i < numc; i++)
             j.mvc[2 * i] = mvc[i].x, j.mvc[2 * i + 1] = mvc[i].y;
         j.qp = (uint8_t)qp_of(self->m_cost);
-        if (!g_qp_set[j.qp])
+        if (!g_qp_set[lowref][j.qp])
         {
-            x265_hip_costtab_set_qp(g_ctx, j.qp);
-            g_qp_set[j.qp] = true;
+            x265_hip_costtab_set_qp(ctx, j.qp);
+            g_qp_set[lowref][j.qp] = true;
         }
         x265_hip_me_result r;
-        if (x265_hip_me_batch(g_ctx, &j, 1, &r) != X265_HIP_OK)
+        if (x265_hip_me_batch(ctx, &j, 1, &r) != X265_HIP_OK)
         {
             fprintf(stderr, "me_batch: %s\n", x265_hip_last_error());
             abort();
         }
-        g_hip_calls++;
+        (lowref ? g_hip_low_calls : g_hip_calls)++;
+        if ((g_hip_low_calls + g_hip_calls) % 200000 == 0)
+            fprintf(stderr, "enc_capture: %ld + %ld calls answered so far\n", g_hip_calls, g_hip_low_calls);
         if (r.cost != cost || r.mvx != out.x || r.mvy != out.y)
-            g_hip_mismatch++;
+            (lowref ? g_hip_low_mismatch : g_hip_mismatch)++;
         /* the encoder goes on with the GPU's answer */
         cost = r.cost;
         out.x = r.mvx;
@@ -340,12 +415,12 @@ int main(int argc, char **argv)
     }
     if (getenv("X265_USE_HIP_ME"))
     {
-        if (x265_hip_ctx_create(0, &g_ctx) != X265_HIP_OK)
+        if (x265_hip_ctx_create(0, &g_ctx) != X265_HIP_OK || x265_hip_ctx_create(0, &g_ctx_low) != X265_HIP_OK)
         {
             fprintf(stderr, "x265_hip_ctx_create: %s\n", x265_hip_last_error());
             return 1;
         }
-        g_hip_me = true;
+        g_hip_me = g_hip_sparse = true;
         fprintf(stderr, "enc_capture: motionEstimate answered by x265_hip_me_batch\n");
     }
 #endif
@@ -411,8 +486,12 @@ int main(int argc, char **argv)
             (ts1.tv_sec - ts0.tv_sec) + (ts1.tv_nsec - ts0.tv_nsec) * 1e-9, (unsigned long long)hash);
 #ifdef WITH_HIP
     if (g_hip_me)
+    {
         fprintf(stderr, "enc_capture: %ld motionEstimate calls answered on the GPU, %ld differed from the reference's own answer\n",
                 g_hip_calls, g_hip_mismatch);
+        fprintf(stderr, "enc_capture: %ld lookahead (lowres) motionEstimate calls answered on the GPU, %ld differed\n",
+                g_hip_low_calls, g_hip_low_mismatch);
+    }
 #endif
     fprintf(stderr, "enc_capture: %zu bytes of bitstream, %ld full-resolution + %ld lowres motionEstimate calls recorded, %d planes\n",
             bytes_out, g_n_full, g_n_low, g_next_plane);

@@ -266,5 +266,7 @@ def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
         if mode == "X265_USE_HIP_ME":
             m = re.search(r"(\d+) motionEstimate calls answered on the GPU, (\d+) differed", r.stderr)
             assert m and int(m.group(1)) > 100 and int(m.group(2)) == 0, r.stderr
+            m = re.search(r"(\d+) lookahead \(lowres\) motionEstimate calls answered on the GPU, (\d+) differed", r.stderr)
+            assert m and int(m.group(1)) > 100 and int(m.group(2)) == 0, r.stderr
         hashes.append(re.search(r"%d pictures in .* bitstream hash ([0-9a-f]+)" % N, r.stderr).group(1))
     assert hashes[0] == hashes[1] == hashes[2]

@@ -30,10 +30,10 @@ else
 X265_USE_HIP=1 timeout -k 10 900 oracle/_ref/enc_hip /tmp/dropin.yuv "$W" "$H" "$N" /tmp 0 0 0 4 1 2>&1 | grep -v "Assembly not supported" | tee /tmp/dropin_hip.txt || exit 1
 fi
 echo "== motionEstimate answered by x265_hip_me_batch (C primitives elsewhere)"
-X265_USE_HIP_ME=1 timeout -k 10 900 oracle/_ref/enc_hip /tmp/dropin.yuv "$W" "$H" "$N" /tmp 0 0 0 4 1 2>&1 | grep -v "Assembly not supported" | tee /tmp/dropin_me.txt || exit 1
+X265_USE_HIP_ME=1 timeout -k 10 900 oracle/_ref/enc_hip /tmp/dropin.yuv "$W" "$H" "$N" /tmp 0 0 0 4 1 2>&1 | grep --line-buffered -v "Assembly not supported" | tee /tmp/dropin_me.txt || exit 1
 a=$(grep -o "hash [0-9a-f]*" /tmp/dropin_c.txt); b=$(grep -o "hash [0-9a-f]*" /tmp/dropin_hip.txt); c=$(grep -o "hash [0-9a-f]*" /tmp/dropin_me.txt)
 if [ -n "$a" ] && [ "$a" == "$b" ] && [ "$a" == "$c" ] && grep -q "HIP primitive table installed" /tmp/dropin_hip.txt &&
-   grep -q "answered on the GPU, 0 differed" /tmp/dropin_me.txt; then
+   [ "$(grep -c "answered on the GPU, 0 differed" /tmp/dropin_me.txt)" == 2 ]; then   # full-resolution and lookahead calls
   echo "DROP-IN OK: identical bitstreams ($a)"
 else
   echo "DROP-IN MISMATCH: '$a' vs '$b' vs '$c'"; exit 1
