@@ -263,15 +263,22 @@ int x265_hip_bidir_cost_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int 
  * (:400-433: luma_copy_pp / luma_hpp / luma_vpp / luma_hps + luma_vsp).  Bi-directional: both lists to 14-bit
  * intermediates (:436-473: luma_p2s / luma_hps / luma_vps / luma_hps + luma_vss; ipfilter.cpp:38-54, 117-160,
  * 204-239, 285-317) and luma_addAvg (common/pixel.cpp:819-839).  Weighted bi-prediction (xWeightedPredictionBi)
- * is not covered.  pu_w x pu_h samples are written at (pu_x, pu_y) of dst_plane, which must not be one of the
+ * is not covered.  Weighted uni-directional prediction is: with ref1_plane == X265_HIP_PRED_WEIGHTED the block
+ * goes the way motionCompensation takes whenever the PPS enables weighted prediction (TComPrediction.cpp:265-279):
+ * the 14-bit intermediate of ref0, then TComWeightPrediction::addWeightUni (TComWeightPrediction.cpp:433-458,
+ * 678-697) = weight_sp (common/pixel.cpp:492-508) with w0 = qmv1_x (wpScalingParam::inputWeight), offset = qmv1_y
+ * (inputOffset), shift = log2_denom + 6 and round = 1 << (shift - 1).
+ * pu_w x pu_h samples are written at (pu_x, pu_y) of dst_plane, which must not be one of the
  * request's references; requests of one batch whose destination blocks overlap race. */
+#define X265_HIP_PRED_WEIGHTED (-2)
 typedef struct x265_hip_pred_req
 {
     int32_t dst_plane;
     int32_t ref0_plane, ref1_plane; /* ref1_plane < 0: uni-directional prediction from ref0 */
     int16_t pu_x, pu_y;
     uint8_t pu_w, pu_h; /* one of the 25 partitions */
-    uint8_t pad[2];
+    uint8_t log2_denom; /* X265_HIP_PRED_WEIGHTED only: wpScalingParam::log2WeightDenom, 0..7 */
+    uint8_t pad;
     int16_t qmv0_x, qmv0_y, qmv1_x, qmv1_y;
 } x265_hip_pred_req;
 

@@ -30,6 +30,11 @@
 #include "lowres.h"
 #include "motion.h"
 #include "bitcost.h"
+#ifdef WITH_HIP
+#include "TLibCommon/TComPic.h"
+#include "TLibCommon/TComDataCU.h"
+#include "TLibCommon/TComPrediction.h"
+#endif
 #undef protected
 #undef private
 #include "x265.h"
@@ -45,6 +50,12 @@ int real_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const M
             const MV *mvc, int merange, MV &out) asm("__real_" ME_SYM);
 int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp, int numc,
             const MV *mvc, int merange, MV &out) asm("__wrap_" ME_SYM);
+
+#ifdef WITH_HIP
+#define MC_SYM "_ZN4x26514TComPrediction18motionCompensationEPNS_10TComDataCUEPNS_7TComYuvEiibb"
+void real_mc(TComPrediction *self, TComDataCU *cu, TComYuv *predYuv, int list, int partIdx, bool bLuma, bool bChroma) asm("__real_" MC_SYM);
+void wrap_mc(TComPrediction *self, TComDataCU *cu, TComYuv *predYuv, int list, int partIdx, bool bLuma, bool bChroma) asm("__wrap_" MC_SYM);
+#endif
 
 namespace {
 
@@ -249,6 +260,125 @@ int device_low_ref(pixel *const planes[4], int stride, int lines)
 } // namespace
 #endif
 
+#ifdef WITH_HIP
+/* X265_USE_HIP_MC=1: the luma block of every TComPrediction::motionCompensation call (TComPrediction.cpp:252-297) is
+ * predicted again by x265_hip_predict_batch, compared with what the reference wrote and then written over it, so
+ * the encoder goes on with the GPU's pixels.  Weighted bi-prediction (off at the medium preset) is left alone. */
+namespace {
+bool g_hip_mc = false;
+long g_mc_calls = 0, g_mc_weighted = 0, g_mc_bi = 0, g_mc_mismatch = 0, g_mc_skipped = 0;
+const int MC_DST = 60; /* plane id of the destination picture, outside device_plane's slots */
+std::vector<uint8_t> g_mc_buf;
+}
+
+void wrap_mc(TComPrediction *self, TComDataCU *cu, TComYuv *predYuv, int list, int partIdx, bool bLuma, bool bChroma)
+{
+    real_mc(self, cu, predYuv, list, partIdx, bLuma, bChroma);
+    if (!g_hip_mc || !bLuma)
+        return;
+    std::lock_guard<std::mutex> g(g_mu);
+    int w, h;
+    uint32_t partAddr;
+    cu->getPartIndexAndSize(partIdx, partAddr, w, h);
+    TComSlice *slice = cu->getSlice();
+    if (slice->isInterP())
+        list = REF_PIC_LIST_0;
+    int lists[2] = { -1, -1 };
+    bool weighted = false;
+    if (list != REF_PIC_LIST_X)
+    {
+        lists[0] = list;
+        weighted = slice->getPPS()->getUseWP();
+    }
+    else
+    {
+        if (slice->getPPS()->getWPBiPred())
+        {
+            g_mc_skipped++;
+            return;
+        }
+        const int r0 = cu->getCUMvField(REF_PIC_LIST_0)->getRefIdx(partAddr), r1 = cu->getCUMvField(REF_PIC_LIST_1)->getRefIdx(partAddr);
+        if (r0 >= 0 && r1 >= 0)
+        {
+            /* xCheckIdenticalMotion, TComPrediction.cpp:232-250 */
+            const bool same = slice->getRefPic(REF_PIC_LIST_0, r0)->getPOC() == slice->getRefPic(REF_PIC_LIST_1, r1)->getPOC() &&
+                cu->getCUMvField(REF_PIC_LIST_0)->getMv(partAddr) == cu->getCUMvField(REF_PIC_LIST_1)->getMv(partAddr);
+            lists[0] = 0;
+            if (!same)
+                lists[1] = 1;
+        }
+        else
+            lists[0] = r0 >= 0 ? 0 : 1;
+    }
+    const int rows = (g_height + 63) / 64 * 64;
+    x265_hip_pred_req q;
+    memset(&q, 0, sizeof(q));
+    q.dst_plane = MC_DST;
+    q.ref1_plane = -1;
+    q.pu_w = (uint8_t)w, q.pu_h = (uint8_t)h;
+    int stride = 0;
+    const pixel *base0 = nullptr;
+    for (int k = 0; k < 2 && lists[k] >= 0; k++)
+    {
+        const int refIdx = cu->getCUMvField(lists[k])->getRefIdx(partAddr);
+        MV mv = cu->getCUMvField(lists[k])->getMv(partAddr);
+        cu->clipMv(mv);
+        TComPicYuv *rp = slice->getRefPic(lists[k], refIdx)->getPicYuvRec();
+        stride = rp->getStride();
+        const intptr_t off = rp->getLumaAddr(cu->getAddr(), cu->getZorderIdxInCU() + partAddr) - rp->getLumaAddr();
+        q.pu_x = (int16_t)(off % stride), q.pu_y = (int16_t)(off / stride);
+        int id = device_plane(rp->getLumaAddr(), stride, rows);
+        if (k == 0)
+        {
+            q.ref0_plane = id, q.qmv0_x = mv.x, q.qmv0_y = mv.y;
+            base0 = rp->getLumaAddr() - (intptr_t)MY * stride - MX;
+            if (weighted)
+            {
+                wpScalingParam *wp;
+                slice->getWpScaling(lists[k], refIdx, wp);
+                q.ref1_plane = X265_HIP_PRED_WEIGHTED;
+                q.qmv1_x = (int16_t)wp[0].inputWeight, q.qmv1_y = (int16_t)wp[0].inputOffset;
+                q.log2_denom = (uint8_t)wp[0].log2WeightDenom;
+            }
+        }
+        else
+        {
+            if (g_slots[q.ref0_plane].base != base0) /* evicted by the second upload: cannot happen with 60 slots in use by a handful of pictures, but check */
+                abort();
+            q.ref1_plane = id, q.qmv1_x = mv.x, q.qmv1_y = mv.y;
+        }
+    }
+    const size_t plane_bytes = (size_t)stride * (rows + 2 * MY);
+    if (g_mc_buf.size() != plane_bytes)
+    {
+        g_mc_buf.assign(plane_bytes, 0);
+        if (x265_hip_plane_upload(g_ctx, MC_DST, g_mc_buf.data(), plane_bytes, stride, MY * stride + MX) != X265_HIP_OK)
+            abort();
+    }
+    const size_t upto = (size_t)MY * stride + MX + (size_t)(q.pu_y + h) * stride;
+    if (x265_hip_predict_batch(g_ctx, &q, 1) != X265_HIP_OK || x265_hip_plane_download(g_ctx, MC_DST, g_mc_buf.data(), upto) != X265_HIP_OK)
+    {
+        fprintf(stderr, "predict_batch: %s\n", x265_hip_last_error());
+        abort();
+    }
+    const uint8_t *gpu = g_mc_buf.data() + (size_t)MY * stride + MX + (size_t)q.pu_y * stride + q.pu_x;
+    pixel *dst = predYuv->getLumaAddr(partAddr);
+    const int dstride = predYuv->getStride();
+    bool diff = false;
+    for (int y = 0; y < h; y++)
+    {
+        diff |= memcmp(dst + y * dstride, gpu + (size_t)y * stride, w) != 0;
+        memcpy(dst + y * dstride, gpu + (size_t)y * stride, w);
+    }
+    g_mc_calls++;
+    g_mc_weighted += weighted;
+    g_mc_bi += lists[1] >= 0;
+    g_mc_mismatch += diff;
+    if (g_mc_calls % 200000 == 0)
+        fprintf(stderr, "enc_capture: %ld motionCompensation calls answered so far\n", g_mc_calls);
+}
+#endif
+
 int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp, int numc,
             const MV *mvc, int merange, MV &out)
 {
@@ -413,9 +543,19 @@ int main(int argc, char **argv)
         }
         fprintf(stderr, "enc_capture: HIP primitive table installed\n");
     }
+    if (getenv("X265_USE_HIP_MC"))
+    {
+        if (!g_ctx && x265_hip_ctx_create(0, &g_ctx) != X265_HIP_OK)
+        {
+            fprintf(stderr, "x265_hip_ctx_create: %s\n", x265_hip_last_error());
+            return 1;
+        }
+        g_hip_mc = g_hip_sparse = true;
+        fprintf(stderr, "enc_capture: motionCompensation (luma) answered by x265_hip_predict_batch\n");
+    }
     if (getenv("X265_USE_HIP_ME"))
     {
-        if (x265_hip_ctx_create(0, &g_ctx) != X265_HIP_OK || x265_hip_ctx_create(0, &g_ctx_low) != X265_HIP_OK)
+        if ((!g_ctx && x265_hip_ctx_create(0, &g_ctx) != X265_HIP_OK) || x265_hip_ctx_create(0, &g_ctx_low) != X265_HIP_OK)
         {
             fprintf(stderr, "x265_hip_ctx_create: %s\n", x265_hip_last_error());
             return 1;
@@ -485,6 +625,9 @@ int main(int argc, char **argv)
     fprintf(stderr, "enc_capture: %d pictures in %.2f s, bitstream hash %016llx\n", got,
             (ts1.tv_sec - ts0.tv_sec) + (ts1.tv_nsec - ts0.tv_nsec) * 1e-9, (unsigned long long)hash);
 #ifdef WITH_HIP
+    if (g_hip_mc)
+        fprintf(stderr, "enc_capture: %ld motionCompensation luma blocks predicted on the GPU (%ld weighted, %ld bi-directional), %ld differed from the reference's own pixels, %ld left alone\n",
+                g_mc_calls, g_mc_weighted, g_mc_bi, g_mc_mismatch, g_mc_skipped);
     if (g_hip_me)
     {
         fprintf(stderr, "enc_capture: %ld motionEstimate calls answered on the GPU, %ld differed from the reference's own answer\n",

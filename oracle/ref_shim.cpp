@@ -362,7 +362,14 @@ void x265r_predict_batch(const x265o_plane *planes, const x265o_pred_req *reqs, 
         int part = partitionFromSizes(r->pu_w, r->pu_h);
         pixel *dst = (pixel *)d.origin + r->pu_x + (intptr_t)r->pu_y * d.stride;
         pixel *pa = (pixel *)a.origin + r->pu_x + (intptr_t)r->pu_y * a.stride;
-        if (r->ref1_plane < 0)
+        if (r->ref1_plane == X265O_PRED_WEIGHTED)
+        {
+            /* motionCompensation with getUseWP (TComPrediction.cpp:265-279) + addWeightUni (TComWeightPrediction.cpp:433-458) */
+            int shift = r->log2_denom + (IF_INTERNAL_PREC - X265_DEPTH);
+            ref_predict_luma_short(part, r->pu_w, r->pu_h, pa, a.stride, r->qmv0_x, r->qmv0_y, s0);
+            g_c.weight_sp(s0, dst, 64, d.stride, r->pu_w, r->pu_h, r->qmv1_x, shift ? 1 << (shift - 1) : 0, shift, r->qmv1_y);
+        }
+        else if (r->ref1_plane < 0)
         {
             /* xPredInterLumaBlk with the destination's own stride */
             int xf = r->qmv0_x & 3, yf = r->qmv0_y & 3;

@@ -1250,7 +1250,21 @@ static void predict_luma_short(int part, int w, int h, const uint8_t *p, intptr_
     }
 }
 
-/* ref: TComPrediction::xPredInterUni / xPredInterBi for luma, TComPrediction.cpp:330-387 (no weighted prediction) */
+/* ref: weight_sp_c, common/pixel.cpp:492-508 (IF_INTERNAL_OFFS = 8192) */
+void x265o_weight_sp(const int16_t *src, uint8_t *dst, intptr_t sstride, intptr_t dstride, int width, int height, int w0,
+                     int round, int shift, int offset)
+{
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++)
+        {
+            int v = ((w0 * (src[y * sstride + x] + 8192) + round) >> shift) + offset;
+            dst[y * dstride + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+}
+
+/* ref: TComPrediction::xPredInterUni / xPredInterBi for luma, TComPrediction.cpp:330-387; weighted
+ * uni-directional prediction: motionCompensation's getUseWP branch, TComPrediction.cpp:265-279, with
+ * TComWeightPrediction::addWeightUni, TComWeightPrediction.cpp:433-458 (weighted bi-prediction is not covered) */
 void x265o_predict_batch(const x265o_plane *planes, const x265o_pred_req *reqs, int n)
 {
     for (int i = 0; i < n; i++)
@@ -1260,7 +1274,15 @@ void x265o_predict_batch(const x265o_plane *planes, const x265o_pred_req *reqs, 
         int part = x265o_partition_from_sizes(r->pu_w, r->pu_h);
         uint8_t *dst = (uint8_t *)d->origin + r->pu_x + (intptr_t)r->pu_y * d->stride;
         uint8_t tmp[64 * 64];
-        if (r->ref1_plane < 0)
+        if (r->ref1_plane == X265O_PRED_WEIGHTED)
+        {
+            int16_t s0[64 * 64];
+            int shift = r->log2_denom + 6; /* IF_INTERNAL_PREC - X265_DEPTH */
+            predict_luma_short(part, r->pu_w, r->pu_h, a->origin + r->pu_x + (intptr_t)r->pu_y * a->stride, a->stride, r->qmv0_x,
+                               r->qmv0_y, s0);
+            x265o_weight_sp(s0, dst, 64, d->stride, r->pu_w, r->pu_h, r->qmv1_x, 1 << (shift - 1), shift, r->qmv1_y);
+        }
+        else if (r->ref1_plane < 0)
         {
             predict_luma(part, r->pu_w, a->origin + r->pu_x + (intptr_t)r->pu_y * a->stride, a->stride, r->qmv0_x, r->qmv0_y, tmp);
             for (int y = 0; y < r->pu_h; y++)

@@ -136,7 +136,8 @@ def random_cost_reqs(rng, n, W, H, dtype, parts, metrics=(0, 1), planes=(1, (0, 
 
 def random_pred_reqs(rng, W, H, dtype, parts, dst_plane=5, refs=(0, 2), cell=64):
     """one prediction request per 64x64 cell of the picture (destination blocks of a batch must not overlap):
-    every partition, uni- and bi-directional, all fractions"""
+    every partition, uni- and bi-directional and weighted uni-directional (ref1_plane -2: w0 in qmv1_x, offset in
+    qmv1_y), all fractions"""
     cells = [(cx, cy) for cy in range(0, H - cell + 1, cell) for cx in range(0, W - cell + 1, cell)]
     reqs = np.zeros(len(cells), dtype)
     for r, (cx, cy) in zip(reqs, cells):
@@ -147,6 +148,14 @@ def random_pred_reqs(rng, W, H, dtype, parts, dst_plane=5, refs=(0, 2), cell=64)
         r["pu_w"], r["pu_h"] = w, h
         for k in ("qmv0_x", "qmv0_y", "qmv1_x", "qmv1_y"):
             r[k] = int(rng.integers(-90, 90)) if rng.integers(4) else 4 * int(rng.integers(-20, 20))
+        if r["ref1_plane"] < 0 and rng.integers(2):
+            # motionCompensation's getUseWP branch; unit weights (what an unweighted reference of such a slice
+            # gets), the weights x265's analysis produces (denominator 7, weight near 128) and the whole range
+            kind = int(rng.integers(3))
+            denom = 7 if kind == 1 else int(rng.integers(0, 8))
+            r["ref1_plane"], r["log2_denom"] = -2, denom
+            r["qmv1_x"] = 1 << denom if kind == 0 else int(rng.integers(96, 160)) if kind == 1 else int(rng.integers(-128, 256))
+            r["qmv1_y"] = 0 if kind == 0 else int(rng.integers(-20, 20)) if kind == 1 else int(rng.integers(-128, 128))
     return reqs
 
 

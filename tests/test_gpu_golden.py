@@ -234,12 +234,16 @@ def test_bad_arguments_are_rejected(gpu_ctx):
     pr["pu_y"] = 400
     with pytest.raises(lib.X265HipError):
         gpu_ctx.predict_batch(pr)  # destination block below the padded plane
+    pr["pu_y"], pr["ref1_plane"], pr["log2_denom"], pr["qmv1_x"] = 0, -2, 9, 64
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.predict_batch(pr)  # weighted prediction with a denominator beyond log2WeightDenom's 0..7
 
 
 def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
     """the drop-in itself: oracle/_ref/enc_hip is the reference encoder (its own sources) linked with
-    source/common/hip/hip-primitives.cpp and libx265_hip.so; with the table installed, and with every motionEstimate
-    call answered by x265_hip_me_batch instead, it must produce the bitstream its C primitives produce.  Present only where the reference was available to build it (`make -C oracle dropin`)."""
+    source/common/hip/hip-primitives.cpp and libx265_hip.so; with the table installed, with every motionEstimate
+    call answered by x265_hip_me_batch instead, and with every motionCompensation luma block answered by
+    x265_hip_predict_batch instead, it must produce the bitstream its C primitives produce.  Present only where the reference was available to build it (`make -C oracle dropin`)."""
     import re
     import subprocess
     from x265_amd import synth
@@ -255,7 +259,8 @@ def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
             f.write(seq.frame(i).astype(np.uint8).tobytes())
             f.write(bytes([128]) * (W * H // 2))
     hashes = []
-    for mode in (None, "X265_USE_HIP", "X265_USE_HIP_ME"):  # C primitives; HIP table; motionEstimate via x265_hip_me_batch
+    # C primitives; HIP table; motionEstimate via x265_hip_me_batch; motionCompensation (luma) via x265_hip_predict_batch
+    for mode in (None, "X265_USE_HIP", "X265_USE_HIP_ME", "X265_USE_HIP_MC"):
         env = dict(os.environ)
         if mode:
             env[mode] = "1"
@@ -268,5 +273,8 @@ def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
             assert m and int(m.group(1)) > 100 and int(m.group(2)) == 0, r.stderr
             m = re.search(r"(\d+) lookahead \(lowres\) motionEstimate calls answered on the GPU, (\d+) differed", r.stderr)
             assert m and int(m.group(1)) > 100 and int(m.group(2)) == 0, r.stderr
+        if mode == "X265_USE_HIP_MC":
+            m = re.search(r"(\d+) motionCompensation luma blocks predicted on the GPU \((\d+) weighted, (\d+) bi-directional\), (\d+) differed", r.stderr)
+            assert m and int(m.group(1)) > 100 and int(m.group(2)) > 0 and int(m.group(4)) == 0, r.stderr
         hashes.append(re.search(r"%d pictures in .* bitstream hash ([0-9a-f]+)" % N, r.stderr).group(1))
-    assert hashes[0] == hashes[1] == hashes[2]
+    assert hashes[0] == hashes[1] == hashes[2] == hashes[3]

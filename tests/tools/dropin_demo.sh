@@ -1,8 +1,10 @@
 #!/bin/bash
 # Drop-in demonstration: the reference encoder (oracle/_ref/enc_hip = the reference's own sources
-# + source/common/hip/hip-primitives.cpp + libx265_hip.so) encodes the same clip twice, once with its C primitives
-# once with the HIP primitive table installed, and once with every full-resolution MotionEstimate::motionEstimate call
-# answered by x265_hip_me_batch; the three bitstreams must be identical.
+# + source/common/hip/hip-primitives.cpp + libx265_hip.so) encodes the same clip four times: with its C primitives,
+# with the HIP primitive table installed, with every MotionEstimate::motionEstimate call (the lookahead's included)
+# answered by x265_hip_me_batch, and with the luma block of every TComPrediction::motionCompensation call answered
+# by x265_hip_predict_batch; the four bitstreams must be identical and no answer may differ from the reference's.
+# DROPIN_SKIP_TABLE=1 (large clips) skips the per-call table and motionCompensation runs.
 #   tests/tools/dropin_demo.sh [width height frames]
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
@@ -31,8 +33,16 @@ X265_USE_HIP=1 timeout -k 10 900 oracle/_ref/enc_hip /tmp/dropin.yuv "$W" "$H" "
 fi
 echo "== motionEstimate answered by x265_hip_me_batch (C primitives elsewhere)"
 X265_USE_HIP_ME=1 timeout -k 10 900 oracle/_ref/enc_hip /tmp/dropin.yuv "$W" "$H" "$N" /tmp 0 0 0 4 1 2>&1 | grep --line-buffered -v "Assembly not supported" | tee /tmp/dropin_me.txt || exit 1
-a=$(grep -o "hash [0-9a-f]*" /tmp/dropin_c.txt); b=$(grep -o "hash [0-9a-f]*" /tmp/dropin_hip.txt); c=$(grep -o "hash [0-9a-f]*" /tmp/dropin_me.txt)
-if [ -n "$a" ] && [ "$a" == "$b" ] && [ "$a" == "$c" ] && grep -q "HIP primitive table installed" /tmp/dropin_hip.txt &&
+echo "== motionCompensation (luma) answered by x265_hip_predict_batch (C primitives elsewhere)"
+if [ -n "$DROPIN_SKIP_TABLE" ]; then   # one plane download per call: small clips only
+  echo "(skipped)"; d_skip=1
+else
+X265_USE_HIP_MC=1 timeout -k 10 900 oracle/_ref/enc_hip /tmp/dropin.yuv "$W" "$H" "$N" /tmp 0 0 0 4 1 2>&1 | grep --line-buffered -v "Assembly not supported" | tee /tmp/dropin_mc.txt || exit 1
+d=$(grep -o "hash [0-9a-f]*" /tmp/dropin_mc.txt)
+grep -q "predicted on the GPU.* 0 differed" /tmp/dropin_mc.txt || { echo "DROP-IN MISMATCH in motionCompensation"; exit 1; }
+fi
+a=$(grep -o "hash [0-9a-f]*" /tmp/dropin_c.txt); [ -n "$d_skip" ] && d=$a; b=$(grep -o "hash [0-9a-f]*" /tmp/dropin_hip.txt); c=$(grep -o "hash [0-9a-f]*" /tmp/dropin_me.txt)
+if [ -n "$a" ] && [ "$a" == "$b" ] && [ "$a" == "$c" ] && [ "$a" == "$d" ] && grep -q "HIP primitive table installed" /tmp/dropin_hip.txt &&
    [ "$(grep -c "answered on the GPU, 0 differed" /tmp/dropin_me.txt)" == 2 ]; then   # full-resolution and lookahead calls
   echo "DROP-IN OK: identical bitstreams ($a)"
 else

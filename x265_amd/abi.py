@@ -48,7 +48,7 @@ assert BIDIR_REQ.itemsize == 28
 PRED_REQ = np.dtype([
     ("dst_plane", "<i4"), ("ref0_plane", "<i4"), ("ref1_plane", "<i4"),
     ("pu_x", "<i2"), ("pu_y", "<i2"),
-    ("pu_w", "u1"), ("pu_h", "u1"), ("pad", "u1", (2,)),
+    ("pu_w", "u1"), ("pu_h", "u1"), ("log2_denom", "u1"), ("pad", "u1"),
     ("qmv0_x", "<i2"), ("qmv0_y", "<i2"), ("qmv1_x", "<i2"), ("qmv1_y", "<i2"),
 ])
 assert PRED_REQ.itemsize == 28

@@ -741,6 +741,10 @@ int x265_hip_predict_batch(x265_hip_ctx *c, const x265_hip_pred_req *reqs, int n
             return r;
         if (q.dst_plane == q.ref0_plane || q.dst_plane == q.ref1_plane)
             return fail(X265_HIP_EINVAL, "pred_req[%d]: the destination plane is one of the references", i);
+        if (q.ref1_plane == X265_HIP_PRED_WEIGHTED &&
+            (q.log2_denom > 7 || q.qmv1_x < -128 || q.qmv1_x > 255 || q.qmv1_y < -128 || q.qmv1_y > 127))
+            return fail(X265_HIP_EINVAL, "pred_req[%d]: weight %d / offset %d / log2 denominator %d out of range", i, q.qmv1_x,
+                        q.qmv1_y, q.log2_denom);
         if ((r = check_inside(c, q.dst_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, "pred_req", i)) ||
             (r = check_displaced(c, q.ref0_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv0_x, q.qmv0_y, "pred_req", i)) ||
             (q.ref1_plane >= 0 &&

@@ -1182,7 +1182,7 @@ struct CostLds
     int cost[COST_BATCH];
     // per request, resolved once by lane k: block origins, strides,
     // ntx | xf << 8 | yf << 10 | metric << 12 | (8-row strips) << 14 | second fraction << 15 | sa8d kind << 19 |
-    // units per row << 21 | INFO_LOWRES | INFO_MCAVG | INFO_PRED_BI
+    // units per row << 21 | INFO_LOWRES | INFO_MCAVG | INFO_PRED_BI | INFO_PRED_W
     const uint8_t *fenc[COST_BATCH];
     const uint8_t *ref[COST_BATCH];
     int fstride[COST_BATCH], rstride[COST_BATCH], info[COST_BATCH];
@@ -1216,6 +1216,25 @@ __device__ __forceinline__ int req_qy0(const x265_hip_pred_req &r) { return r.qm
 __device__ __forceinline__ int req_ref1(const x265_hip_pred_req &r) { return r.ref1_plane; }
 __device__ __forceinline__ int req_qx1(const x265_hip_pred_req &r) { return r.qmv1_x; }
 __device__ __forceinline__ int req_qy1(const x265_hip_pred_req &r) { return r.qmv1_y; }
+// weighted uni-directional prediction: w0 | offset << 16 | log2 denominator << 24
+__device__ __forceinline__ int req_weight(const x265_hip_pred_req &r)
+{
+    return (r.qmv1_x & 0xffff) | ((r.qmv1_y & 0xff) << 16) | ((r.log2_denom & 7) << 24);
+}
+__device__ __forceinline__ int req_weight(const x265_hip_cost_req &) { return 0; }
+__device__ __forceinline__ int req_weight(const x265_hip_bidir_req &) { return 0; }
+
+// weight_sp on a packed pair of 14-bit intermediates (reference common/pixel.cpp:492-508): the pair of pixels
+__device__ __forceinline__ uint32_t weight_pair(uint32_t p, int wpack)
+{
+    const int w0 = (int16_t)(wpack & 0xffff), offset = (int8_t)((wpack >> 16) & 0xff), shift = ((wpack >> 24) & 7) + 6;
+    const int round = 1 << (shift - 1);
+    int lo = ((((int16_t)(p & 0xffff) + 8192) * w0 + round) >> shift) + offset;
+    int hi = (((((int)p >> 16) + 8192) * w0 + round) >> shift) + offset;
+    lo = min(max(lo, 0), 255);
+    hi = min(max(hi, 0), 255);
+    return (uint32_t)lo | ((uint32_t)hi << 16);
+}
 __device__ __forceinline__ int req_ref0(const x265_hip_bidir_req &r) { return r.ref0_plane; }
 __device__ __forceinline__ int req_qx0(const x265_hip_bidir_req &r) { return r.qmv0_x; }
 __device__ __forceinline__ int req_qy0(const x265_hip_bidir_req &r) { return r.qmv0_y; }
@@ -1230,13 +1249,14 @@ __device__ __forceinline__ int req_qy1(const x265_hip_bidir_req &r) { return r.q
 // an even slot so that the two halves of an 8x8 block sit in lanes 2j and 2j + 1 (sa8d_strip).
 // MODE_PRED: requests are x265_hip_pred_req; nothing is compared, the predicted strips are stored into the
 // destination plane (uni-directional: the pixels of the other modes; bi-directional: luma_addAvg of the two
-// lists' 14-bit intermediates, info bit 19).
+// lists' 14-bit intermediates, INFO_PRED_BI; weighted uni-directional: weight_sp of the 14-bit intermediate,
+// INFO_PRED_W, parameters in rstride1[]).
 // The modes are bits: bidir_cost_kernel is MODE_BIDIR | MODE_DIST (all four comparisons).  With INFO_MCAVG a
 // bidirectional request combines its two predictions the way motion compensation does (14-bit intermediates +
 // luma_addAvg, xPredInterBi) instead of pixelavg_pp: what xMergeEstimation measures on a bi-directional merge
 // candidate (TEncSearch.cpp:2209-2210) and mode decision on a bi-predicted block.
 enum { MODE_COST = 0, MODE_BIDIR = 1, MODE_DIST = 2, MODE_PRED = 4 };
-enum { INFO_LOWRES = 1 << 24, INFO_MCAVG = 1 << 25, INFO_PRED_BI = 1 << 26 };
+enum { INFO_LOWRES = 1 << 24, INFO_MCAVG = 1 << 25, INFO_PRED_BI = 1 << 26, INFO_PRED_W = 1 << 27 };
 #define DIST_UNITS 16 // 64x64: sixteen 16x16 blocks; 32x24 / 24x32: twelve 8x8 blocks
 
 template <int MODE, typename Req>
@@ -1304,6 +1324,11 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                     nunits = nux * (cur.pu_h >> (2 + kind));
                     info |= (kind << 19) | (nux << 21);
                 }
+            }
+            if (PRED && req_ref1(cur) == X265_HIP_PRED_WEIGHTED)
+            {
+                info |= INFO_PRED_W;
+                L.rstride1[lane] = req_weight(cur);
             }
             if (BIDIR || (PRED && req_ref1(cur) >= 0))
             {
@@ -1410,6 +1435,17 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                         {
                             pix[y][0] = add_avg_pair(pix[y][0], pix1[y][0]);
                             pix[y][1] = add_avg_pair(pix[y][1], pix1[y][1]);
+                        }
+                    }
+                    else if (info & INFO_PRED_W)
+                    {
+                        const int wpack = L.rstride1[k];
+                        ref_strip<NT, true>(r0, rstride, xf, yf, pix);
+#pragma unroll
+                        for (int y = 0; y < R; y++)
+                        {
+                            pix[y][0] = weight_pair(pix[y][0], wpack);
+                            pix[y][1] = weight_pair(pix[y][1], wpack);
                         }
                     }
                     else
