@@ -55,6 +55,12 @@ int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const M
 #define MC_SYM "_ZN4x26514TComPrediction18motionCompensationEPNS_10TComDataCUEPNS_7TComYuvEiibb"
 void real_mc(TComPrediction *self, TComDataCU *cu, TComYuv *predYuv, int list, int partIdx, bool bLuma, bool bChroma) asm("__real_" MC_SYM);
 void wrap_mc(TComPrediction *self, TComDataCU *cu, TComYuv *predYuv, int list, int partIdx, bool bLuma, bool bChroma) asm("__wrap_" MC_SYM);
+#define LI_SYM "_ZN4x2656Lowres4initEPNS_10TComPicYuvEii"
+void real_li(Lowres *self, TComPicYuv *orig, int poc, int type) asm("__real_" LI_SYM);
+void wrap_li(Lowres *self, TComPicYuv *orig, int poc, int type) asm("__wrap_" LI_SYM);
+#define AW_SYM "_ZN4x26515MotionReference11applyWeightEii"
+void real_aw(MotionReference *self, int rows, int numRows) asm("__real_" AW_SYM);
+void wrap_aw(MotionReference *self, int rows, int numRows) asm("__wrap_" AW_SYM);
 #endif
 
 namespace {
@@ -261,6 +267,94 @@ int device_low_ref(pixel *const planes[4], int stride, int lines)
 #endif
 
 #ifdef WITH_HIP
+/* X265_USE_HIP_PLANES=1: the planes the encoder produces for the search are produced again on the device, compared
+ * with the reference's and written over them: the four lookahead planes of every Lowres::init (lowres.cpp:129-175)
+ * by x265_hip_lowres_init, and every weighted reference plane MotionReference::applyWeight completes
+ * (reference.cpp:78-121) by x265_hip_plane_weight. */
+namespace {
+bool g_hip_planes = false;
+x265_hip_ctx *g_ctx_planes = nullptr;
+long g_li_planes = 0, g_li_mismatch = 0, g_aw_planes = 0, g_aw_mismatch = 0, g_aw_partial = 0;
+std::vector<uint8_t> g_pl_buf;
+
+/* rows -MY .. h + MY - 1, columns -MX .. w + MX - 1 of a padded buffer: what the reference writes */
+bool take_region(uint8_t *host_base, const uint8_t *gpu_base, int stride, int w, int h)
+{
+    bool diff = false;
+    for (int y = 0; y < h + 2 * MY; y++)
+    {
+        diff |= memcmp(host_base + (size_t)y * stride, gpu_base + (size_t)y * stride, w + 2 * MX) != 0;
+        memcpy(host_base + (size_t)y * stride, gpu_base + (size_t)y * stride, w + 2 * MX);
+    }
+    return diff;
+}
+
+void planes_fail(const char *what)
+{
+    fprintf(stderr, "%s: %s\n", what, x265_hip_last_error());
+    abort();
+}
+}
+
+void wrap_li(Lowres *self, TComPicYuv *orig, int poc, int type)
+{
+    real_li(self, orig, poc, type);
+    if (!g_hip_planes)
+        return;
+    std::lock_guard<std::mutex> g(g_mu);
+    const int stride = orig->getStride(), rows = (g_height + 63) / 64 * 64;
+    if (orig->getLumaMarginX() != MX || orig->getLumaMarginY() != MY)
+        abort();
+    x265_hip_lowres_geometry geo;
+    if (x265_hip_plane_upload(g_ctx_planes, 0, orig->getLumaAddr() - (intptr_t)MY * stride - MX, (size_t)stride * (rows + 2 * MY), stride,
+                              MY * stride + MX) != X265_HIP_OK ||
+        x265_hip_lowres_geometry_of(g_width, g_height, MX, MY, &geo) != X265_HIP_OK ||
+        x265_hip_lowres_init(g_ctx_planes, 0, g_width, g_height, MX, MY, 1) != X265_HIP_OK)
+        planes_fail("lowres_init");
+    if (geo.stride != self->lumaStride || geo.width != self->width || geo.lines != self->lines)
+    {
+        fprintf(stderr, "lowres geometry differs: %d %d %d vs %d %d %d\n", geo.stride, geo.width, geo.lines, (int)self->lumaStride,
+                self->width, self->lines);
+        abort();
+    }
+    g_pl_buf.resize(geo.bytes);
+    for (int k = 0; k < 4; k++)
+    {
+        if (x265_hip_plane_download(g_ctx_planes, 1 + k, g_pl_buf.data(), geo.bytes) != X265_HIP_OK)
+            planes_fail("plane_download");
+        g_li_planes++;
+        g_li_mismatch += take_region(self->buffer[k], g_pl_buf.data(), geo.stride, geo.width, geo.lines);
+    }
+}
+
+void wrap_aw(MotionReference *self, int rows, int numRows)
+{
+    const int before = self->m_numWeightedRows;
+    real_aw(self, rows, numRows);
+    if (!g_hip_planes || !self->isWeighted || self->m_numWeightedRows != numRows || before == numRows)
+        return; /* only the call that completes the plane */
+    std::lock_guard<std::mutex> g(g_mu);
+    if (before < numRows - 1)
+    {
+        /* reference.cpp:88-90 takes the height of the last CU row alone whenever rows == numRows: a call that
+         * completes more than one row at once (pictures of two CU rows or fewer) leaves the rest of the reference's
+         * buffer as allocated, so there is nothing to compare with */
+        g_aw_partial++;
+        return;
+    }
+    TComPicYuv *pic = self->m_reconPic;
+    const int stride = pic->getStride(), prow = (g_height + 63) / 64 * 64;
+    const size_t bytes = (size_t)stride * (prow + 2 * MY);
+    if (x265_hip_plane_upload(g_ctx_planes, 8, pic->getLumaAddr() - (intptr_t)MY * stride - MX, bytes, stride, MY * stride + MX) != X265_HIP_OK ||
+        x265_hip_plane_weight(g_ctx_planes, 8, 9, g_width, g_height, MX, MY, self->weight, self->offset, self->shift) != X265_HIP_OK)
+        planes_fail("plane_weight");
+    g_pl_buf.resize(bytes);
+    if (x265_hip_plane_download(g_ctx_planes, 9, g_pl_buf.data(), bytes) != X265_HIP_OK)
+        planes_fail("plane_download");
+    g_aw_planes++;
+    g_aw_mismatch += take_region(self->m_weightBuffer, g_pl_buf.data(), stride, g_width, g_height);
+}
+
 /* X265_USE_HIP_MC=1: the luma block of every TComPrediction::motionCompensation call (TComPrediction.cpp:252-297) is
  * predicted again by x265_hip_predict_batch, compared with what the reference wrote and then written over it, so
  * the encoder goes on with the GPU's pixels.  Weighted bi-prediction (off at the medium preset) is left alone. */
@@ -543,6 +637,16 @@ int main(int argc, char **argv)
         }
         fprintf(stderr, "enc_capture: HIP primitive table installed\n");
     }
+    if (getenv("X265_USE_HIP_PLANES"))
+    {
+        if (x265_hip_ctx_create(0, &g_ctx_planes) != X265_HIP_OK)
+        {
+            fprintf(stderr, "x265_hip_ctx_create: %s\n", x265_hip_last_error());
+            return 1;
+        }
+        g_hip_planes = true;
+        fprintf(stderr, "enc_capture: lookahead planes and weighted reference planes made by x265_hip_lowres_init / x265_hip_plane_weight\n");
+    }
     if (getenv("X265_USE_HIP_MC"))
     {
         if (!g_ctx && x265_hip_ctx_create(0, &g_ctx) != X265_HIP_OK)
@@ -625,6 +729,9 @@ int main(int argc, char **argv)
     fprintf(stderr, "enc_capture: %d pictures in %.2f s, bitstream hash %016llx\n", got,
             (ts1.tv_sec - ts0.tv_sec) + (ts1.tv_nsec - ts0.tv_nsec) * 1e-9, (unsigned long long)hash);
 #ifdef WITH_HIP
+    if (g_hip_planes)
+        fprintf(stderr, "enc_capture: %ld lookahead planes made on the GPU, %ld differed; %ld weighted reference planes made on the GPU, %ld differed (%ld the reference left incomplete)\n",
+                g_li_planes, g_li_mismatch, g_aw_planes, g_aw_mismatch, g_aw_partial);
     if (g_hip_mc)
         fprintf(stderr, "enc_capture: %ld motionCompensation luma blocks predicted on the GPU (%ld weighted, %ld bi-directional), %ld differed from the reference's own pixels, %ld left alone\n",
                 g_mc_calls, g_mc_weighted, g_mc_bi, g_mc_mismatch, g_mc_skipped);

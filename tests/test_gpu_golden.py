@@ -251,16 +251,17 @@ def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
     exe = os.path.join(root, "oracle", "_ref", "enc_hip")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/enc_hip not built")
-    W, H, N = 208, 128, 3
+    W, H, N = 208, 256, 6  # four CTU rows: see wrap_aw in oracle/enc_capture.cpp
     seq = synth.Sequence(W, H, seed=7, n_patches=2)
     clip = tmp_path / "in.yuv"
     with open(clip, "wb") as f:
         for i in range(N):
-            f.write(seq.frame(i).astype(np.uint8).tobytes())
+            f.write(np.clip(seq.frame(i) * (1.0 - 0.12 * i) + 0.5, 0, 255).astype(np.uint8).tobytes())  # a fade: weighted references
             f.write(bytes([128]) * (W * H // 2))
     hashes = []
     # C primitives; HIP table; motionEstimate via x265_hip_me_batch; motionCompensation (luma) via x265_hip_predict_batch
-    for mode in (None, "X265_USE_HIP", "X265_USE_HIP_ME", "X265_USE_HIP_MC"):
+    # lookahead / weighted planes via x265_hip_lowres_init / x265_hip_plane_weight
+    for mode in (None, "X265_USE_HIP", "X265_USE_HIP_ME", "X265_USE_HIP_MC", "X265_USE_HIP_PLANES"):
         env = dict(os.environ)
         if mode:
             env[mode] = "1"
@@ -273,8 +274,11 @@ def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
             assert m and int(m.group(1)) > 100 and int(m.group(2)) == 0, r.stderr
             m = re.search(r"(\d+) lookahead \(lowres\) motionEstimate calls answered on the GPU, (\d+) differed", r.stderr)
             assert m and int(m.group(1)) > 100 and int(m.group(2)) == 0, r.stderr
+        if mode == "X265_USE_HIP_PLANES":
+            m = re.search(r"(\d+) lookahead planes made on the GPU, (\d+) differed; (\d+) weighted reference planes made on the GPU, (\d+) differed", r.stderr)
+            assert m and int(m.group(1)) == 4 * N and int(m.group(2)) == 0 and int(m.group(3)) > 0 and int(m.group(4)) == 0, r.stderr
         if mode == "X265_USE_HIP_MC":
             m = re.search(r"(\d+) motionCompensation luma blocks predicted on the GPU \((\d+) weighted, (\d+) bi-directional\), (\d+) differed", r.stderr)
             assert m and int(m.group(1)) > 100 and int(m.group(2)) > 0 and int(m.group(4)) == 0, r.stderr
         hashes.append(re.search(r"%d pictures in .* bitstream hash ([0-9a-f]+)" % N, r.stderr).group(1))
-    assert hashes[0] == hashes[1] == hashes[2] == hashes[3]
+    assert len(set(hashes)) == 1, hashes
