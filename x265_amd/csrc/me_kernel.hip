@@ -1263,6 +1263,23 @@ template <int MODE, typename Req>
 __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *reqs, int n, int32_t *out, uint32_t *counters, int parity, int rb)
 {
     constexpr bool BIDIR = (MODE & MODE_BIDIR) != 0, DIST = (MODE & MODE_DIST) != 0, PRED = (MODE & MODE_PRED) != 0;
+    // A batch of 32 64x64 blocks is 64 passes of the item loop, and a list of such blocks has fewer batches than the
+    // chip has waves: the work per batch is bounded instead.  Every wave looks at the same 64 requests spread over
+    // the list and halves rb until a batch holds about 512 items (eight passes) by their mean.  The positions are
+    // multiples of the golden ratio (mod 1): equally spaced ones alias with the period of a list built picture by
+    // picture (measured: sixteen of them fell on 64x64 blocks of a mixed list).  The loads are issued first, so
+    // that they fly while the plane directory is copied.
+    int sample_items = 0;
+    if (!PRED && rb > 1)
+    {
+        const int sl = threadIdx.x & 63;
+        const int si = n >= 64 ? (int)(((unsigned long long)((unsigned)sl * 0x9E3779B1u) * (unsigned long long)n) >> 32) : sl;
+        if (si < n)
+        {
+            const int w = reqs[si].pu_w, h = reqs[si].pu_h;
+            sample_items = (w >> 2) * (h >> (2 + ((h & 7) == 0)));
+        }
+    }
     __shared__ CostLds lds[4];
     __shared__ int count_lds[4][COST_BATCH];                              // items of a request (pre[] holds the padded count)
     __shared__ int units_lds[DIST ? 4 : 1][COST_BATCH * DIST_UNITS];
@@ -1279,6 +1296,15 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
     int *const units = units_lds[DIST ? threadIdx.x >> 6 : 0];
     auto &low = low_lds[BIDIR ? threadIdx.x >> 6 : 0];
     const int lane = threadIdx.x & 63;
+    if (!PRED && rb > 1)
+    {
+        for (int o = 32; o; o >>= 1)
+            sample_items += __shfl_xor(sample_items, o);
+        const int limit = 512 * (n < 64 ? n : 64);
+        while (rb > 1 && sample_items * rb > limit)
+            rb >>= 1;
+        rb = uniform(rb);
+    }
     const int nbatch = (n + rb - 1) / rb;
     const int parts = min((int)gridDim.x, COST_PARTS), part = blockIdx.x % parts;
     const int nwaves = 4 * (((int)gridDim.x - part + parts - 1) / parts); // waves serving this part
@@ -1619,6 +1645,13 @@ static int batch_requests(int n)
     return rb;
 }
 
+// workgroups for a list: the kernel may lower rb to 4 for lists of large blocks (cost_body), so enough waves for that
+static int cost_blocks(int n, int rb)
+{
+    const int rmin = rb < 4 ? rb : 4;
+    return ((n + rmin - 1) / rmin + 3) / 4;
+}
+
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st)
 {
     if (n > 0)
@@ -1629,7 +1662,7 @@ void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs,
 {
     if (n > 0)
     {
-        const int rb = batch_requests(n), blocks = ((n + rb - 1) / rb + 3) / 4;
+        const int rb = batch_requests(n), blocks = cost_blocks(n, rb);
         hipLaunchKernelGGL(bidir_cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity, rb);
     }
 }
@@ -1647,7 +1680,7 @@ void launch_dist(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
 {
     if (n > 0)
     {
-        const int rb = batch_requests(n), blocks = ((n + rb - 1) / rb + 3) / 4;
+        const int rb = batch_requests(n), blocks = cost_blocks(n, rb);
         hipLaunchKernelGGL(dist_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity, rb);
     }
 }
@@ -1656,7 +1689,7 @@ void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
 {
     if (n > 0)
     {
-        const int rb = batch_requests(n), blocks = ((n + rb - 1) / rb + 3) / 4;
+        const int rb = batch_requests(n), blocks = cost_blocks(n, rb);
         hipLaunchKernelGGL(cost_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity, rb);
     }
 }
