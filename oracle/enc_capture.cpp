@@ -12,6 +12,15 @@
  *   enc_capture in.yuv width height frames out_dir [max_full_calls [max_lowres_calls [first_full_call
  *               [pool_threads [frame_threads]]]]]
  * With both call limits 0 nothing is recorded and the program is the reference encoder timed end to end.
+ *
+ * Built with -DWITH_HIP and linked to libx265_hip.so (target `dropin`, binary enc_hip) the same program is the
+ * drop-in demonstration (tests/tools/dropin_demo.sh); the environment selects what the GPU answers, and in each
+ * mode the answers are compared with the reference's own before the encoder goes on with them:
+ *   X265_USE_HIP=1         the primitive table is installed through source/common/hip/hip-primitives.cpp
+ *   X265_USE_HIP_ME=1      every MotionEstimate::motionEstimate call, the lookahead's included -> x265_hip_me_batch
+ *   X265_USE_HIP_MC=1      the luma block of every TComPrediction::motionCompensation call -> x265_hip_predict_batch
+ *   X265_USE_HIP_PLANES=1  Lowres::init -> x265_hip_lowres_init, MotionReference::applyWeight -> x265_hip_plane_weight
+ * All four member functions are intercepted with ld --wrap; the bitstream hash printed at the end must not change.
  */
 #include <map>
 #include <mutex>
