@@ -44,7 +44,9 @@ BIDIR_REQ = np.dtype([
 ])
 assert BIDIR_REQ.itemsize == 28
 
-# x265_hip_pred_req: motion-compensated luma prediction into dst_plane (uni-directional when ref1_plane < 0)
+# x265_hip_pred_req: motion-compensated luma prediction into dst_plane (uni-directional when ref1_plane < 0;
+# ref1_plane == PRED_WEIGHTED: weighted uni-directional, w0 in qmv1_x, offset in qmv1_y, log2_denom)
+PRED_WEIGHTED = -2
 PRED_REQ = np.dtype([
     ("dst_plane", "<i4"), ("ref0_plane", "<i4"), ("ref1_plane", "<i4"),
     ("pu_x", "<i2"), ("pu_y", "<i2"),
