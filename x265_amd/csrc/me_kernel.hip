@@ -1298,10 +1298,18 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
     const int lane = threadIdx.x & 63;
     if (!PRED && rb > 1)
     {
+        const int cnt = n < 64 ? n : 64;
+        // one block size throughout (by the sample): batches can be cut to exactly one pass; otherwise a batch
+        // of a pass and a half leaves half of the second pass idle, so four passes are kept
+        const bool one_size = __ballot(lane < cnt && sample_items != __shfl(sample_items, 0)) == 0;
         for (int o = 32; o; o >>= 1)
             sample_items += __shfl_xor(sample_items, o);
-        const int limit = 512 * (n < 64 ? n : 64);
-        while (rb > 1 && sample_items * rb > limit)
+        while (rb > 1 && sample_items * rb > 512 * cnt)
+            rb >>= 1;
+        // and while the list has fewer than eight batches per wave slot of the chip, as long as a batch still fills
+        // its passes of the item loop: 95 k 64x64 blocks in batches of 4 are 4.6 batches per wave slot, five rounds
+        // of which the last is 60 % full
+        while (rb > 1 && (n + rb - 1) / rb < 8 * 5120 && sample_items * (rb >> 1) >= (one_size ? 64 : 256) * cnt)
             rb >>= 1;
         rb = uniform(rb);
     }
@@ -1645,11 +1653,11 @@ static int batch_requests(int n)
     return rb;
 }
 
-// workgroups for a list: the kernel may lower rb to 4 for lists of large blocks (cost_body), so enough waves for that
-static int cost_blocks(int n, int rb)
+// workgroups for a list: the kernel may lower rb down to 1 for lists of large blocks (cost_body), so enough waves
+// for that (the launch caps the number at COST_MAX_BLOCKS)
+static int cost_blocks(int n, int)
 {
-    const int rmin = rb < 4 ? rb : 4;
-    return ((n + rmin - 1) / rmin + 3) / 4;
+    return (n + 3) / 4;
 }
 
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st)
