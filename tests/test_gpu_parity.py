@@ -52,6 +52,27 @@ def test_cost_batch_ragged(gpu_ctx, oracle, small_seq, n, small_only):
     assert len(bad) == 0, f"request {bad[0]}: {reqs[bad[0]]} got {got[bad[0]]} want {want[bad[0]]}"
 
 
+@pytest.mark.parametrize("sizes,n", [(((64, 64),), 4500), (((32, 32),), 9000), (((16, 16),), 9000), (((64, 64), (8, 8)), 9000)])
+def test_cost_batch_lists_that_resize_their_batches(gpu_ctx, oracle, small_seq, sizes, n):
+    """lists long enough for batches of several requests and made of large blocks: the kernel lowers the batch
+    size from its sample of the list (cost_body: one size -> batches of one pass; clustered sizes, sorted here,
+    -> by the mean), which must not change any result; cost_batch and dist_batch"""
+    from x265_amd import abi
+    rng = np.random.default_rng(n + len(sizes))
+    W, H = small_seq[0].w, small_seq[0].h
+    reqs = np.zeros(n, abi.COST_REQ)
+    for i, r in enumerate(reqs):
+        w, h = sizes[i * len(sizes) // n]
+        r["fenc_plane"], r["ref_plane"] = 1, int(rng.choice([0, 2]))
+        r["pu_x"], r["pu_y"] = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+        r["pu_w"], r["pu_h"], r["metric"] = w, h, int(rng.integers(0, 2))
+        r["qmv_x"], r["qmv_y"] = int(rng.integers(-90, 90)), int(rng.integers(-90, 90))
+    want = oracle.cost_batch(_planes(small_seq), reqs)
+    assert np.array_equal(gpu_ctx.cost_batch(reqs), want)
+    reqs["metric"] = rng.integers(0, 4, n)
+    assert np.array_equal(gpu_ctx.dist_batch(reqs), oracle.cost_batch(_planes(small_seq), reqs))
+
+
 @pytest.mark.parametrize("method", [0, 1, 2, 3])
 def test_me_batch_methods(gpu_ctx, oracle, small_seq, costtabs, method):
     from x265_amd import abi, synth
