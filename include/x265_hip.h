@@ -61,7 +61,7 @@ enum { X265_HIP_SAD = 0, X265_HIP_SATD = 1, X265_HIP_SA8D = 2, X265_HIP_SSE = 3 
 #define X265_HIP_MC_AVG 0x40
 
 #define X265_HIP_MAX_MVC    12  /* AMVP + spatial candidates, <= 11 in the reference (TEncSearch.cpp:2311) */
-#define X265_HIP_MAX_PLANES 64
+#define X265_HIP_MAX_PLANES 512 /* a 64-picture GOP segment with its four lookahead planes per picture is 320 */
 #define X265_HIP_MAX_QP     82  /* BitCost::BC_MAX_QP, source/encoder/bitcost.h:72 */
 #define X265_HIP_FENC_STRIDE 64 /* FENC_STRIDE, source/common/common.h:45 */
 
@@ -172,7 +172,9 @@ int x265_hip_plane_download(x265_hip_ctx *ctx, int plane_id, uint8_t *host_buf, 
  * Lowres::create + Lowres::init (source/common/lowres.cpp:30-69, 164-174): the half-resolution plane and
  * its three half-pel companions (frame_init_lowres_core, source/common/pixel.cpp:595-618), edge-extended
  * by marginX / marginY (extendPicBorder, pixel.cpp:893-911), made on the device from plane `src_plane`
- * (a full-resolution picture of `width` x `height` with margins of at least 2 samples right and below).
+ * (a full-resolution picture of `width` x `height`; with W = roundup8(width / 2), L = roundup8(height / 2) the
+ * kernel reads source rows 0 .. 2 L and columns 0 .. 2 W + 3, i.e. 2 L - height + 1 rows below and 2 W - width + 4
+ * columns right of the picture must lie inside the plane's buffer: X265_HIP_ERANGE otherwise).
  * Fills plane ids dst_plane0 .. dst_plane0 + 3 = lowresPlane[0..3] (owned by the context, released with
  * x265_hip_plane_release).  Asynchronous on the context's stream. */
 typedef struct x265_hip_lowres_geometry

@@ -428,15 +428,57 @@ int x265r_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, in
     return me.subpelCompare(&rp, MV(qmvx, qmvy), cmp);
 }
 
+struct CostSlice
+{
+    const x265o_plane *planes;
+    const x265o_cost_req *reqs;
+    int32_t *out;
+    int first, last;
+};
+
+/* one MotionEstimate per thread, as the encoder keeps one per CTU row (cturow.h:59) */
+static void *cost_slice(void *arg)
+{
+    CostSlice *s = (CostSlice *)arg;
+    MotionEstimate me;
+    ReferencePlanes rp;
+    for (int i = s->first; i < s->last; i++)
+    {
+        const x265o_cost_req *r = &s->reqs[i];
+        const x265o_plane *fenc = &s->planes[r->fenc_plane], *ref = &s->planes[r->ref_plane];
+        rp.fpelPlane = (pixel *)ref->origin;
+        rp.lumaStride = (int)ref->stride;
+        me.setSourcePlane((pixel *)fenc->origin, fenc->stride);
+        me.setSourcePU(r->pu_x + r->pu_y * (int)fenc->stride, r->pu_w, r->pu_h);
+        const int part = partitionFromSizes(r->pu_w, r->pu_h);
+        pixelcmp_t cmp = r->metric == X265O_SSE ? primitives.sse_pp[part] : r->metric == X265O_SA8D ? primitives.sa8d_inter[part]
+                       : r->metric ? primitives.satd[part] : primitives.sad[part];
+        s->out[i] = me.subpelCompare(&rp, MV(r->qmv_x, r->qmv_y), cmp);
+    }
+    return 0;
+}
+
 void x265r_cost_batch(const x265o_plane *planes, const x265o_cost_req *reqs, int n, int32_t *out, int nthreads)
 {
-    (void)nthreads;
-    for (int i = 0; i < n; i++)
+    init();
+    if (nthreads <= 1 || n < 2 * nthreads)
     {
-        const x265o_cost_req *r = &reqs[i];
-        out[i] = x265r_subpel_cost(&planes[r->fenc_plane], &planes[r->ref_plane], r->pu_x, r->pu_y, r->pu_w, r->pu_h,
-                                   r->qmv_x, r->qmv_y, r->metric);
+        CostSlice s = { planes, reqs, out, 0, n };
+        cost_slice(&s);
+        return;
     }
+    pthread_t *th = new pthread_t[nthreads];
+    CostSlice *sl = new CostSlice[nthreads];
+    for (int t = 0; t < nthreads; t++)
+    {
+        CostSlice s = { planes, reqs, out, (int)((int64_t)n * t / nthreads), (int)((int64_t)n * (t + 1) / nthreads) };
+        sl[t] = s;
+        pthread_create(&th[t], 0, cost_slice, &sl[t]);
+    }
+    for (int t = 0; t < nthreads; t++)
+        pthread_join(th[t], 0);
+    delete[] th;
+    delete[] sl;
 }
 
 /* config-2 building block via the reference: motionEstimate's FULL raster is not separable from

@@ -224,6 +224,20 @@ int x265_hip_ctx_sync(x265_hip_ctx *c)
 
 // ---- planes and cost tables ---------------------------------------------------------------------
 
+// drop plane `id` from the directory and free its buffer if the context owns it: after this no validated request
+// can name the plane, whatever happens to the allocation that usually follows
+static void plane_clear(x265_hip_ctx *c, int id)
+{
+    if (c->owned_plane[id])
+        (void)hipFree(c->owned_plane[id]);
+    c->owned_plane[id] = nullptr;
+    c->host_tabs.planes[id].origin = nullptr;
+    c->host_tabs.planes[id].stride = 0;
+    c->plane_bytes[id] = 0;
+    c->plane_origin[id] = 0;
+    c->tabs_dirty = true;
+}
+
 static int plane_set(x265_hip_ctx *c, int id, const void *dev, size_t bytes, int stride, int origin)
 {
     if (stride <= 0 || origin < 0 || (size_t)origin >= bytes)
@@ -243,13 +257,7 @@ int x265_hip_plane_release(x265_hip_ctx *c, int id)
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->owned_plane[id])
-        (void)hipFree(c->owned_plane[id]);
-    c->owned_plane[id] = nullptr;
-    c->host_tabs.planes[id].origin = nullptr;
-    c->host_tabs.planes[id].stride = 0;
-    c->plane_bytes[id] = 0;
-    c->tabs_dirty = true;
+    plane_clear(c, id);
     return X265_HIP_OK;
 }
 
@@ -262,9 +270,7 @@ int x265_hip_plane_upload(x265_hip_ctx *c, int id, const uint8_t *host_buf, size
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!c->owned_plane[id] || c->plane_bytes[id] != bytes)
     {
-        if (c->owned_plane[id])
-            (void)hipFree(c->owned_plane[id]);
-        c->owned_plane[id] = nullptr;
+        plane_clear(c, id);
         // 64 bytes of slack: dword loads at unaligned byte addresses may run past the last sample
         HIP_TRY(hipMalloc(&c->owned_plane[id], bytes + 64));
         HIP_TRY(hipMemsetAsync((uint8_t *)c->owned_plane[id] + bytes, 0, 64, c->stream));
@@ -281,9 +287,7 @@ int x265_hip_plane_bind(x265_hip_ctx *c, int id, const void *device_buf, size_t 
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->owned_plane[id])
-        (void)hipFree(c->owned_plane[id]);
-    c->owned_plane[id] = nullptr;
+    plane_clear(c, id);
     return plane_set(c, id, device_buf, bytes, stride, origin);
 }
 
@@ -336,6 +340,16 @@ int x265_hip_lowres_init(x265_hip_ctx *c, int src_plane, int width, int height, 
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->host_tabs.planes[src_plane].origin)
         return fail(X265_HIP_EINVAL, "lowres_init: source plane %d is not set", src_plane);
+    {
+        // lowres_init_kernel computes every padded sample from picture positions clamped to the rounded lowres
+        // size, so it reads source rows 0 .. 2 lines and, with its dword loads, columns 0 .. 2 width + 3
+        const PlaneDesc &sp = c->host_tabs.planes[src_plane];
+        const long last = (long)c->plane_origin[src_plane] + 2L * g.lines * sp.stride + 2L * g.width + 4;
+        if (last > (long)c->plane_bytes[src_plane] + 16)
+            return fail(X265_HIP_ERANGE, "lowres_init: plane %d does not cover rows 0..%d and columns 0..%d of the picture "
+                        "(%d rows below and %d columns right of a %dx%d picture are read)", src_plane, 2 * g.lines,
+                        2 * g.width + 3, 2 * g.lines - height + 1, 2 * g.width - width + 4, width, height);
+    }
     HIP_TRY(hipSetDevice(c->device));
     LowresArgs a;
     a.src = c->host_tabs.planes[src_plane].origin;
@@ -351,9 +365,7 @@ int x265_hip_lowres_init(x265_hip_ctx *c, int src_plane, int width, int height, 
         if (!c->owned_plane[id] || c->plane_bytes[id] != g.bytes)
         {
             HIP_TRY(hipStreamSynchronize(c->stream));
-            if (c->owned_plane[id])
-                (void)hipFree(c->owned_plane[id]);
-            c->owned_plane[id] = nullptr;
+            plane_clear(c, id);
             HIP_TRY(hipMalloc(&c->owned_plane[id], g.bytes + 64));
             // the reference clears the buffers (lowres.cpp:63); bytes between the padded width and the stride stay 0
             HIP_TRY(hipMemsetAsync(c->owned_plane[id], 0, g.bytes + 64, c->stream));
@@ -421,9 +433,7 @@ int x265_hip_plane_weight(x265_hip_ctx *c, int src, int dst, int width, int heig
     if (!c->owned_plane[dst] || c->plane_bytes[dst] != bytes)
     {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->owned_plane[dst])
-            (void)hipFree(c->owned_plane[dst]);
-        c->owned_plane[dst] = nullptr;
+        plane_clear(c, dst);
         HIP_TRY(hipMalloc(&c->owned_plane[dst], bytes + 64));
         HIP_TRY(hipMemsetAsync(c->owned_plane[dst], 0, bytes + 64, c->stream));
     }
@@ -554,6 +564,9 @@ static int check_jobs(const x265_hip_ctx *c, const x265_hip_me_job *jobs, int n)
         int r = check_block(c, j.fenc_plane, j.ref_plane, j.pu_w, j.pu_h, "me_job", i);
         if (r)
             return r;
+        if ((j.method & ~X265_HIP_LOWRES_REF) > X265_HIP_FULL || j.subme > 7 || j.num_mvc > X265_HIP_MAX_MVC)
+            return fail(X265_HIP_EINVAL, "me_job[%d]: method %d / subme %d / num_mvc %d out of range", i, j.method, j.subme,
+                        j.num_mvc);
         if (j.method & X265_HIP_LOWRES_REF)
         {
             // a Lowres reference: the lookahead's 8x8 CU, four planes of one stride
@@ -563,20 +576,29 @@ static int check_jobs(const x265_hip_ctx *c, const x265_hip_me_job *jobs, int n)
                 return fail(X265_HIP_EINVAL, "me_job[%d]: lowres planes %d..%d out of range", i, j.ref_plane, j.ref_plane + 3);
             for (int k = 1; k < 4; k++)
                 if (!c->host_tabs.planes[j.ref_plane + k].origin ||
-                    c->host_tabs.planes[j.ref_plane + k].stride != c->host_tabs.planes[j.ref_plane].stride)
-                    return fail(X265_HIP_EINVAL, "me_job[%d]: lowres plane %d missing or of another stride", i, j.ref_plane + k);
+                    c->host_tabs.planes[j.ref_plane + k].stride != c->host_tabs.planes[j.ref_plane].stride ||
+                    c->plane_bytes[j.ref_plane + k] != c->plane_bytes[j.ref_plane] ||
+                    c->plane_origin[j.ref_plane + k] != c->plane_origin[j.ref_plane])
+                    return fail(X265_HIP_EINVAL, "me_job[%d]: lowres plane %d missing or of another layout", i, j.ref_plane + k);
         }
-        if ((j.method & ~X265_HIP_LOWRES_REF) > X265_HIP_FULL || j.subme > 7 || j.num_mvc > X265_HIP_MAX_MVC)
-            return fail(X265_HIP_EINVAL, "me_job[%d]: method %d / subme %d / num_mvc %d out of range", i, j.method, j.subme,
-                        j.num_mvc);
         if (j.qp >= X265_HIP_MAX_QP || !c->host_tabs.costtab[j.qp])
             return fail(X265_HIP_EINVAL, "me_job[%d]: no cost table uploaded for qp %d", i, j.qp);
         if (j.mvmin_x > j.mvmax_x || j.mvmin_y > j.mvmax_y)
             return fail(X265_HIP_EINVAL, "me_job[%d]: empty search range", i);
-        // reach: the window, one sample around it for the sub-pel refinement, and the zero vector with its diamond
-        // (motion.cpp:570-578, 707-712), which the reference tests without a range check
-        const long lox = std::min<long>(j.mvmin_x, 0) - 1, hix = std::max<long>(j.mvmax_x, 0) + 1;
-        const long loy = std::min<long>(j.mvmin_y, 0) - 1, hiy = std::max<long>(j.mvmax_y, 0) + 1;
+        // Reach: the window and the zero vector (tested without a range check, motion.cpp:570-578), plus what the
+        // search may step outside them, as the reference does: its range checks stop a pattern only after the
+        // centre has left the window.  DIA: one diamond step (motion.cpp:608-625).  HEX: a hexagon step of 2 and
+        // the square refine of 1 (:650-698).  UMH: the unguarded diamonds, octagon and hexagon around the start
+        // (:707-742) take the centre up to 4 out; the crosses and rings are guarded and the closing hexagon search
+        // only starts from inside (:882-883).  STAR and FULL guard every point.  The sub-pel stage then moves by
+        // up to 2 hpel_iters + qpel_iters quarter samples (workload[], :47-57; a Lowres reference: one half-pel and
+        // one quarter-pel ring, :1055-1080); check_reach adds the filters' margins.
+        static const int k_int_over[5] = { 1, 3, 4, 0, 0 };
+        static const int k_qsteps[8] = { 2, 3, 3, 5, 6, 3, 5, 6 };
+        const int qsteps = (j.method & X265_HIP_LOWRES_REF) ? 3 : k_qsteps[j.subme];
+        const long over = k_int_over[j.method & ~X265_HIP_LOWRES_REF] + (qsteps + 3) / 4;
+        const long lox = std::min<long>(j.mvmin_x, 0) - over, hix = std::max<long>(j.mvmax_x, 0) + over;
+        const long loy = std::min<long>(j.mvmin_y, 0) - over, hiy = std::max<long>(j.mvmax_y, 0) + over;
         if ((r = check_inside(c, j.fenc_plane, j.pu_x, j.pu_y, j.pu_w, j.pu_h, "me_job", i)) ||
             (r = check_reach(c, j.ref_plane, j.pu_x + lox, j.pu_y + loy, j.pu_x + hix + j.pu_w, j.pu_y + hiy + j.pu_h, "me_job", i)))
             return r;

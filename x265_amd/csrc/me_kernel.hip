@@ -1286,9 +1286,9 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
     // Lowres references of bidirectional requests: half-pel planes 1..3 of both references at the displaced block
     __shared__ const uint8_t *low_lds[BIDIR ? 4 : 1][6][BIDIR ? COST_BATCH : 1];
     __shared__ PlaneDesc planes[X265_HIP_MAX_PLANES];
-    static_assert(sizeof(PlaneDesc) == 16 && X265_HIP_MAX_PLANES * 4 <= 256, "plane directory copy below");
-    if (threadIdx.x < X265_HIP_MAX_PLANES * 4)
-        ((uint32_t *)planes)[threadIdx.x] = ((const uint32_t *)tabs->planes)[threadIdx.x];
+    static_assert(sizeof(PlaneDesc) == 16, "plane directory copy below: one 16-byte entry per thread and round");
+    for (int i = threadIdx.x; i < X265_HIP_MAX_PLANES; i += 256)
+        ((uint4 *)planes)[i] = ((const uint4 *)tabs->planes)[i];
     __syncthreads();
 
     CostLds &L = lds[threadIdx.x >> 6];
