@@ -316,6 +316,16 @@ int x265_hip_me_batch(x265_hip_ctx *ctx, const x265_hip_me_job *jobs, int n, x26
 int x265_hip_me_batch_device(x265_hip_ctx *ctx, const void *d_jobs, int n, void *d_results);
 int x265_hip_cost_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs);
 
+/* x265_hip_cost_batch_device for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same requests, same costs;
+ * the kernel's batch counters live in a static 8 KiB device array of the library (one copy per GPU, held until the
+ * process ends) instead of the context's buffer, so the call allocates and frees nothing.  At most
+ * X265_HIP_NOALLOC_MAX_REQUESTS requests per call (X265_HIP_ERANGE beyond).  All calls on one GPU share the array:
+ * calls that overlap on one GPU (two contexts, two threads) race and must be serialised by the caller.
+ * Asynchronous on the context's stream like the other `_device` forms. */
+#define X265_HIP_NOALLOC_MAX_REQUESTS (1 << 24)
+int x265_hip_cost_batch_device_noalloc(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs);
+
 /* Exhaustive integer-pel search of every square PU (64,32,16,8: 85 per CTU) of the listed 64x64
  * CTUs over [mvmin, mvmax], SAD + mvcost, first minimum in raster order -- the integer stage of
  * motionEstimate with X265_FULL_SEARCH (motion.cpp:997-1032) started from bcost = INT_MAX, with

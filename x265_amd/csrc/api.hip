@@ -84,7 +84,35 @@ struct x265_hip_ctx
     Buf prim_a, prim_b; // staging of the primitive thunks
 };
 
+// ---- scratch of the entry point that allocates nothing (x265_hip_cost_batch_device_noalloc) --------------
+// The cost kernels hand their batches out through counters in device memory.  Contexts keep theirs in a buffer
+// from hipMalloc; callers that cannot allocate get this array instead: one copy per GPU, held until the process
+// ends, shared by every call on that GPU.  In host code `scratch` is only a handle for hipGetSymbolAddress; the
+// device address it yields (one per device) is what host code passes on.
+#define X265HIP_MAX_DEVICES 64
+static __device__ __align__(256) uint32_t scratch[X265HIP_COST_COUNTER_BYTES / sizeof(uint32_t)];
+
 namespace {
+
+uint32_t *g_scratch_ptr[X265HIP_MAX_DEVICES] = {};
+std::mutex g_scratch_mu;
+
+// once per device, with that device current
+int scratch_setup(int device)
+{
+    if (device < 0 || device >= X265HIP_MAX_DEVICES)
+        return 0; // such a device gets no scratch: the entry point refuses it
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (!g_scratch_ptr[device])
+    {
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p)
+            return fail(X265_HIP_ERUNTIME, "hipGetSymbolAddress(scratch) returned a null address on device %d", device);
+        g_scratch_ptr[device] = (uint32_t *)p;
+    }
+    return 0;
+}
 
 int ensure(x265_hip_ctx *c, Buf &b, size_t bytes)
 {
@@ -156,6 +184,9 @@ int x265_hip_ctx_create(int device, x265_hip_ctx **out)
     if (!is_gfx950(device))
         return fail(X265_HIP_ENODEV, "device %d is not gfx950; this library carries gfx950 code only", device);
     HIP_TRY(hipSetDevice(device));
+    int sr = scratch_setup(device);
+    if (sr)
+        return sr;
     x265_hip_ctx *c = new (std::nothrow) x265_hip_ctx;
     if (!c)
         return fail(X265_HIP_ENOMEM, "out of host memory");
@@ -653,6 +684,32 @@ int x265_hip_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void 
     if (r)
         return r;
     LAUNCH(launch_cost(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    return X265_HIP_OK;
+}
+
+// x265_hip_cost_batch_device without any allocation: the batch counters are this GPU's `scratch` array (through
+// the address taken at context creation) instead of the context's buffer.  Every call on a GPU shares that array,
+// so it is cleared on the stream in front of the launch (another context's call leaves its counts behind) and the
+// kernel counts in set 0.  No hipMalloc / hipFree / growing staging on this path.
+int x265_hip_cost_batch_device_noalloc(x265_hip_ctx *c, const void *d_reqs, int n, void *d_costs)
+{
+    if (!c || n < 0 || (n && (!d_reqs || !d_costs)))
+        return fail(X265_HIP_EINVAL, "cost_batch_device_noalloc: bad argument");
+    if (n > X265_HIP_NOALLOC_MAX_REQUESTS)
+        return fail(X265_HIP_ERANGE, "cost_batch_device_noalloc: %d requests exceed the limit of %d per call", n,
+                    X265_HIP_NOALLOC_MAX_REQUESTS);
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t *const ptr = c->device < X265HIP_MAX_DEVICES ? g_scratch_ptr[c->device] : nullptr;
+    if (!ptr)
+        return fail(X265_HIP_ERUNTIME, "cost_batch_device_noalloc: no scratch address for device %d", c->device);
+    int r = push_tabs(c); // a copy into the context's directory, nothing is allocated
+    if (r)
+        return r;
+    HIP_TRY(hipMemsetAsync(ptr, 0, X265HIP_COST_COUNTER_BYTES, c->stream));
+    LAUNCH(launch_cost(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, ptr, 0, c->stream));
     return X265_HIP_OK;
 }
 

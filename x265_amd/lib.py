@@ -35,6 +35,7 @@ EXPORTS = [
     "x265_hip_plane_extend_border", "x265_hip_plane_weight",
     "x265_hip_bidir_cost_batch", "x265_hip_bidir_cost_batch_device",
     "x265_hip_dist_batch", "x265_hip_dist_batch_device", "x265_hip_predict_batch", "x265_hip_predict_batch_device",
+    "x265_hip_cost_batch_device_noalloc",
 ]
 
 
@@ -236,6 +237,9 @@ class Context:
 
     def cost_batch_device(self, d_reqs, n, d_costs):
         _check(load().x265_hip_cost_batch_device(self._h, C.c_void_p(d_reqs), C.c_int(n), C.c_void_p(d_costs)))
+
+    def cost_batch_device_noalloc(self, d_reqs, n, d_costs):
+        _check(load().x265_hip_cost_batch_device_noalloc(self._h, C.c_void_p(d_reqs), C.c_int(n), C.c_void_p(d_costs)))
 
     def fullsearch_device(self, d_jobs, n, d_results):
         _check(load().x265_hip_fullsearch_device(self._h, C.c_void_p(d_jobs), C.c_int(n), C.c_void_p(d_results)))
