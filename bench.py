@@ -3,20 +3,19 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Workload (BASELINE.json configs[1]): batched integer-pel full search, 1080p, 64x64 CTUs, +-64 range.
-One step = one picture searched against one reference: every 64x64 CTU, every square PU
-(64/32/16/8) wholly inside the picture, every integer position of the window that
-xSetSearchRange gives around the CTU's predictor, SAD + mvcost, first minimum in raster order.
-`value` counts (PU, position) cost evaluations per second with planes, job lists and results resident
-in HBM.  Two more timed legs (reported in extra keys) run on the same pictures: the full motionEstimate
-replay (HEX, subme 2, merange 57, 3 references: configs[2]) and the SATD sub-pel candidate set (every
-square PU x 3 references x 16 half-/quarter-pel candidates through 8-tap interpolation + SATD).
+Workload (BASELINE.json configs[3] / configs[4]): a synthetic 3840x2160 sequence cut into closed GOP segments
+(x265_amd/shard.py), segment s on rank s mod N, every rank holding the planes of its own segments in HBM
+(x265_amd/runner.py); nothing crosses ranks on the data path.  One step = the sub-pel SATD candidate stage of one P
+picture of the rank's segments: every square PU (64/32/16/8) x every reference (the up to 3 previous pictures of the
+same segment) x 16 half-/quarter-pel candidates, each an 8-tap interpolation + SATD (MotionEstimate::subpelCompare +
+satd, motion.cpp:1126-1164).  `value` = SATD candidates per second over all ranks with planes, request lists and
+results resident in HBM.
 
-Unless --no-4k is given the same three legs are also run on one 4K picture (configs[3]) and reported under
-`uhd` (kernel times, per GPU; not part of `value`).
-
-For N > 1 the driver launches one rank per GPU; ranks take disjoint GOP segments of the
-sequence (no collective on the data path) and the job-wide rate is units / max-over-ranks time.
+Further timed legs on the same pictures, each with its own roofline, in extra keys: `me_stage` (the full motionEstimate
+replay, HEX / subme 2 / merange 57: ME-stage pictures per second) and `fullsearch` (configs[1]'s integer SAD search,
++-64, against the nearest reference).  `hd` repeats the three legs on 1080p pictures (kernel times, per GPU).
+`cpu_baseline` times the reference's own subpelCompare + satd (oracle/_ref, C primitives; no yasm in the image, so no
+x86 assembly) on the host cores over the same request list.
 """
 import argparse
 import json
@@ -29,59 +28,70 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H = 1920, 1080
 RANGE = 64
-PX_PEAK = 1.34e14     # measured v_qsad_pk_u16_u8 / v_sad_u8 pixel rate, profiles/r01_ubench_valu.txt
-LANE_PEAK = 3.93e13   # integer VALU lane-ops/s: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (measured 3.65e13)
-HBM_PEAK = 8000.0     # GB/s
+# Peaks (MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 at 2.4 GHz; tools/ubench_valu.hip, profiles/r02_ubench_valu.txt)
+VALU_PEAK = 7.86e13        # 32-bit lane-ops/s: a wave64 instruction every 2 cycles per SIMD (v_add_u32, v_fma_f32 ...)
+VALU_ISSUE_4CYC = 3.93e13  # the forms these kernels are made of (packed 16-bit, v_dot4 / v_dot2, v_perm, v_sad_u8, DPP) issue every 4
+SAD_PX_PEAK = 1.57e14      # CUs x 64 lanes x 2.4 GHz x 4 pixels per lane-op (v_qsad_pk_u16_u8 measured: 1.53e14)
+HBM_PEAK = 8000.0          # GB/s
+
+
+def valid_pus_per_ctu(w, h):
+    """number of square PUs wholly inside the picture, per CTU in raster order"""
+    ncx, ncy = -(-w // 64), -(-h // 64)
+    cx, cy = np.meshgrid(np.arange(ncx), np.arange(ncy), indexing="xy")
+    out = np.zeros(ncx * ncy, np.int64)
+    for s in (64, 32, 16, 8):
+        out += ((np.minimum(64, w - cx * 64) // s) * (np.minimum(64, h - cy * 64) // s)).reshape(-1)
+    return out
 
 
 def build_ctu_jobs(seq, cur, ref, fenc_plane, ref_plane, qp=30, size=None):
+    """CTU jobs of the integer full search of picture `cur` against `ref` (kept for the tests that import it)"""
     from x265_amd import lib, synth
-    W, H = size or (globals()["W"], globals()["H"])
+    W, H = size or (seq.w, seq.h)
     ncx, ncy = synth.ctu_grid(W, H)
     dx, dy = seq.global_motion(cur, ref)
+    cx, cy = np.meshgrid(np.arange(ncx) * 64, np.arange(ncy) * 64, indexing="xy")
+    cx, cy = cx.reshape(-1), cy.reshape(-1)
     jobs = np.zeros(ncx * ncy, lib.CTU_JOB)
-    k = 0
-    for cy in range(ncy):
-        for cx in range(ncx):
-            j = jobs[k]
-            k += 1
-            x, y = cx * 64, cy * 64
-            lox, loy, hix, hiy = synth.search_range(np.int64(4 * dx), np.int64(4 * dy), RANGE, x, y, W, H)
-            j["fenc_plane"], j["ref_plane"] = fenc_plane, ref_plane
-            j["ctu_x"], j["ctu_y"] = x, y
-            j["mvmin_x"], j["mvmin_y"], j["mvmax_x"], j["mvmax_y"] = lox, loy, hix, hiy
-            j["qmvp_x"], j["qmvp_y"] = 4 * dx, 4 * dy
-            j["qp"] = qp
+    lox, loy, hix, hiy = synth.search_range(np.int64(4 * dx), np.int64(4 * dy), RANGE, cx, cy, W, H)
+    jobs["fenc_plane"], jobs["ref_plane"] = fenc_plane, ref_plane
+    jobs["ctu_x"], jobs["ctu_y"] = cx, cy
+    jobs["mvmin_x"], jobs["mvmin_y"], jobs["mvmax_x"], jobs["mvmax_y"] = lox, loy, hix, hiy
+    jobs["qmvp_x"], jobs["qmvp_y"], jobs["qp"] = 4 * dx, 4 * dy, qp
     return jobs
 
 
-def valid_pus_per_ctu(size=None):
-    """number of square PUs wholly inside the picture, per CTU in raster order"""
-    from x265_amd import synth
-    W, H = size or (globals()["W"], globals()["H"])
-    ncx, ncy = synth.ctu_grid(W, H)
-    out = np.zeros(ncx * ncy, np.int64)
-    for cy in range(ncy):
-        for cx in range(ncx):
-            n = 0
-            for s in (64, 32, 16, 8):
-                nx = min(64, W - cx * 64) // s
-                ny = min(64, H - cy * 64) // s
-                n += nx * ny
-            out[cy * ncx + cx] = n
-    return out
+class Picture:
+    """device-resident work lists of one P picture"""
+
+    def __init__(self, torch, dev, runner, cur, refs, vp):
+        from x265_amd import lib, synth
+        self.cur, self.refs = cur, refs
+        rq = runner.satd_requests(cur, refs)
+        self.n_satd, self.satd_ops = len(rq), synth.satd_lane_ops(rq)
+        self.d_satd = torch.from_numpy(rq.view(np.uint8).copy()).to(dev)
+        self.me_host = runner.me_jobs(cur, refs)
+        self.n_me = len(self.me_host)
+        self.d_me = torch.from_numpy(self.me_host.view(np.uint8).copy()).to(dev)
+        cj = runner.ctu_jobs(cur, refs[0], RANGE)
+        npos = (cj["mvmax_x"].astype(np.int64) - cj["mvmin_x"] + 1) * (cj["mvmax_y"].astype(np.int64) - cj["mvmin_y"] + 1)
+        self.n_ctu, self.fs_units, self.fs_pos = len(cj), int((npos * vp).sum()), int(npos.sum())
+        self.d_fs = torch.from_numpy(cj.view(np.uint8).copy()).to(dev)
+        self.plane_bytes = (1 + len(refs)) * runner.seq_plane_bytes
+        self.satd_host = rq if cur == runner.keep_host_for else None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=100)  # the clocks ramp under sustained load: tens of ms
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10, help="untimed steps per leg; every leg also warms up for 60 ms (clock ramp)")
+    ap.add_argument("--gop", type=int, default=8, help="pictures per closed GOP segment")
+    ap.add_argument("--segments-per-rank", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-4k", action="store_true", help="skip the extra 4K legs (reported under the key uhd)")
-    ap.add_argument("--frames", type=int, default=4, help="pictures per rank kept resident (steps cycle over them)")
+    ap.add_argument("--no-hd", action="store_true", help="skip the 1080p legs (key hd)")
     args = ap.parse_args()
 
     import torch
@@ -90,8 +100,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # X265_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks then
-    # share devices); the driver's runs use RCCL, one rank per GPU
+    # X265_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks then share
+    # devices); the driver's runs use RCCL, one rank per GPU
     backend = os.environ.get("X265_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local %= torch.cuda.device_count()
@@ -104,52 +114,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from x265_amd import abi, lib, synth
+    from x265_amd import abi, lib, runner as rn, shard, synth
 
-    # ---- resident input: this rank's GOP segment -----------------------------------------------
-    nfr = args.frames
-    seq = synth.Sequence(W, H, seed=0x265)
-    first = rank * nfr  # disjoint segments of the same synthetic sequence
-    planes = [synth.Plane(seq.frame(first + i)) for i in range(nfr + 3)]
     ctx = lib.Context(local)
-    for i, p in enumerate(planes):
-        ctx.plane_upload(i, p.buf, p.stride, p.origin)
-    for qp in range(28, 40):
-        ctx.set_qp(qp)
-
-    # step s searches picture (3 + s % nfr) against the previous picture
-    vp = valid_pus_per_ctu()
-    fs_jobs, fs_units, fs_pos = [], [], []
-    for i in range(nfr):
-        cur = 3 + i
-        j = build_ctu_jobs(seq, first + cur, first + cur - 1, cur, cur - 1)
-        npos = (j["mvmax_x"].astype(np.int64) - j["mvmin_x"] + 1) * (j["mvmax_y"].astype(np.int64) - j["mvmin_y"] + 1)
-        fs_units.append(int((npos * vp).sum()))
-        fs_pos.append(int(npos.sum()))
-        fs_jobs.append(torch.from_numpy(j.view(np.uint8).copy()).to(dev))
-    n_ctu = len(vp)
-    fs_out = torch.empty(n_ctu * lib.PUS_PER_CTU * 8, dtype=torch.uint8, device=dev)
-
-    me_jobs, me_n = [], []
-    for i in range(nfr):
-        cur = 3 + i
-        refs = [cur - 1, cur - 2, cur - 3]
-        mot = [seq.global_motion(first + cur, first + r) for r in refs]
-        j = synth.me_jobs(W, H, cur, refs, mot, method=abi.HEX, subme=2, merange=57, seed=first + cur)
-        me_n.append(len(j))
-        me_jobs.append(torch.from_numpy(j.view(np.uint8).copy()).to(dev))
-    me_out = torch.empty(max(me_n) * 8, dtype=torch.uint8, device=dev)
-
-    sp_reqs, sp_n, sp_ops = [], [], []
-    for i in range(nfr):
-        cur = 3 + i
-        refs = [cur - 1, cur - 2, cur - 3]
-        rq = synth.subpel_requests(W, H, cur, refs, [seq.global_motion(first + cur, first + r) for r in refs])
-        sp_n.append(len(rq))
-        sp_ops.append(synth.satd_lane_ops(rq))
-        sp_reqs.append(torch.from_numpy(rq.view(np.uint8).copy()).to(dev))
-    sp_out = torch.empty(max(sp_n), dtype=torch.int32, device=dev)
-
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
 
     def barrier():
@@ -159,184 +126,200 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_fs(step):
-        i = step % nfr
-        ctx.fullsearch_device(fs_jobs[i].data_ptr(), n_ctu, fs_out.data_ptr())
-        return fs_units[i], fs_pos[i]
+    def max_over_ranks(v):
+        if world == 1:
+            return float(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    def run_me(step):
-        i = step % nfr
-        ctx.me_batch_device(me_jobs[i].data_ptr(), me_n[i], me_out.data_ptr())
-        return me_n[i]
-
-    def run_sp(step):
-        i = step % nfr
-        ctx.cost_batch_device(sp_reqs[i].data_ptr(), sp_n[i], sp_out.data_ptr())
-        return sp_n[i], sp_ops[i]
-
-    def timed(fn, steps, warmup):
+    def leg(fn, steps, warmup):
+        """fn(step) launches one step and returns its unit counts; exactly `steps` steps inside the bracket"""
         for s in range(warmup):
             fn(s)
+        t0 = time.perf_counter()
+        s = warmup
+        while time.perf_counter() - t0 < 0.06:  # the clocks ramp under sustained load
+            fn(s)
+            s += 1
+            ctx.sync()
         barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record(ext)
-        acc = []
-        for s in range(steps):
-            acc.append(fn(s))
+        acc = [fn(s) for s in range(steps)]
         e1.record(ext)
         barrier()
         dt = time.perf_counter() - t0
-        ev_ms = e0.elapsed_time(e1)
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, ev_ms, acc
+        return max_over_ranks(dt), e0.elapsed_time(e1), acc
 
-    dt_fs, ev_fs, acc_fs = timed(run_fs, args.steps, args.warmup)
-    units = sum(a[0] for a in acc_fs)
-    positions = sum(a[1] for a in acc_fs)
-    dt_me, ev_me, acc_me = timed(run_me, args.steps, args.warmup)
-    me_calls = sum(acc_me)
-    dt_sp, ev_sp, acc_sp = timed(run_sp, args.steps, args.warmup)
-    sp_cands = sum(a[0] for a in acc_sp)
-    sp_lane_ops = sum(a[1] for a in acc_sp)
+    def load_pictures(seq, gop, spr, n_refs=3):
+        """this rank's segments of a world * spr * gop picture sequence, all resident; one Picture per P picture"""
+        n_frames = world * spr * gop
+        vp = valid_pus_per_ctu(seq.w, seq.h)
+        pics, runners = [], []
+        for i, seg in enumerate(shard.segments_for_rank(n_frames, gop, rank, world)):
+            r = rn.SegmentRunner(ctx, seq, n_refs=n_refs, plane_base=i * gop)
+            r.load(seg)
+            r.seq_plane_bytes = synth.Plane.nbytes_for(seq.w, seq.h)
+            r.keep_host_for = seg[0] + min(gop - 1, n_refs) if (rank == 0 and i == 0) else -1
+            runners.append(r)
+            for cur, refs in r.pairs():
+                pics.append(Picture(torch, dev, r, cur, refs, vp))
+        return pics, runners, n_frames
 
-    # ---- the same three legs on one 4K picture (BASELINE configs[3]); extra information, outside `value` ----
-    uhd = None
-    if not args.no_4k:
-        UW, UH = 3840, 2160
-        useq = synth.Sequence(UW, UH, seed=0x265)
-        ubase = 16  # plane ids 16 .. 19
-        for i in range(4):
-            p = synth.Plane(useq.frame(first + i))
-            ctx.plane_upload(ubase + i, p.buf, p.stride, p.origin)
-        urefs = [2, 1, 0]
-        umot = [useq.global_motion(first + 3, first + r) for r in urefs]
-        uvp = valid_pus_per_ctu((UW, UH))
-        uj = build_ctu_jobs(useq, first + 3, first + 2, ubase + 3, ubase + 2, size=(UW, UH))
-        unpos = (uj["mvmax_x"].astype(np.int64) - uj["mvmin_x"] + 1) * (uj["mvmax_y"].astype(np.int64) - uj["mvmin_y"] + 1)
-        umj = synth.me_jobs(UW, UH, 3, urefs, umot, method=abi.HEX, subme=2, merange=57, seed=first + 3)
-        urq = synth.subpel_requests(UW, UH, 3, urefs, umot)
-        for a in (umj, urq):
-            a["fenc_plane"] += ubase
-            a["ref_plane"] += ubase
-        d_fs, d_me, d_sp = (torch.from_numpy(a.view(np.uint8).copy()).to(dev) for a in (uj, umj, urq))
-        o_fs = torch.empty(len(uj) * lib.PUS_PER_CTU * 8, dtype=torch.uint8, device=dev)
-        o_me = torch.empty(len(umj) * 8, dtype=torch.uint8, device=dev)
-        o_sp = torch.empty(len(urq), dtype=torch.int32, device=dev)
+    def three_legs(pics, steps, warmup):
+        n = len(pics)
+        o_satd = torch.empty(max(p.n_satd for p in pics), dtype=torch.int32, device=dev)
+        o_me = torch.empty(max(p.n_me for p in pics) * 8, dtype=torch.uint8, device=dev)
+        o_fs = torch.empty(max(p.n_ctu for p in pics) * lib.PUS_PER_CTU * 8, dtype=torch.uint8, device=dev)
 
-        def leg(fn, reps=20):
-            t0 = time.perf_counter()
-            while time.perf_counter() - t0 < 0.05:  # warm-up by time: the clocks ramp under sustained load
-                fn()
-                ctx.sync()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(ext)
-            for _ in range(reps):
-                fn()
-            e1.record(ext)
-            ctx.sync()
-            return e0.elapsed_time(e1) / reps
+        def run_satd(s):
+            p = pics[s % n]
+            ctx.cost_batch_device(p.d_satd.data_ptr(), p.n_satd, o_satd.data_ptr())
+            return p
 
-        ms_fs = leg(lambda: ctx.fullsearch_device(d_fs.data_ptr(), len(uj), o_fs.data_ptr()))
-        ms_me = leg(lambda: ctx.me_batch_device(d_me.data_ptr(), len(umj), o_me.data_ptr()))
-        ms_sp = leg(lambda: ctx.cost_batch_device(d_sp.data_ptr(), len(urq), o_sp.data_ptr()))
-        uops = synth.satd_lane_ops(urq)
-        uhd = {"workload": "configs[3]: one 3840x2160 picture per step and GPU, same three legs, 3 references for the ME legs; "
-                           "kernel time (HIP events), per GPU",
-               "fullsearch": {"candidates_per_s": float((unpos * uvp).sum()) / ms_fs * 1e3, "ms_per_picture_per_ref": ms_fs,
-                              "frac_of_sad_roof": float(unpos.sum()) * 4096 / (ms_fs * 1e-3) / PX_PEAK},
-               "me_stage": {"frames_per_s": 1e3 / ms_me, "ms_per_frame": ms_me, "me_calls_per_s": len(umj) / ms_me * 1e3},
-               "satd_candidates": {"candidates_per_s": len(urq) / ms_sp * 1e3, "ms_per_frame": ms_sp,
-                                   "frac_of_valu_peak": uops / (ms_sp * 1e-3) / LANE_PEAK}}
-        for i in range(4):
-            ctx.plane_release(ubase + i)
+        def run_me(s):
+            p = pics[s % n]
+            ctx.me_batch_device(p.d_me.data_ptr(), p.n_me, o_me.data_ptr())
+            return p
 
-    # ---- CPU baseline: the reference's own C primitives (oracle/_ref) when present, else the port ----
-    cpu = None
+        def run_fs(s):
+            p = pics[s % n]
+            ctx.fullsearch_device(p.d_fs.data_ptr(), p.n_ctu, o_fs.data_ptr())
+            return p
+
+        return leg(run_satd, steps, warmup), leg(run_me, steps, warmup), leg(run_fs, steps, warmup)
+
+    # ---- configs[3] / configs[4]: 4K, GOP-sharded ----------------------------------------------------------------
+    UW, UH = 3840, 2160
+    seq = synth.Sequence(UW, UH, seed=0x265)
+    pics, runners, n_frames = load_pictures(seq, args.gop, args.segments_per_rank)
+    (dt_sp, ev_sp, acc_sp), (dt_me, ev_me, acc_me), (dt_fs, ev_fs, acc_fs) = three_legs(pics, args.steps, args.warmup)
+
+    hd = None
+    if not args.no_hd:
+        hseq = synth.Sequence(1920, 1080, seed=0x265)
+        for r in runners:
+            r.release()
+        hpics, hrunners, _ = load_pictures(hseq, 4, 1)
+        (_, h_sp, a_sp), (_, h_me, a_me), (_, h_fs, a_fs) = three_legs(hpics, args.steps, 0)
+        hd = {"workload": "the same three legs on 1920x1080 pictures (configs[1], configs[2]): one closed segment of 4 pictures per "
+                          "GPU, kernel time (HIP events), per GPU",
+              "satd_candidates_per_s": sum(p.n_satd for p in a_sp) / h_sp * 1e3,
+              "satd_frac_of_valu_peak": sum(p.satd_ops for p in a_sp) / (h_sp * 1e-3) / VALU_PEAK,
+              "me_frames_per_s": len(a_me) / h_me * 1e3, "me_calls_per_s": sum(p.n_me for p in a_me) / h_me * 1e3,
+              "fullsearch_candidates_per_s": sum(p.fs_units for p in a_fs) / h_fs * 1e3,
+              "fullsearch_frac_of_sad_peak": sum(p.fs_pos for p in a_fs) * 4096 / (h_fs * 1e-3) / SAD_PX_PEAK}
+        for r in hrunners:
+            r.release()
+
+    # ---- CPU baselines and work models (rank 0, N = 1): the reference's own code where it was built --------------
+    cpu = cpu_me = me_model = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from concurrent.futures import ThreadPoolExecutor
         from oracle import pyoracle  # checker libraries: used for this baseline leg only
         chk = pyoracle.load_ref() if pyoracle.have_ref() else pyoracle.load_oracle()
         cores = min(16, os.cpu_count() or 1)
-        j = build_ctu_jobs(seq, first + 3, first + 2, 3, 2)
-        tab = lib.costtab_build(30)
-        pl = [p.as_tuple() for p in planes]
-
-        def one(k):
-            jj = j[k]
-            chk.ctu_fullsearch(pl[3], pl[2], tab, int(jj["ctu_x"]), int(jj["ctu_y"]),
-                               (int(jj["mvmin_x"]), int(jj["mvmin_y"])), (int(jj["mvmax_x"]), int(jj["mvmax_y"])),
-                               (int(jj["qmvp_x"]), int(jj["qmvp_y"])))
-            npos = (int(jj["mvmax_x"]) - int(jj["mvmin_x"]) + 1) * (int(jj["mvmax_y"]) - int(jj["mvmin_y"]) + 1)
-            return npos * int(vp[k])
-        # whole pictures of the same workload, repeated until about 10 s of wall time have passed
+        p0 = next(p for p in pics if p.satd_host is not None)
+        r0 = runners[0]
+        first = r0_first = shard.segments_for_rank(n_frames, args.gop, 0, 1)[0][0]
+        # host copies of the planes this picture reads, indexed by plane id
+        host_planes = {}
+        for pic in [p0.cur] + list(p0.refs):
+            host_planes[r0.plane_base + (pic - first)] = synth.Plane(seq.frame(pic)).as_tuple()
+        pl = [host_planes.get(i, host_planes[min(host_planes)]) for i in range(max(host_planes) + 1)]
+        rq = p0.satd_host
         t0 = time.perf_counter()
-        cu, passes = 0, 0
-        with ThreadPoolExecutor(cores) as ex:
-            while time.perf_counter() - t0 < 10.0:
-                cu += sum(ex.map(one, range(n_ctu)))
-                passes += 1
+        passes = 0
+        while time.perf_counter() - t0 < 10.0:
+            chk.cost_batch(pl, rq, nthreads=cores)
+            passes += 1
         cdt = time.perf_counter() - t0
-        cpu = {"value": cu / cdt, "unit": "candidates/s", "cores": cores, "kind": chk.kind,
-               "sample": f"{passes} pass(es) over the {n_ctu} CTUs of one 1080p picture, same windows; "
-                         f"{'reference C sad primitives, -O3 (no asm: no yasm in the image)' if chk.kind == 'reference' else 'C restatement'}"
-                         f", one thread per CTU, {cdt:.1f} s"}
-        # the same for the ME stage: the job list of one picture through the reference MotionEstimate
-        mj = synth.me_jobs(W, H, 3, [2, 1, 0], [seq.global_motion(first + 3, first + r) for r in (2, 1, 0)],
-                           method=abi.HEX, subme=2, merange=57, seed=first + 3)
+        what = "reference subpelCompare + satd, C primitives -O3 (no asm: no yasm in the image)" if chk.kind == "reference" else "C restatement"
+        cpu = {"value": passes * len(rq) / cdt, "unit": "SATD candidates/s", "cores": cores, "kind": chk.kind,
+               "sample": f"{passes} pass(es) over the {len(rq)} requests of one 4K P picture with {len(p0.refs)} references; {what}; {cdt:.1f} s"}
         tabs = {q: lib.costtab_build(q) for q in range(28, 40)}
         t0 = time.perf_counter()
         mp = 0
         while time.perf_counter() - t0 < 8.0:
-            chk.me_batch(pl, tabs, mj, nthreads=cores)
+            chk.me_batch(pl, tabs, p0.me_host, nthreads=cores)
             mp += 1
         mdt = time.perf_counter() - t0
-        cpu_me = {"frames_per_s": mp / mdt, "me_calls_per_s": mp * len(mj) / mdt, "cores": cores, "kind": chk.kind,
-                  "sample": f"{mp} pass(es) over one picture's {len(mj)} motionEstimate calls, {mdt:.1f} s"}
+        cpu_me = {"frames_per_s": mp / mdt, "me_calls_per_s": mp * p0.n_me / mdt, "cores": cores, "kind": chk.kind,
+                  "sample": f"{mp} pass(es) over one 4K picture's {p0.n_me} motionEstimate calls, {mdt:.1f} s"}
+        # what the searches of that picture evaluate, priced at SURVEY.md 8(d)'s algorithmic lane-ops (oracle work model)
+        _, me_model = pyoracle.load_oracle().me_batch_ops(pl, tabs, p0.me_host, nthreads=cores)
+        me_model["calls"] = p0.n_me
+        if not args.no_hd:  # the 1080p legs released the 4K planes: put this picture's back
+            for pid, (buf, origin, stride) in host_planes.items():
+                ctx.plane_upload(pid, buf, stride, origin)
+        o_model = torch.empty(p0.n_me * 8, dtype=torch.uint8, device=dev)
+
+        def run_model(s):
+            ctx.me_batch_device(p0.d_me.data_ptr(), p0.n_me, o_model.data_ptr())
+            return p0
+        _, ev_model, _ = leg(run_model, 20, 0)
+        me_model["kernel_ms"] = ev_model / 20
 
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE)
-            t = json.load(open(tpath))["fullsearch2_kernel"]
-            traffic = (t["fetch_kib_corrected"] + t["write_kib"]) * 1024
-        total_units = units * world
-        k_ms = ev_fs / args.steps
-        px_ops = positions / args.steps * 4096  # 64x64 pixel-ops per position per CTU with full 8x8 reuse
-        alg_bytes = n_ctu * (4096 + (64 + 2 * RANGE) ** 2 + 85 * 8 + 28)
+        def profile_json(name):
+            path = os.path.join(ROOT, "profiles", name)
+            return json.load(open(path)) if os.path.exists(path) else {}
+
+        traffic = profile_json("r02_traffic.json")
+        K = args.steps
+        cands = sum(p.n_satd for p in acc_sp)
+        ops = sum(p.satd_ops for p in acc_sp)
+        k_ms = ev_sp / K
+        # algorithmic bytes of a launch: the planes it reads once (source + references) + 20 B per request + 4 B per result
+        alg_bytes = sum(p.plane_bytes + 24 * p.n_satd for p in acc_sp) / K
+        t_cost = traffic.get("cost_kernel_4k")
         line = {
-            "metric": "SATD ME candidates/sec + ME-stage frames/sec, bit-exact: value = integer-pel search candidates/s (SAD, configs[1]); SATD candidates/s and ME-stage frames/s in satd_candidates / me_stage",
-            "value": total_units / dt_fs, "unit": "candidates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_fs / args.steps * 1e3,
+            "metric": "SATD ME candidates/sec + ME-stage frames/sec @1080p/4K, 1-8 GPU, bit-exact",
+            "value": cands * world / dt_sp, "unit": "SATD candidates/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": dt_sp / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: 1080p, 64x64 CTUs, +-64 integer full search, 85 square PUs per CTU, 1 reference",
-                       "ctus_per_step": n_ctu, "gop_sharding": f"{world} segment(s) of {nfr} pictures"},
-            "me_stage": {"workload": "configs[2]: motionEstimate replay, HEX, subme 2, merange 57, 3 references, "
-                                     "square PUs 64..8",
-                         "frames_per_s": args.steps * world / dt_me, "me_calls_per_s": me_calls * world / dt_me,
-                         "ms_per_frame": dt_me / args.steps * 1e3, "kernel_ms_per_frame": ev_me / args.steps},
-            "satd_candidates": {"workload": "sub-pel stage of the same pictures: square PUs 64..8 x 3 references x 16 half-/"
-                                            "quarter-pel candidates, 8-tap interpolation + SATD (x265_hip_cost_batch)",
-                                "candidates_per_s": sp_cands * world / dt_sp, "ms_per_frame": dt_sp / args.steps * 1e3,
-                                "roofline": {"bound": "valu", "achieved": sp_lane_ops / (ev_sp * 1e-3) / 1e12,
-                                             "peak": LANE_PEAK / 1e12, "unit": "Tlane-op/s",
-                                             "frac": sp_lane_ops / (ev_sp * 1e-3) / LANE_PEAK, "kernel": "cost_kernel"}},
-            "roofline": {"bound": "valu", "achieved": px_ops / (k_ms * 1e-3) / 1e12, "peak": PX_PEAK / 1e12,
-                         "unit": "Tpixel-op/s", "frac": px_ops / (k_ms * 1e-3) / PX_PEAK,
-                         "kernel": "fullsearch2_kernel", "kernel_ms": k_ms, "traffic": traffic,
-                         "algorithmic_bytes": alg_bytes,
+            "config": {"workload": "configs[3]/[4]: 3840x2160, closed GOP segments sharded over the ranks, sub-pel stage of one P picture "
+                                   "per step: square PUs 64..8 x up to 3 references of the segment x 16 half-/quarter-pel candidates, "
+                                   "8-tap interpolation + SATD (x265_hip_cost_batch)",
+                       "sequence_frames": n_frames, "gop": args.gop, "segments_per_rank": args.segments_per_rank,
+                       "p_pictures_per_rank": len(pics), "candidates_per_step": cands / K},
+            "roofline": {"bound": "valu", "kernel": "cost_kernel", "kernel_ms": k_ms,
+                         "achieved": ops / K / (k_ms * 1e-3) / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-op/s",
+                         "frac": ops / K / (k_ms * 1e-3) / VALU_PEAK,
+                         "algorithmic_lane_ops": ops / K,
+                         "issue_ceiling": {"peak": VALU_ISSUE_4CYC / 1e12, "frac": ops / K / (k_ms * 1e-3) / VALU_ISSUE_4CYC,
+                                           "note": "measured issue rate of the 4-cycle integer forms the kernel is made of"},
+                         "algorithmic_bytes": alg_bytes, "traffic": t_cost,
                          "hbm": {"achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
                                  "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK}},
+            "me_stage": {"workload": "motionEstimate replay of the same pictures: HEX, subme 2, merange 57, square PUs 64..8 x the "
+                                     "segment's references (x265_hip_me_batch)",
+                         "frames_per_s": K * world / dt_me, "me_calls_per_s": sum(p.n_me for p in acc_me) * world / dt_me,
+                         "ms_per_frame": dt_me / K * 1e3, "kernel_ms_per_frame": ev_me / K},
+            "fullsearch": {"workload": "configs[1] at 4K: +-64 integer SAD search of every CTU (85 square PUs) against the nearest reference",
+                           "candidates_per_s": sum(p.fs_units for p in acc_fs) * world / dt_fs, "ms_per_frame": dt_fs / K * 1e3,
+                           "roofline": {"bound": "valu", "kernel": "fullsearch2_kernel", "kernel_ms": ev_fs / K,
+                                        "achieved": sum(p.fs_pos for p in acc_fs) * 4096 / (ev_fs * 1e-3) / 1e12, "peak": SAD_PX_PEAK / 1e12,
+                                        "unit": "Tpixel-op/s", "frac": sum(p.fs_pos for p in acc_fs) * 4096 / (ev_fs * 1e-3) / SAD_PX_PEAK,
+                                        "traffic": traffic.get("fullsearch2_kernel_4k")}},
         }
-        if uhd:
-            line["uhd"] = uhd
+        if me_model:
+            ms = me_model["kernel_ms"]  # that picture's list timed on its own
+            line["me_stage"]["roofline"] = {
+                "bound": "valu", "kernel": "me_kernel", "kernel_ms": ms, "algorithmic_lane_ops": me_model["lane_ops"],
+                "achieved": me_model["lane_ops"] / (ms * 1e-3) / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-op/s",
+                "frac": me_model["lane_ops"] / (ms * 1e-3) / VALU_PEAK,
+                "issue_ceiling": {"peak": VALU_ISSUE_4CYC / 1e12, "frac": me_model["lane_ops"] / (ms * 1e-3) / VALU_ISSUE_4CYC},
+                "model": {k: me_model[k] for k in ("sad_ops", "satd_ops", "interp_ops", "sad_candidates", "subpel_candidates", "calls")},
+                "traffic": traffic.get("me_kernel_4k")}
+        if hd:
+            line["hd"] = hd
         if cpu:
             line["cpu_baseline"] = cpu
+            line["vs_cpu_baseline"] = line["value"] / cpu["value"]
             line["me_stage"]["cpu_baseline"] = cpu_me
         print(json.dumps(line))
     if world > 1:

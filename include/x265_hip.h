@@ -316,6 +316,32 @@ int x265_hip_me_batch(x265_hip_ctx *ctx, const x265_hip_me_job *jobs, int n, x26
 int x265_hip_me_batch_device(x265_hip_ctx *ctx, const void *d_jobs, int n, void *d_results);
 int x265_hip_cost_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs);
 
+/* One ring of the sub-pel refinement of MotionEstimate::motionEstimate (motion.cpp:1047-1119) per request: the costs
+ * subpelCompare(ref, centre + square1[i] * step, cmp) (motion.cpp:1126-1164; square1 at :71-73) for i = 1 .. 4 or 1 .. 8,
+ * step 2 (half-pel ring) or 1 (quarter-pel ring), and optionally the centre itself (the SATD re-measure of
+ * motion.cpp:1082-1086).  Same pixels and same sad / satd as nine x265_hip_cost_req, but the interpolation is shared:
+ * the candidates are a 3 x 3 grid, so three horizontal passes serve all nine (x265_amd/csrc/refine.hip).  No rate
+ * term is added.  costs[9 i + k] is candidate k of request i in square1's order (k = 0 the centre, 1 (0,-1), 2 (0,1),
+ * 3 (-1,0), 4 (1,0), 5 (-1,-1), 6 (-1,1), 7 (1,-1), 8 (1,1)); entries the pattern does not ask for are INT32_MAX. */
+#define X265_HIP_RING_QPEL   0x01 /* candidates at centre + square1[i]     */
+#define X265_HIP_RING_HPEL   0x02 /* candidates at centre + square1[i] * 2 */
+#define X265_HIP_RING_8      0x10 /* i = 1 .. 8 (otherwise 1 .. 4) */
+#define X265_HIP_RING_CENTRE 0x20 /* also the centre */
+#define X265_HIP_RING_COSTS  9
+typedef struct x265_hip_refine_req
+{
+    int32_t fenc_plane;
+    int32_t ref_plane;
+    int16_t pu_x, pu_y;
+    uint8_t pu_w, pu_h; /* one of the 25 partitions */
+    uint8_t metric;     /* X265_HIP_SAD / X265_HIP_SATD */
+    uint8_t pattern;    /* X265_HIP_RING_QPEL or X265_HIP_RING_HPEL, | X265_HIP_RING_8, | X265_HIP_RING_CENTRE */
+    int16_t qmv_x, qmv_y; /* the centre, quarter-pel */
+} x265_hip_refine_req;
+
+int x265_hip_refine_batch(x265_hip_ctx *ctx, const x265_hip_refine_req *reqs, int n, int32_t *costs9);
+int x265_hip_refine_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs9);
+
 /* x265_hip_cost_batch_device for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same requests, same costs;
  * the kernel's batch counters live in a static 8 KiB device array of the library (one copy per GPU, held until the

@@ -179,6 +179,21 @@ class Checker:
         self._f("me_batch")(self._planes(planes), tabs, _ptr(jobs), C.c_int(len(jobs)), _ptr(out), C.c_int(nthreads))
         return out
 
+    def me_batch_ops(self, planes, costtabs, jobs, nthreads=1):
+        """me_batch plus the work model of the searches (oracle only): dict of algorithmic lane-ops and candidate counts"""
+        jobs = np.ascontiguousarray(jobs, dtype=ME_JOB)
+        out = np.zeros(len(jobs), ME_RESULT)
+        tabs = (C.c_void_p * 256)()
+        keep = []
+        for qp, t in costtabs.items():
+            t = np.ascontiguousarray(t, np.uint16)
+            keep.append(t)
+            tabs[qp] = t.ctypes.data
+        ops = np.zeros(5, np.float64)
+        self._f("me_batch_ops")(self._planes(planes), tabs, _ptr(jobs), C.c_int(len(jobs)), _ptr(out), C.c_int(nthreads), _ptr(ops))
+        return out, {"sad_ops": ops[0], "satd_ops": ops[1], "interp_ops": ops[2], "sad_candidates": ops[3],
+                     "subpel_candidates": ops[4], "lane_ops": float(ops[:3].sum())}
+
     def cost_batch(self, planes, reqs, nthreads=1):
         reqs = np.ascontiguousarray(reqs, dtype=COST_REQ)
         out = np.zeros(len(reqs), np.int32)

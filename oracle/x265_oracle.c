@@ -357,10 +357,18 @@ static inline int mvcost_q(const me_ctx *c, int qx, int qy)
 
 static inline int16_t s16(int v) { return (int16_t)v; }
 
+/* Work model for the roofline of the search kernel (bench.py): the candidates a search actually evaluates, priced
+ * at SURVEY.md 8(d)'s algorithmic lane-ops: SAD 3 per pixel, SATD 111 per 4x4 tile, hpp / vpp 8 MAC + 3 per pixel,
+ * hps + vsp 8 (H + 7) / H + 8 MAC + 3 per pixel.  Per thread; summed by x265o_me_batch_ops. */
+static __thread double t_ops_sad, t_ops_satd, t_ops_interp;
+static __thread long t_n_sad, t_n_sub;
+
 /* cost of a full-pel position given in full-pel units: SAD + mvcost(mv << 2)
  * (ref: COST_MV, motion.cpp:179-185).  MV << 2 is an int16 operation (mv.h:63). */
 static inline int sad_at(const me_ctx *c, int mx, int my)
 {
+    t_ops_sad += 3.0 * c->w * c->h;
+    t_n_sad++;
     return sad_wh(c->w, c->h, c->fenc, 64, c->fref + mx + my * c->stride, c->stride);
 }
 
@@ -405,6 +413,15 @@ static int subpel_cost(const me_ctx *c, int qx, int qy, int use_satd)
     if (c->lowres[0])
         return lowres_qpel_cost(c, qx, qy, use_satd);
     int xf = qx & 3, yf = qy & 3;
+    {
+        const double px = (double)c->w * c->h;
+        if (use_satd)
+            t_ops_satd += px * (111.0 / 16);
+        else
+            t_ops_sad += 3.0 * px;
+        t_ops_interp += px * ((xf && yf) ? 8.0 * (c->h + 7) / c->h + 8 + 3 : (xf || yf) ? 11.0 : 0.0);
+        t_n_sub++;
+    }
     const uint8_t *p = c->fref + (qx >> 2) + (qy >> 2) * c->stride;
     uint8_t buf[64 * 64];
     const uint8_t *cmp = buf;
@@ -1437,11 +1454,14 @@ typedef struct
     const x265o_cost_req *reqs;
     int32_t *cres;
     int lo, hi;
+    double ops[5]; /* me_slice: this slice's work model (sad, satd, interpolation lane-ops; sad and sub-pel candidates) */
 } slice_arg;
 
 static void *me_slice(void *p)
 {
     slice_arg *a = (slice_arg *)p;
+    t_ops_sad = t_ops_satd = t_ops_interp = 0;
+    t_n_sad = t_n_sub = 0;
     for (int i = a->lo; i < a->hi; i++)
     {
         const x265o_me_job *j = &a->jobs[i];
@@ -1450,6 +1470,11 @@ static void *me_slice(void *p)
         a->mres[i].mvx = mv.x;
         a->mres[i].mvy = mv.y;
     }
+    a->ops[0] = t_ops_sad;
+    a->ops[1] = t_ops_satd;
+    a->ops[2] = t_ops_interp;
+    a->ops[3] = (double)t_n_sad;
+    a->ops[4] = (double)t_n_sub;
     return 0;
 }
 
@@ -1467,6 +1492,7 @@ static void *cost_slice(void *p)
 
 static void fan_out(void *(*fn)(void *), slice_arg *proto, int n, int nthreads)
 {
+    memset(proto->ops, 0, sizeof(proto->ops));
     if (nthreads <= 1 || n < 2 * nthreads)
     {
         proto->lo = 0;
@@ -1484,7 +1510,11 @@ static void fan_out(void *(*fn)(void *), slice_arg *proto, int n, int nthreads)
         pthread_create(&th[t], 0, fn, &args[t]);
     }
     for (int t = 0; t < nthreads; t++)
+    {
         pthread_join(th[t], 0);
+        for (int k = 0; k < 5; k++)
+            proto->ops[k] += args[t].ops[k];
+    }
     free(args);
     free(th);
 }
@@ -1499,6 +1529,21 @@ void x265o_me_batch(const x265o_plane *planes, const uint16_t *const *costtabs, 
     a.jobs = jobs;
     a.mres = out;
     fan_out(me_slice, &a, n, nthreads);
+}
+
+/* x265o_me_batch plus the work model of the searches: ops5 = { sad lane-ops, satd lane-ops, interpolation lane-ops,
+ * full-pel sad candidates, sub-pel (subpelCompare) candidates } summed over the list */
+void x265o_me_batch_ops(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_me_job *jobs, int n,
+                        x265o_me_result *out, int nthreads, double *ops5)
+{
+    slice_arg a;
+    memset(&a, 0, sizeof(a));
+    a.planes = planes;
+    a.tabs = costtabs;
+    a.jobs = jobs;
+    a.mres = out;
+    fan_out(me_slice, &a, n, nthreads);
+    memcpy(ops5, a.ops, sizeof(a.ops));
 }
 
 void x265o_cost_batch(const x265o_plane *planes, const x265o_cost_req *reqs, int n, int32_t *out, int nthreads)

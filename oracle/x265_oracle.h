@@ -116,6 +116,8 @@ int  x265o_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, i
 
 /* Batched front-ends.  costtabs[qp] points at 65536 entries (centre at +32768).
  * nthreads <= 1 runs inline. */
+void x265o_me_batch_ops(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_me_job *jobs, int n,
+                        x265o_me_result *out, int nthreads, double *ops5);
 void x265o_cost_batch(const x265o_plane *planes, const x265o_cost_req *reqs, int n, int32_t *out, int nthreads);
 void x265o_me_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_me_job *jobs, int n,
                     x265o_me_result *out, int nthreads);

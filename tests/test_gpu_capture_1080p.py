@@ -1,0 +1,64 @@
+"""BASELINE configs[0] at its stated resolution inside the driver-run suite: where oracle/_ref/enc_capture (the whole
+reference encoder built from its own sources with MotionEstimate::motionEstimate intercepted, `make -C oracle capture`)
+is present, it encodes 8 pictures of the synthetic 1920x1080 clip with --preset medium on this machine, and every call
+it made (real AMVP predictors, candidate vectors, search bounds, per-CU QPs, reconstructed references, the lookahead's
+Lowres planes) is replayed through x265_hip_me_batch and must give the reference's own (cost, mv)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "enc_capture")
+
+CALL = np.dtype([
+    ("fenc_plane", "<i4"), ("ref_plane", "<i4"), ("pu_x", "<i2"), ("pu_y", "<i2"), ("pu_w", "u1"), ("pu_h", "u1"),
+    ("method", "u1"), ("subme", "u1"), ("mvmin_x", "<i2"), ("mvmin_y", "<i2"), ("mvmax_x", "<i2"), ("mvmax_y", "<i2"),
+    ("qmvp_x", "<i2"), ("qmvp_y", "<i2"), ("merange", "<i2"), ("num_mvc", "u1"), ("qp", "u1"), ("mvc", "<i2", (24,)),
+    ("lowres", "u1"), ("pad", "u1", (3,)), ("cost", "<i4"), ("mvx", "<i2"), ("mvy", "<i2")])
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/enc_capture not built (needs the reference sources)")
+def test_reference_encoder_calls_at_1080p_replay_bit_exactly(tmp_path):
+    from x265_amd import abi, lib, synth
+    W, H, N = 1920, 1080, 8
+    seq = synth.Sequence(W, H, seed=0x265)
+    clip = tmp_path / "in.yuv"
+    with open(clip, "wb") as f:
+        for i in range(N):
+            f.write(seq.frame(i).tobytes())
+            f.write(bytes([128]) * (W * H // 2))
+    r = subprocess.run([EXE, str(clip), str(W), str(H), str(N), str(tmp_path), "120000", "40000", "0", "8", "1"],
+                       capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stderr[-2000:]
+    calls = np.fromfile(tmp_path / "calls.bin", dtype=CALL)
+    assert len(calls) > 20000 and calls["lowres"].sum() > 5000 and (calls["lowres"] == 0).sum() > 10000, r.stderr[-500:]
+    raw = np.memmap(tmp_path / "planes.bin", dtype=np.uint8, mode="r")
+    planes, pos = [], 0
+    while pos < len(raw):
+        pid, stride, origin, nbytes = (int(v) for v in raw[pos:pos + 16].view("<i4"))
+        assert pid == len(planes)
+        planes.append((np.array(raw[pos + 16:pos + 16 + nbytes]), origin, stride))
+        pos += 16 + nbytes
+    assert len(planes) + 4 <= abi.MAX_PLANES  # every plane of the capture resident at once
+    jobs = np.zeros(len(calls), abi.ME_JOB)
+    for k in ("fenc_plane", "ref_plane", "pu_x", "pu_y", "pu_w", "pu_h", "subme", "mvmin_x", "mvmin_y", "mvmax_x", "mvmax_y",
+              "qmvp_x", "qmvp_y", "merange", "num_mvc", "qp"):
+        jobs[k] = calls[k]
+    jobs["method"] = calls["method"] | (calls["lowres"] * abi.LOWRES_REF)
+    jobs["mvc"] = calls["mvc"]
+    ctx = lib.Context(0)
+    for q in np.unique(calls["qp"]):
+        ctx.set_qp(int(q))
+    for i, (buf, origin, stride) in enumerate(planes):
+        ctx.plane_upload(i, buf, stride, origin)
+    got = ctx.me_batch(jobs)
+    ctx.close()
+    bad = np.nonzero((got["cost"] != calls["cost"]) | (got["mvx"] != calls["mvx"]) | (got["mvy"] != calls["mvy"]))[0]
+    assert len(bad) == 0, (len(bad), len(calls), calls[bad[0]], got[bad[0]])
+    sizes = {int(s): int((calls["pu_w"][calls["lowres"] == 0] == s).sum()) for s in (8, 16, 32, 64)}
+    print(f"{len(calls)} calls of a 1080p medium-preset encode replayed ({int(calls['lowres'].sum())} lookahead; full-resolution "
+          f"block sizes {sizes}; QPs {np.unique(calls['qp']).tolist()}), 0 mismatches")

@@ -117,6 +117,89 @@ def test_cost_batch_large_random(hd, oracle):
     assert np.array_equal(got, want)
 
 
+@pytest.fixture(scope="module")
+def uhd():
+    """four 3840x2160 pictures (plane ids 0..3) with the cost tables of QP 28..39"""
+    from x265_amd import lib, synth
+    seq = synth.Sequence(3840, 2160, seed=0x265)
+    planes = [synth.Plane(seq.frame(i)) for i in range(4)]
+    ctx = lib.Context(0)
+    for i, p in enumerate(planes):
+        ctx.plane_upload(i, p.buf, p.stride, p.origin)
+    for q in range(28, 40):
+        ctx.set_qp(q)
+    yield seq, planes, ctx
+    ctx.close()
+
+
+def test_me_stage_whole_4k_frame_three_refs(uhd, oracle):
+    """BASELINE configs[3]: every motionEstimate call of a 4K picture against three references (516,060 calls),
+    each result equal to the oracle's"""
+    from x265_amd import abi, lib, synth
+    seq, planes, ctx = uhd
+    refs = [2, 1, 0]
+    jobs = synth.me_jobs(3840, 2160, 3, refs, [seq.global_motion(3, r) for r in refs], method=abi.HEX, subme=2, merange=57, seed=3)
+    assert len(jobs) == 3 * 172020
+    got = ctx.me_batch(jobs)
+    tabs = {q: lib.costtab_build(q) for q in range(28, 40)}
+    want = oracle.me_batch([p.as_tuple() for p in planes], tabs, jobs, nthreads=THREADS)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, (len(bad), jobs[bad[0]], got[bad[0]], want[bad[0]])
+
+
+def test_satd_candidates_whole_4k_frame_three_refs(uhd, oracle):
+    """the list bench.py times (configs[3]: square PUs x 3 references x 16 half-/quarter-pel candidates, 8.26 M
+    interpolation + SATD requests), every cost equal to the oracle's"""
+    from x265_amd import synth
+    seq, planes, ctx = uhd
+    refs = [2, 1, 0]
+    reqs = synth.subpel_requests(3840, 2160, 3, refs, [seq.global_motion(3, r) for r in refs])
+    assert len(reqs) == 3 * 16 * 172020
+    got = ctx.cost_batch(reqs)
+    want = oracle.cost_batch([p.as_tuple() for p in planes], reqs, nthreads=THREADS)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, (len(bad), reqs[bad[0]], got[bad[0]], want[bad[0]])
+
+
+def test_fullsearch_whole_4k_frame(uhd, oracle):
+    """all 2040 CTUs of a 4K picture: a sample of CTUs exactly against the oracle, every one of the 173,400 results by
+    the size-independent properties (cost == SAD at the returned vector + its rate, vector inside the window, winner
+    not worse than the window centre)"""
+    import sys
+    sys.path.insert(0, ".")
+    from bench import build_ctu_jobs
+    from x265_amd import abi, lib
+    seq, planes, ctx = uhd
+    jobs = build_ctu_jobs(seq, 3, 2, 3, 2, qp=31)
+    assert len(jobs) == 2040
+    res = ctx.fullsearch(jobs)
+    tab = lib.costtab_build(31)
+    pl = [p.as_tuple() for p in planes]
+    for k in (0, 59, 33 * 60, 2039, 17 * 60 + 31, 32 * 60 + 58):
+        j = jobs[k]
+        want = oracle.ctu_fullsearch(pl[3], pl[2], tab, int(j["ctu_x"]), int(j["ctu_y"]), (int(j["mvmin_x"]), int(j["mvmin_y"])),
+                                     (int(j["mvmax_x"]), int(j["mvmax_y"])), (int(j["qmvp_x"]), int(j["qmvp_y"])))
+        bad = np.nonzero(res[k] != want)[0]
+        assert len(bad) == 0, (k, bad[0], res[k][bad[0]], want[bad[0]])
+    pus = np.array([(bx * (64 >> l), by * (64 >> l), 64 >> l) for l in range(4) for by in range(1 << l) for bx in range(1 << l)])
+    reqs = np.zeros(2040 * 85, abi.COST_REQ)
+    reqs["fenc_plane"], reqs["ref_plane"] = 3, 2
+    reqs["pu_x"] = (jobs["ctu_x"][:, None] + pus[None, :, 0]).reshape(-1)
+    reqs["pu_y"] = (jobs["ctu_y"][:, None] + pus[None, :, 1]).reshape(-1)
+    reqs["pu_w"] = reqs["pu_h"] = np.tile(pus[:, 2], 2040)
+    reqs["qmv_x"], reqs["qmv_y"] = res["mvx"].reshape(-1), res["mvy"].reshape(-1)
+    sad = ctx.cost_batch(reqs).astype(np.int64)
+    mvpx, mvpy = np.repeat(jobs["qmvp_x"].astype(np.int64), 85), np.repeat(jobs["qmvp_y"].astype(np.int64), 85)
+    mvc = (tab[(reqs["qmv_x"] - mvpx + 32768) & 0xffff].astype(np.int64) + tab[(reqs["qmv_y"] - mvpy + 32768) & 0xffff]) & 0xffff
+    assert np.array_equal(sad + mvc, res["cost"].reshape(-1))
+    fx, fy = res["mvx"] >> 2, res["mvy"] >> 2
+    assert (fx >= jobs["mvmin_x"][:, None]).all() and (fx <= jobs["mvmax_x"][:, None]).all()
+    assert (fy >= jobs["mvmin_y"][:, None]).all() and (fy <= jobs["mvmax_y"][:, None]).all()
+    reqs["qmv_x"], reqs["qmv_y"] = mvpx, mvpy
+    centre = ctx.cost_batch(reqs).astype(np.int64) + (2 * int(tab[32768]) & 0xffff)
+    assert (res["cost"].reshape(-1) <= centre).all()
+
+
 def test_4k_sample(oracle):
     """3840x2160: coordinates beyond 2048 and the 4032-byte stride; sample of ME calls and CTUs vs the oracle"""
     from x265_amd import abi, lib, synth

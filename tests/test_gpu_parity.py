@@ -571,3 +571,95 @@ def test_device_resident_entry_points(gpu_ctx, oracle, small_seq, costtabs):
     gpu_ctx.plane_release(5)
     for p in held:
         hip.hipFree(p)
+
+
+def _random_refine_reqs(rng, n, W, H, parts, planes=(1, (0, 2))):
+    from x265_amd import abi
+    reqs = np.zeros(n, abi.REFINE_REQ)
+    for r in reqs:
+        w, h = parts[int(rng.integers(0, 25))]
+        r["fenc_plane"], r["ref_plane"] = planes[0], int(rng.choice(planes[1]))
+        r["pu_x"], r["pu_y"], r["pu_w"], r["pu_h"] = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1)), w, h
+        r["metric"] = int(rng.integers(0, 2))
+        r["pattern"] = int(rng.choice([abi.RING_QPEL, abi.RING_HPEL])) | (abi.RING_8 if rng.integers(2) else 0) | \
+            (abi.RING_CENTRE if rng.integers(2) else 0)
+        r["qmv_x"] = int(rng.integers(-90, 90)) if rng.integers(4) else 4 * int(rng.integers(-20, 20))
+        r["qmv_y"] = int(rng.integers(-90, 90)) if rng.integers(4) else 4 * int(rng.integers(-20, 20))
+    return reqs
+
+
+def _check_refine(ctx, oracle, planes, reqs):
+    from x265_amd import abi
+    got = ctx.refine_batch(reqs)
+    creqs, used = abi.refine_as_cost_reqs(reqs)
+    want = oracle.cost_batch([p.as_tuple() for p in planes], creqs.reshape(-1), nthreads=8).reshape(-1, abi.RING_COSTS)
+    want = np.where(used, want, 0x7fffffff)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) == 0, (len(bad), reqs[bad[0]], got[bad[0]], want[bad[0]])
+
+
+def test_refine_rings_all_partitions_patterns_fractions(gpu_ctx, small_seq, oracle):
+    """x265_hip_refine_batch: the shared-interpolation ring kernel equals nine independent subpelCompare + sad / satd
+    for every partition, both rings, 4 / 8 directions, with and without the centre, at any centre fraction"""
+    from x265_amd import abi
+    rng = np.random.default_rng(2024)
+    _check_refine(gpu_ctx, oracle, small_seq, _random_refine_reqs(rng, 6000, 416, 240, abi.PARTS))
+
+
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 63, 257])
+def test_refine_ragged_counts(gpu_ctx, small_seq, oracle, n):
+    from x265_amd import abi
+    rng = np.random.default_rng(n)
+    _check_refine(gpu_ctx, oracle, small_seq, _random_refine_reqs(rng, n, 416, 240, abi.PARTS))
+
+
+@pytest.mark.parametrize("size", [8, 16, 32, 64])
+def test_refine_lists_of_one_size(gpu_ctx, small_seq, oracle, size):
+    """lists of a single PU size (the cell grouping packs four 8x8 PUs into a pass, a 64x64 PU is sixteen cells),
+    every fraction of the centre, SATD, half-pel ring with centre then quarter-pel ring"""
+    from x265_amd import abi
+    reqs = []
+    for pat in (abi.RING_HPEL | abi.RING_8 | abi.RING_CENTRE, abi.RING_QPEL | abi.RING_8, abi.RING_HPEL | abi.RING_CENTRE, abi.RING_QPEL):
+        for y in range(0, 240 - size + 1, size):
+            for x in range(0, 416 - size + 1, size):
+                r = np.zeros((), abi.REFINE_REQ)
+                r["fenc_plane"], r["ref_plane"], r["pu_x"], r["pu_y"], r["pu_w"], r["pu_h"] = 1, 0, x, y, size, size
+                r["metric"], r["pattern"] = abi.SATD, pat
+                r["qmv_x"], r["qmv_y"] = (x // size) % 9 - 4, (y // size) % 7 - 3
+                reqs.append(r)
+    _check_refine(gpu_ctx, oracle, small_seq, np.array(reqs, abi.REFINE_REQ))
+
+
+def test_me_jobs_that_could_step_outside_a_tight_plane_are_refused(oracle):
+    """the host-array entry point validates what a search can reach, per method and sub-pel level: the reference's
+    hexagon search steps up to 3 samples outside [mvmin, mvmax] (2 + the square refine), sub-pel refinement up to 2
+    more, and the 8-tap filters 4 below.  A plane whose bottom margin is one row short of that must be refused, one
+    that has exactly the rows must be accepted and searched like the oracle does."""
+    from x265_amd import abi, lib, synth
+    seq = synth.Sequence(128, 128, seed=5, n_patches=1)
+    full = synth.Plane(seq.frame(0))
+    ctx = lib.Context(0)
+    ctx.set_qp(30)
+    job = np.zeros(1, abi.ME_JOB)
+    job["fenc_plane"], job["ref_plane"] = 0, 1
+    job["pu_x"], job["pu_y"], job["pu_w"], job["pu_h"] = 32, 64, 16, 16
+    job["method"], job["subme"], job["merange"], job["qp"] = abi.HEX, 7, 16, 30
+    job["mvmin_x"], job["mvmin_y"], job["mvmax_x"], job["mvmax_y"] = -8, -8, 8, 40
+    # lowest row a HEX / subme 7 search can read: block bottom (64 + 16 - 1) + mvmax 40 + 3 (hexagon + square) +
+    # ceil((2 * 2 + 2) / 4) = 2 (sub-pel) + 4 (filter) = row 128
+    need_rows = synth.MARGIN_Y + 64 + 16 + 40 + 3 + 2 + 4
+    ctx.plane_upload(0, full.buf, full.stride, full.origin)
+    for rows, ok in ((need_rows, True), (need_rows - 1, False)):
+        ctx.plane_upload(1, full.buf[:rows * full.stride], full.stride, full.origin)
+        if ok:
+            got = ctx.me_batch(job)
+            want = oracle.me_batch([full.as_tuple(), full.as_tuple()], {30: lib.costtab_build(30)}, job)
+            assert np.array_equal(got, want)
+        else:
+            with pytest.raises(lib.X265HipError, match="lie outside"):
+                ctx.me_batch(job)
+    # a diamond search with integer-only refinement reaches less: 1 + 1 + 4
+    job["method"], job["subme"] = abi.DIA, 0
+    ctx.plane_upload(1, full.buf[:(need_rows - 3) * full.stride], full.stride, full.origin)
+    ctx.me_batch(job)
+    ctx.close()

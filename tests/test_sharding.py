@@ -58,3 +58,16 @@ def test_two_rank_gloo_sharding():
         assert sorted(gathered[0] + gathered[1]) == list(range(100))
         assert not set(gathered[0]) & set(gathered[1])
         assert t == 2.0  # max over ranks of (1.0, 2.0)
+
+
+def test_runner_plan_is_the_same_sharded_and_unsharded():
+    """the sequence runner's plan (which picture is searched against which references, in which plane slots) is a
+    function of the segment alone, so it does not depend on the number of ranks"""
+    from x265_amd import shard
+    def plan(rank, world):
+        return [(seg, cur, refs) for seg in shard.segments_for_rank(40, 8, rank, world) for cur, refs in shard.reference_pairs(seg, 3)]
+    whole = plan(0, 1)
+    for world in (2, 4, 8):
+        parts = [p for r in range(world) for p in plan(r, world)]
+        assert sorted(parts) == sorted(whole)
+    assert all(seg[0] <= min(refs) and max(refs) < cur < seg[1] for seg, cur, refs in whole)

@@ -2,6 +2,7 @@
 import numpy as np
 
 MAX_MVC = 12
+MAX_PLANES = 512
 NUM_PARTS = 25
 
 # LumaPartitions order, source/common/primitives.h:38-46 of the reference (index order is ABI)
@@ -54,3 +55,32 @@ PRED_REQ = np.dtype([
     ("qmv0_x", "<i2"), ("qmv0_y", "<i2"), ("qmv1_x", "<i2"), ("qmv1_y", "<i2"),
 ])
 assert PRED_REQ.itemsize == 28
+
+# x265_hip_refine_req: one sub-pel ring around `qmv` (costs of centre + square1[i] * step); nine costs per request
+RING_QPEL, RING_HPEL, RING_8, RING_CENTRE, RING_COSTS = 0x01, 0x02, 0x10, 0x20, 9
+SQUARE1 = [(0, 0), (0, -1), (0, 1), (-1, 0), (1, 0), (-1, -1), (-1, 1), (1, -1), (1, 1)]  # motion.cpp:71-73
+REFINE_REQ = np.dtype([
+    ("fenc_plane", "<i4"), ("ref_plane", "<i4"),
+    ("pu_x", "<i2"), ("pu_y", "<i2"),
+    ("pu_w", "u1"), ("pu_h", "u1"), ("metric", "u1"), ("pattern", "u1"),
+    ("qmv_x", "<i2"), ("qmv_y", "<i2"),
+])
+assert REFINE_REQ.itemsize == 20
+
+
+def refine_as_cost_reqs(reqs):
+    """the candidates of a list of refine requests as plain cost requests (what a ring is defined by): a
+    (len(reqs), 9) array of cost requests and the mask of the entries each request's pattern asks for"""
+    reqs = np.asarray(reqs, REFINE_REQ)
+    n = len(reqs)
+    out = np.zeros((n, RING_COSTS), COST_REQ)
+    step = np.where(reqs["pattern"] & RING_HPEL, 2, 1).astype(np.int64)
+    for f in ("fenc_plane", "ref_plane", "pu_x", "pu_y", "pu_w", "pu_h", "metric"):
+        out[f] = reqs[f][:, None]
+    sq = np.array(SQUARE1, np.int64)
+    out["qmv_x"] = (reqs["qmv_x"].astype(np.int64)[:, None] + sq[None, :, 0] * step[:, None]).astype(np.int16)
+    out["qmv_y"] = (reqs["qmv_y"].astype(np.int64)[:, None] + sq[None, :, 1] * step[:, None]).astype(np.int16)
+    k = np.arange(RING_COSTS)[None, :]
+    ndirs = np.where(reqs["pattern"] & RING_8, 8, 4)[:, None]
+    used = np.where(k == 0, (reqs["pattern"] & RING_CENTRE)[:, None] != 0, k <= ndirs)
+    return out, used

@@ -746,6 +746,57 @@ int x265_hip_cost_batch(x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n, i
     return X265_HIP_OK;
 }
 
+int x265_hip_refine_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void *d_costs9)
+{
+    if (!c || n < 0 || (n && (!d_reqs || !d_costs9)))
+        return fail(X265_HIP_EINVAL, "refine_batch_device: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = push_tabs(c);
+    if (r)
+        return r;
+    LAUNCH(launch_refine(c->dev_tabs, (const x265_hip_refine_req *)d_reqs, n, (int32_t *)d_costs9, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    return X265_HIP_OK;
+}
+
+int x265_hip_refine_batch(x265_hip_ctx *c, const x265_hip_refine_req *reqs, int n, int32_t *costs9)
+{
+    if (!c || n < 0 || (n && (!reqs || !costs9)))
+        return fail(X265_HIP_EINVAL, "refine_batch: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++)
+    {
+        const x265_hip_refine_req &q = reqs[i];
+        int r = check_block(c, q.fenc_plane, q.ref_plane, q.pu_w, q.pu_h, "refine_req", i);
+        if (r)
+            return r;
+        const int ring = q.pattern & (X265_HIP_RING_QPEL | X265_HIP_RING_HPEL);
+        if (q.metric > X265_HIP_SATD || (ring != X265_HIP_RING_QPEL && ring != X265_HIP_RING_HPEL) ||
+            (q.pattern & ~(X265_HIP_RING_QPEL | X265_HIP_RING_HPEL | X265_HIP_RING_8 | X265_HIP_RING_CENTRE)))
+            return fail(X265_HIP_EINVAL, "refine_req[%d]: unknown metric %d / pattern 0x%x", i, q.metric, q.pattern);
+        // the kernel stages rows (cy - step) >> 2 - 3 .. + h + 5 and, per horizontal position, columns ix - 3 .. ix + w + 4
+        const int step = ring == X265_HIP_RING_HPEL ? 2 : 1;
+        const long x0 = q.pu_x + ((q.qmv_x - step) >> 2), x1 = q.pu_x + ((q.qmv_x + step) >> 2) + q.pu_w;
+        const long y0 = q.pu_y + ((q.qmv_y - step) >> 2), y1 = y0 + q.pu_h + 2;
+        if ((r = check_inside(c, q.fenc_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, "refine_req", i)) ||
+            (r = check_reach(c, q.ref_plane, x0, y0, x1, y1, "refine_req", i)))
+            return r;
+    }
+    const size_t ob = (size_t)n * X265_HIP_RING_COSTS * sizeof(int32_t);
+    int r;
+    if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))) || (r = ensure(c, c->out, ob)))
+        return r;
+    HIP_TRY(hipMemcpyAsync(c->in.d, reqs, (size_t)n * sizeof(*reqs), hipMemcpyHostToDevice, c->stream));
+    LAUNCH(launch_refine(c->dev_tabs, (const x265_hip_refine_req *)c->in.d, n, (int32_t *)c->out.d, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(costs9, c->out.h, ob);
+    return X265_HIP_OK;
+}
+
 int x265_hip_dist_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void *d_costs)
 {
     if (!c || n < 0 || (n && (!d_reqs || !d_costs)))

@@ -76,6 +76,8 @@ void launch_dist(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n,
                  hipStream_t st);
 void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out, uint32_t *counters, int parity,
                        hipStream_t st);
+void launch_refine(const DeviceTables *tabs, const x265_hip_refine_req *reqs, int n, int32_t *out, uint32_t *counters, int parity,
+                   hipStream_t st);
 void launch_prim_cmp(const PrimCmpArgs &a, int32_t *out, hipStream_t st);
 void launch_prim_filter(const PrimFilterArgs &a, hipStream_t st);
 void launch_fullsearch2(const DeviceTables *tabs, const x265_hip_ctu_job *jobs, int n, x265_hip_me_result *out,

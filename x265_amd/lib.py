@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from .abi import BIDIR_REQ, COST_REQ, ME_JOB, ME_RESULT, NUM_PARTS, PRED_REQ
+from .abi import BIDIR_REQ, COST_REQ, ME_JOB, ME_RESULT, NUM_PARTS, PRED_REQ, REFINE_REQ, RING_COSTS
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libx265_hip.so")
@@ -35,7 +35,7 @@ EXPORTS = [
     "x265_hip_plane_extend_border", "x265_hip_plane_weight",
     "x265_hip_bidir_cost_batch", "x265_hip_bidir_cost_batch_device",
     "x265_hip_dist_batch", "x265_hip_dist_batch_device", "x265_hip_predict_batch", "x265_hip_predict_batch_device",
-    "x265_hip_cost_batch_device_noalloc",
+    "x265_hip_cost_batch_device_noalloc", "x265_hip_refine_batch", "x265_hip_refine_batch_device",
 ]
 
 
@@ -193,6 +193,15 @@ class Context:
         out = np.zeros(len(reqs), np.int32)
         _check(load().x265_hip_cost_batch(self._h, _p(reqs), C.c_int(len(reqs)), _p(out)))
         return out
+
+    def refine_batch(self, reqs):
+        reqs = np.ascontiguousarray(reqs, REFINE_REQ)
+        out = np.zeros((len(reqs), RING_COSTS), np.int32)
+        _check(load().x265_hip_refine_batch(self._h, _p(reqs), C.c_int(len(reqs)), _p(out)))
+        return out
+
+    def refine_batch_device(self, d_reqs, n, d_costs9):
+        _check(load().x265_hip_refine_batch_device(self._h, C.c_void_p(d_reqs), C.c_int(n), C.c_void_p(d_costs9)))
 
     def dist_batch(self, reqs):
         reqs = np.ascontiguousarray(reqs, COST_REQ)

@@ -117,6 +117,11 @@ class Plane:
     def nbytes(self):
         return self.buf.size
 
+    @staticmethod
+    def nbytes_for(w, h):
+        """size of the padded plane of a w x h picture"""
+        return (-(-w // CTU) * CTU + 2 * MARGIN_X) * (-(-h // CTU) * CTU + 2 * MARGIN_Y)
+
     def as_tuple(self):
         return (self.buf, self.origin, self.stride)
 
@@ -260,3 +265,24 @@ def lookahead_jobs(lw, ll, fenc_plane, ref_plane0, motion, method=1, subme=1, me
         j["mvc"][:, 2 * c] = 4 * dx + ((hsh >> np.uint64(24 + 8 * c)) % np.uint64(13)).astype(np.int64) - 6
         j["mvc"][:, 2 * c + 1] = 4 * dy + ((hsh >> np.uint64(28 + 8 * c)) % np.uint64(13)).astype(np.int64) - 6
     return j
+
+
+def refine_requests(w, h, cur, refs, motions, metric=SATD):
+    """The sub-pel stage of subpel_requests() as ring requests (x265_hip_refine_batch): per square PU and reference
+    the half-pel ring of 8 and the quarter-pel ring of 8 around the integer vector `motions[i]`: the same 16
+    candidates per (PU, reference), reference-major, then ring, then PU."""
+    from .abi import REFINE_REQ, RING_8, RING_HPEL, RING_QPEL
+    pus = square_pus(w, h)
+    n = len(pus)
+    out = np.zeros(n * len(refs) * 2, REFINE_REQ)
+    k = 0
+    for rp, (dx, dy) in zip(refs, motions):
+        for ring in (RING_HPEL, RING_QPEL):
+            r = out[k:k + n]
+            k += n
+            r["fenc_plane"], r["ref_plane"] = cur, rp
+            r["pu_x"], r["pu_y"] = pus[:, 0], pus[:, 1]
+            r["pu_w"] = r["pu_h"] = pus[:, 2]
+            r["metric"], r["pattern"] = metric, ring | RING_8
+            r["qmv_x"], r["qmv_y"] = 4 * dx, 4 * dy
+    return out
