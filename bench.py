@@ -72,6 +72,10 @@ class Picture:
         rq = runner.satd_requests(cur, refs)
         self.n_satd, self.satd_ops = len(rq), synth.satd_lane_ops(rq)
         self.d_satd = torch.from_numpy(rq.view(np.uint8).copy()).to(dev)
+        rings = runner.ring_requests(cur, refs)  # one list per PU size
+        assert 8 * sum(len(r) for r in rings) == len(rq)
+        self.n_ring = sum(len(r) for r in rings)
+        self.rings = [(torch.from_numpy(r.view(np.uint8).copy()).to(dev), len(r)) for r in rings]
         self.me_host = runner.me_jobs(cur, refs)
         self.n_me = len(self.me_host)
         self.d_me = torch.from_numpy(self.me_host.view(np.uint8).copy()).to(dev)
@@ -171,12 +175,21 @@ def main():
     def three_legs(pics, steps, warmup):
         n = len(pics)
         o_satd = torch.empty(max(p.n_satd for p in pics), dtype=torch.int32, device=dev)
+        o_ring = torch.empty(max(p.n_ring for p in pics) * abi.RING_COSTS, dtype=torch.int32, device=dev)
         o_me = torch.empty(max(p.n_me for p in pics) * 8, dtype=torch.uint8, device=dev)
         o_fs = torch.empty(max(p.n_ctu for p in pics) * lib.PUS_PER_CTU * 8, dtype=torch.uint8, device=dev)
 
         def run_satd(s):
             p = pics[s % n]
             ctx.cost_batch_device(p.d_satd.data_ptr(), p.n_satd, o_satd.data_ptr())
+            return p
+
+        def run_ring(s):
+            p = pics[s % n]
+            off = 0
+            for d, cnt in p.rings:  # four launches on the context's stream, one per PU size
+                ctx.refine_batch_device(d.data_ptr(), cnt, o_ring.data_ptr() + 4 * abi.RING_COSTS * off)
+                off += cnt
             return p
 
         def run_me(s):
@@ -189,13 +202,13 @@ def main():
             ctx.fullsearch_device(p.d_fs.data_ptr(), p.n_ctu, o_fs.data_ptr())
             return p
 
-        return leg(run_satd, steps, warmup), leg(run_me, steps, warmup), leg(run_fs, steps, warmup)
+        return leg(run_ring, steps, warmup), leg(run_satd, steps, warmup), leg(run_me, steps, warmup), leg(run_fs, steps, warmup)
 
     # ---- configs[3] / configs[4]: 4K, GOP-sharded ----------------------------------------------------------------
     UW, UH = 3840, 2160
     seq = synth.Sequence(UW, UH, seed=0x265)
     pics, runners, n_frames = load_pictures(seq, args.gop, args.segments_per_rank)
-    (dt_sp, ev_sp, acc_sp), (dt_me, ev_me, acc_me), (dt_fs, ev_fs, acc_fs) = three_legs(pics, args.steps, args.warmup)
+    (dt_sp, ev_sp, acc_sp), (dt_c1, ev_c1, acc_c1), (dt_me, ev_me, acc_me), (dt_fs, ev_fs, acc_fs) = three_legs(pics, args.steps, args.warmup)
 
     hd = None
     if not args.no_hd:
@@ -203,10 +216,11 @@ def main():
         for r in runners:
             r.release()
         hpics, hrunners, _ = load_pictures(hseq, 4, 1)
-        (_, h_sp, a_sp), (_, h_me, a_me), (_, h_fs, a_fs) = three_legs(hpics, args.steps, 0)
+        (_, h_sp, a_sp), (_, h_c1, a_c1), (_, h_me, a_me), (_, h_fs, a_fs) = three_legs(hpics, args.steps, 0)
         hd = {"workload": "the same three legs on 1920x1080 pictures (configs[1], configs[2]): one closed segment of 4 pictures per "
                           "GPU, kernel time (HIP events), per GPU",
               "satd_candidates_per_s": sum(p.n_satd for p in a_sp) / h_sp * 1e3,
+              "satd_candidates_per_s_single_requests": sum(p.n_satd for p in a_c1) / h_c1 * 1e3,
               "satd_frac_of_valu_peak": sum(p.satd_ops for p in a_sp) / (h_sp * 1e-3) / VALU_PEAK,
               "me_frames_per_s": len(a_me) / h_me * 1e3, "me_calls_per_s": sum(p.n_me for p in a_me) / h_me * 1e3,
               "fullsearch_candidates_per_s": sum(p.fs_units for p in a_fs) / h_fs * 1e3,
@@ -271,9 +285,9 @@ def main():
         cands = sum(p.n_satd for p in acc_sp)
         ops = sum(p.satd_ops for p in acc_sp)
         k_ms = ev_sp / K
-        # algorithmic bytes of a launch: the planes it reads once (source + references) + 20 B per request + 4 B per result
-        alg_bytes = sum(p.plane_bytes + 24 * p.n_satd for p in acc_sp) / K
-        t_cost = traffic.get("cost_kernel_4k")
+        # algorithmic bytes of a launch: the planes it reads once (source + references) + 20 B per ring request + 4 B per candidate cost
+        alg_bytes = sum(p.plane_bytes + 20 * p.n_ring + 36 * p.n_ring for p in acc_sp) / K
+        t_cost = traffic.get("refine_kernel_4k")
         line = {
             "metric": "SATD ME candidates/sec + ME-stage frames/sec @1080p/4K, 1-8 GPU, bit-exact",
             "value": cands * world / dt_sp, "unit": "SATD candidates/s",
@@ -283,10 +297,11 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[3]/[4]: 3840x2160, closed GOP segments sharded over the ranks, sub-pel stage of one P picture "
                                    "per step: square PUs 64..8 x up to 3 references of the segment x 16 half-/quarter-pel candidates, "
-                                   "8-tap interpolation + SATD (x265_hip_cost_batch)",
+                                   "8-tap interpolation + SATD, asked for as rings of 8 around the integer vector, one launch per PU size "
+                                   "(x265_hip_refine_batch, four launches per step)",
                        "sequence_frames": n_frames, "gop": args.gop, "segments_per_rank": args.segments_per_rank,
                        "p_pictures_per_rank": len(pics), "candidates_per_step": cands / K},
-            "roofline": {"bound": "valu", "kernel": "cost_kernel", "kernel_ms": k_ms,
+            "roofline": {"bound": "valu", "kernel": "refine_kernel", "kernel_ms": k_ms, "launches_per_step": 4,
                          "achieved": ops / K / (k_ms * 1e-3) / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-op/s",
                          "frac": ops / K / (k_ms * 1e-3) / VALU_PEAK,
                          "algorithmic_lane_ops": ops / K,
@@ -295,6 +310,12 @@ def main():
                          "algorithmic_bytes": alg_bytes, "traffic": t_cost,
                          "hbm": {"achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
                                  "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK}},
+            "satd_single_requests": {"workload": "the same candidates one request each (x265_hip_cost_batch: nothing shared between candidates)",
+                                     "candidates_per_s": sum(p.n_satd for p in acc_c1) * world / dt_c1, "ms_per_frame": dt_c1 / K * 1e3,
+                                     "roofline": {"bound": "valu", "kernel": "cost_kernel", "kernel_ms": ev_c1 / K,
+                                                  "achieved": sum(p.satd_ops for p in acc_c1) / (ev_c1 * 1e-3) / 1e12, "peak": VALU_PEAK / 1e12,
+                                                  "unit": "Tlane-op/s", "frac": sum(p.satd_ops for p in acc_c1) / (ev_c1 * 1e-3) / VALU_PEAK,
+                                                  "traffic": traffic.get("cost_kernel_4k")}},
             "me_stage": {"workload": "motionEstimate replay of the same pictures: HEX, subme 2, merange 57, square PUs 64..8 x the "
                                      "segment's references (x265_hip_me_batch)",
                          "frames_per_s": K * world / dt_me, "me_calls_per_s": sum(p.n_me for p in acc_me) * world / dt_me,

@@ -94,17 +94,17 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     src = os.path.join(ROOT, "x265_amd", "csrc")
     allowed = {"me_kernel": 48}
     seen = set()
-    for name in ("me_kernel.hip", "fullsearch.hip"):
+    for name in ("me_kernel.hip", "fullsearch.hip", "refine.hip"):
         out = tmp_path / (name + ".s")
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out),
                                os.path.join(src, name)], stderr=subprocess.DEVNULL)
         text = out.read_text()
         for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s*(\d+)", text):
-            kernel = next((k for k in ("me_kernel", "cost_kernel", "dist_kernel", "predict_kernel", "fullsearch2_kernel") if k in m.group(1)), None)
+            kernel = next((k for k in ("me_kernel", "cost_kernel", "dist_kernel", "predict_kernel", "fullsearch2_kernel", "refine_kernel") if k in m.group(1)), None)
             if kernel:
                 seen.add(kernel)
                 assert int(m.group(2)) <= allowed.get(kernel, 0), (kernel, m.group(2))
-    assert seen == {"me_kernel", "cost_kernel", "dist_kernel", "predict_kernel", "fullsearch2_kernel"}
+    assert seen == {"me_kernel", "cost_kernel", "dist_kernel", "predict_kernel", "fullsearch2_kernel", "refine_kernel"}
 
 
 def test_python_struct_layouts_match_the_header(tmp_path):
@@ -118,12 +118,12 @@ def test_python_struct_layouts_match_the_header(tmp_path):
     if not cc:
         pytest.skip("no C compiler")
     src = tmp_path / "sizes.c"
-    src.write_text('#include <stdio.h>\n#include "x265_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", '
+    src.write_text('#include <stdio.h>\n#include "x265_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", '
                    'sizeof(x265_hip_primitives), sizeof(x265_hip_me_job), sizeof(x265_hip_me_result), sizeof(x265_hip_cost_req), '
-                   'sizeof(x265_hip_bidir_req), sizeof(x265_hip_pred_req), sizeof(x265_hip_ctu_job)); return 0; }\n')
+                   'sizeof(x265_hip_bidir_req), sizeof(x265_hip_pred_req), sizeof(x265_hip_ctu_job), sizeof(x265_hip_refine_req)); return 0; }\n')
     exe = tmp_path / "sizes"
     subprocess.check_call([cc, "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(lib.Primitives), abi.ME_JOB.itemsize, abi.ME_RESULT.itemsize, abi.COST_REQ.itemsize,
-            abi.BIDIR_REQ.itemsize, abi.PRED_REQ.itemsize, lib.CTU_JOB.itemsize]
+            abi.BIDIR_REQ.itemsize, abi.PRED_REQ.itemsize, lib.CTU_JOB.itemsize, abi.REFINE_REQ.itemsize]
     assert got == want

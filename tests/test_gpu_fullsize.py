@@ -161,6 +161,23 @@ def test_satd_candidates_whole_4k_frame_three_refs(uhd, oracle):
     assert len(bad) == 0, (len(bad), reqs[bad[0]], got[bad[0]], want[bad[0]])
 
 
+def test_satd_rings_whole_4k_frame_three_refs(uhd, oracle):
+    """the same candidates as rings (x265_hip_refine_batch, the list bench.py's headline times: 1.03 M ring requests
+    sorted by PU size), every one of the 8.26 M costs equal to the oracle's subpelCompare + satd"""
+    from x265_amd import abi, synth
+    seq, planes, ctx = uhd
+    refs = [2, 1, 0]
+    rr = synth.refine_requests(3840, 2160, 3, refs, [seq.global_motion(3, r) for r in refs])
+    rr = rr[np.argsort(-rr["pu_w"].astype(np.int64), kind="stable")]
+    got = ctx.refine_batch(rr)
+    creqs, used = abi.refine_as_cost_reqs(rr)
+    assert used.sum() == 3 * 16 * 172020
+    want = oracle.cost_batch([p.as_tuple() for p in planes], creqs[used], nthreads=THREADS)
+    assert (got[~used] == 0x7fffffff).all()
+    bad = np.nonzero(got[used] != want)[0]
+    assert len(bad) == 0, (len(bad), creqs[used][bad[0]], got[used][bad[0]], want[bad[0]])
+
+
 def test_fullsearch_whole_4k_frame(uhd, oracle):
     """all 2040 CTUs of a 4K picture: a sample of CTUs exactly against the oracle, every one of the 173,400 results by
     the size-independent properties (cost == SAD at the returned vector + its rate, vector inside the window, winner

@@ -32,7 +32,7 @@ def timed(fn, reps=20):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def run(label, crq, rrq):
+def run(label, crq, rrq, check=True):
     d_c, d_r = DeviceBuffer.from_array(crq), DeviceBuffer.from_array(rrq)
     o_c, o_r = DeviceBuffer(4 * len(crq)), DeviceBuffer(36 * len(rrq))
     ms_c = timed(lambda: ctx.cost_batch_device(d_c.ptr, len(crq), o_c.ptr))
@@ -42,6 +42,8 @@ def run(label, crq, rrq):
     print(f"{label:12s} {ncand:9d} candidates  cost_batch {ms_c:7.3f} ms {ncand / ms_c * 1e3:9.3e}/s   refine_batch {ms_r:7.3f} ms "
           f"{ncand / ms_r * 1e3:9.3e}/s  x{ms_c / ms_r:.2f}   algorithmic lane-ops/s {ops / ms_r * 1e3:.3e} "
           f"({ops / ms_r * 1e3 / 7.86e13:.2f} of 7.86e13)", flush=True)
+    if not check:
+        return
     # same numbers: candidate (ref, ring offset, pu) of the cost list = entry (ref, ring, pu)[k] of the ring list
     got = o_r.download(np.int32).reshape(-1, 9)
     want = o_c.download(np.int32)
@@ -54,6 +56,8 @@ def run(label, crq, rrq):
 crq = synth.subpel_requests(W, H, 3, refs, mot)
 rrq = synth.refine_requests(W, H, 3, refs, mot)
 run("all sizes", crq, rrq)
+o = np.argsort(-rrq["pu_w"].astype(int), kind="stable")
+run("sorted", crq, rrq[o], check=False)
 for s in (64, 32, 16, 8):
     run(f"{s}x{s}", crq[crq["pu_w"] == s], rrq[rrq["pu_w"] == s])
 ctx.close()

@@ -57,6 +57,10 @@
 #define M_DOT4_I8(r) "v_dot4_i32_i8 " r ", %8, %10, " r "\n"
 #define M_DOT4_U8(r) "v_dot4_u32_u8 " r ", %8, %10, " r "\n"
 #define M_DOT2_I16(r) "v_dot2_i32_i16 " r ", %8, %10, " r "\n"
+#define M_DOT2C_I16(r) "v_dot2c_i32_i16_e32 " r ", %8, %10\n"
+#define M_DOT4C_I8(r) "v_dot4c_i32_i8_e32 " r ", %8, %10\n"
+#define M_MUL_U24(r) "v_mul_u32_u24_e32 " r ", %8, " r "\n"
+#define M_SBFE(r) "v_bfe_i32 " r ", " r ", 8, 8\n"
 #define M_ADD_DPP(r) "v_add_u32_dpp " r ", %8, " r " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
 #define M_MOV_DPP(r) "v_mov_b32_dpp " r ", %8 row_ror:1 row_mask:0xf bank_mask:0xf\n"
 #define M_ADD_SDWA(r) "v_add_u32_sdwa " r ", %8, " r " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n"
@@ -68,7 +72,7 @@ enum
     OP_MIN_U32_E32, OP_MAX_I32_E32, OP_MOV, OP_ADDF_E32, OP_FMA, OP_FMAC, OP_CNDMASK, OP_MUL_LO, OP_MAD24, OP_MAD16,
     OP_ADD3, OP_LSHL_ADD, OP_LSHL_OR, OP_AND_OR, OP_BFE, OP_PERM, OP_ALIGNBYTE, OP_MIN3, OP_MED3, OP_SAD_U8,
     OP_PK_ADD_U16, OP_PK_SUB_I16, OP_PK_MAX_I16, OP_PK_MAD_U16, OP_PK_LSHL, OP_DOT4_I8, OP_DOT4_U8, OP_DOT2_I16,
-    OP_ADD_DPP, OP_MOV_DPP, OP_ADD_SDWA, OP_QSAD, OP_MQSAD, OP_COUNT
+    OP_ADD_DPP, OP_MOV_DPP, OP_ADD_SDWA, OP_QSAD, OP_MQSAD, OP_DOT2C_I16, OP_DOT4C_I8, OP_MUL_U24, OP_SBFE, OP_COUNT
 };
 
 template <int OP>
@@ -124,6 +128,10 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint64_t *ticks, uint32_
         else if (OP == OP_ADD_DPP) RUN(M_ADD_DPP);
         else if (OP == OP_MOV_DPP) RUN(M_MOV_DPP);
         else if (OP == OP_ADD_SDWA) RUN(M_ADD_SDWA);
+        else if (OP == OP_DOT2C_I16) RUN(M_DOT2C_I16);
+        else if (OP == OP_DOT4C_I8) RUN(M_DOT4C_I8);
+        else if (OP == OP_MUL_U24) RUN(M_MUL_U24);
+        else if (OP == OP_SBFE) RUN(M_SBFE);
         else if (OP == OP_QSAD)
         {
             q0 = __builtin_amdgcn_qsad_pk_u16_u8(r, f, q0); q1 = __builtin_amdgcn_qsad_pk_u16_u8(r, f, q1);
@@ -157,6 +165,7 @@ static const char *k_names[OP_COUNT] = {
     "v_lshl_or_b32", "v_and_or_b32", "v_bfe_u32", "v_perm_b32", "v_alignbyte_b32", "v_min3_u32", "v_med3_i32", "v_sad_u8",
     "v_pk_add_u16", "v_pk_sub_i16", "v_pk_max_i16", "v_pk_mad_u16", "v_pk_lshlrev_b16", "v_dot4_i32_i8", "v_dot4_u32_u8",
     "v_dot2_i32_i16", "v_add_u32_dpp", "v_mov_b32_dpp", "v_add_u32_sdwa", "v_qsad_pk_u16_u8", "v_mqsad_pk_u16_u8",
+    "v_dot2c_i32_i16_e32", "v_dot4c_i32_i8_e32", "v_mul_u32_u24_e32", "v_bfe_i32",
 };
 
 static uint32_t *d_out;

@@ -1,115 +1,169 @@
-// refine.hip -- one sub-pel refinement ring per request, with the interpolation shared through LDS.
+// refine.hip -- one sub-pel refinement ring per request, with the interpolation shared between its candidates.
 //
 // Reference: the sub-pel stage of MotionEstimate::motionEstimate (encoder/motion.cpp:1047-1119): each iteration
 // measures subpelCompare(ref, bmv + square1[i] * step, cmp) (:1126-1164) for i = 1 .. 4 or 8 around one centre, step 2
 // (half-pel ring) or 1 (quarter-pel ring), plus (first half-pel iteration with SATD) the centre itself.  The nine
-// positions are a 3 x 3 grid: three horizontal positions x three vertical positions.  luma_hps + luma_vsp
+// positions are a 3 x 3 grid: three horizontal positions k x three vertical positions j.  luma_hps + luma_vsp
 // (common/ipfilter.cpp:117-160, 241-282) is separable and its first stage is exact (no rounding at 8 bits), so
-//   * one horizontal pass per horizontal position k gives an int16 plane I_k = sum_t c[fx_k][t] * (p - 128) that all
-//     three vertical positions of that column of the grid share;
+//   * one horizontal pass per horizontal position gives int16 rows I_k = sum_t c[fx_k][t] * (p - 128) that the three
+//     vertical positions of that column of the grid share;
 //   * with the tap row {0,0,0,64,0,0,0,0} a stage is the identity up to scale, and the two-stage formula with it
 //     reproduces luma_hpp / luma_vpp / the full-pel copy bit for bit ((64 S + 2048) >> 12 == (S + 32) >> 6), so all
 //     nine positions go through the same code whatever their fractions are.
 //
-// Shape of the kernel.  A wave takes a batch of requests and walks over their cells (<= 16 x 16 pixels of a PU), as
-// many cells at a time as fill its 64 lanes and its LDS region (four 8x8 PUs, one 16x16 cell, ...):
-//   stage A  items (cell, k, row pair, 4 pixels): 16-byte load of the reference row, 8 v_dot4_i32_i8, the two rows
-//            stored as vertical int16 pairs in both pairings -- E[m] = (row 2m, row 2m+1), O[m] = (row 2m+1, row 2m+2) --
-//            so that stage B finds (row t, row t+1) in one dword for any t;
-//   stage B  items (cell, candidate, strip of 4 x 8 pixels): per output row 4 x 4 v_dot2_i32_i16 on pairs read with
-//            ds_read_b128 (taps pre-multiplied by 16: the upper half of the sum is the >> 12), clamp on packed
-//            pairs, then SAD or the packed 4x4 Hadamard of me_device.h against the source block; partial sums meet in
-//            LDS atomics.
-// Per 16x16 cell and ring of 8: about 150 + 330 wave-instructions against 8 x 95 for eight independent cost requests.
+// Shape of the kernel (the batch hand-out is cost_body's, me_kernel.hip).  Work items are (request, k, strip of 4 x 8
+// pixels), dealt k-major over a batch so that the lanes of a pass share k.  A lane
+//   1. filters the 16 reference rows its three vertical positions need (rows iy(j = -1) - 3 .. + 15) horizontally:
+//      16-byte load, 8 v_dot4_i32_i8 per row, kept as eight registers x 4 pixels of vertical int16 pairs;
+//   2. per vertical position j: 5 v_dot2_i32_i16 per pixel over those pairs with a 9-tap window (the 8 taps at offset
+//      delta_j = iy(j) - iy(-1), so one static register pattern serves every j; taps pre-multiplied by 16: the upper
+//      half of the sum is the >> 12), clamp on packed pairs, SAD or the packed 4x4 Hadamard of me_device.h against the
+//      source block, LDS atomic into the candidate's sum.
+// A first version that staged the horizontal passes in LDS (cells of 16 x 16, both vertical pairings, groups of cells
+// per wave) issued 1.65 x the VALU instructions of cost_kernel for the same candidates (profiles/r02_refine_lds_pmc.txt:
+// the staging pass and the cell bookkeeping cost as much as they saved) and was dropped for this register form.
 #include "kernels.h"
 #include "me_device.h"
 
 namespace x265hip {
 
-#define RF_BATCH 16     // requests per batch (at most)
-#define RF_SLOTS 8      // cells worked on at a time (at most)
-#define RF_PLANE_DW 1664 // filtered planes per wave in dwords: four 8x8 cells (4 x 408) or one 16x16 cell (1200)
-#define RF_RAW_DW 544    // raw reference windows per wave in dwords: four 8x8 cells (4 x 17 rows x 8)
+#define RF_BATCH 32 // requests per batch (at most)
 #define RF_PARTS 64
 #define RF_CHUNK 8
-#define RF_MAX_BLOCKS (256 * 4)
-#define RF_Z 3 // raw 16-byte loads per lane and group (at most: 136 for four 8x8 cells)
+#define RF_MAX_BLOCKS (256 * 5)
 
-// vertical taps x 16 as int16 pairs (c0, c1) (c2, c3) (c4, c5) (c6, c7)
-#define RF_V16(c0, c1, c2, c3, c4, c5, c6, c7) \
-    { X265HIP_PK16(16 * (c0), 16 * (c1)), X265HIP_PK16(16 * (c2), 16 * (c3)), X265HIP_PK16(16 * (c4), 16 * (c5)), X265HIP_PK16(16 * (c6), 16 * (c7)) }
-__device__ __constant__ __attribute__((aligned(16))) const uint32_t k_vtaps16[4][4] = {
-    RF_V16(0, 0, 0, 64, 0, 0, 0, 0),
-    RF_V16(-1, 4, -10, 58, 17, -5, 1, 0),
-    RF_V16(-1, 4, -11, 40, 40, -11, 4, -1),
-    RF_V16(0, 1, -5, 17, 58, -10, 4, -1),
+// 9-tap windows of the vertical filter x 16 as int16 pairs, per (fraction, delta): entries 0..4 serve even output
+// rows (C0,C1) (C2,C3) (C4,C5) (C6,C7) (C8,0), entries 5..9 odd ones (0,C0) (C1,C2) (C3,C4) (C5,C6) (C7,C8), where
+// C = (c0..c7, 0) for delta 0 and (0, c0..c7) for delta 1
+#define RF_P(a, b) X265HIP_PK16(16 * (a), 16 * (b))
+#define RF_WIN(C0, C1, C2, C3, C4, C5, C6, C7, C8) \
+    { RF_P(C0, C1), RF_P(C2, C3), RF_P(C4, C5), RF_P(C6, C7), RF_P(C8, 0), RF_P(0, C0), RF_P(C1, C2), RF_P(C3, C4), RF_P(C5, C6), RF_P(C7, C8), 0, 0 }
+#define RF_TAPS(c0, c1, c2, c3, c4, c5, c6, c7) RF_WIN(c0, c1, c2, c3, c4, c5, c6, c7, 0), RF_WIN(0, c0, c1, c2, c3, c4, c5, c6, c7)
+__device__ __constant__ __attribute__((aligned(16))) const uint32_t k_ring_taps[8][12] = {
+    RF_TAPS(0, 0, 0, 64, 0, 0, 0, 0),
+    RF_TAPS(-1, 4, -10, 58, 17, -5, 1, 0),
+    RF_TAPS(-1, 4, -11, 40, 40, -11, 4, -1),
+    RF_TAPS(0, 1, -5, 17, 58, -10, 4, -1),
 };
-// (dx, dy) of square1[0..8] (motion.cpp:71-73) as (dx + 1) | (dy + 1) << 2
-__device__ __constant__ const uint8_t k_sq_kj[9] = { 1 | 1 << 2, 1 | 0 << 2, 1 | 2 << 2, 0 | 1 << 2, 2 | 1 << 2, 0 | 0 << 2, 0 | 2 << 2, 2 | 0 << 2, 2 | 2 << 2 };
+// index into square1 (motion.cpp:71-73) of grid position (k, j) = (dx + 1, dy + 1)
+__device__ __constant__ const uint8_t k_sq_of[3][3] = { { 5, 3, 6 }, { 1, 0, 2 }, { 7, 4, 8 } };
 
-struct RefineLds
+struct RingLds
 {
-    uint32_t plane[RF_PLANE_DW];
-    uint32_t raw[RF_RAW_DW + 4]; // a row's last read may touch one dword past its window
+    int pre[RF_BATCH + 1]; // exclusive prefix of the requests' strip counts
     int cost[RF_BATCH * X265_HIP_RING_COSTS];
     const uint8_t *fenc[RF_BATCH]; // PU origin in the source plane
     const uint8_t *ref[RF_BATCH];  // PU origin in the reference plane
     int fstride[RF_BATCH], rstride[RF_BATCH];
-    int geom[RF_BATCH]; // log2(cw / 4) | log2(ch / 4) << 2 | ncx << 4 | strips are 8 tall << 12 | metric << 13
+    int info[RF_BATCH]; // ntx | tall << 5 | metric << 6 | step << 7 | eight directions << 9 | centre << 10
     int qmv[RF_BATCH];  // (cy << 16) | (cx & 0xffff)
-    int pat[RF_BATCH];  // step | ncand << 4 | centre << 8
-    int pre[RF_BATCH + 1]; // exclusive prefix of the requests' cell counts
-    // the cells of a group, two sets: the next group is formed and its loads issued while the current one computes
-    int s_req[2][RF_SLOTS], s_xy[2][RF_SLOTS], s_plane[2][RF_SLOTS], s_raw[2][RF_SLOTS];
-};
-
-// wave-uniform description of a group of cells
-struct Group
-{
-    int size, total_z, total_a, total_b;
-    int zpre[RF_SLOTS], apre[RF_SLOTS], bpre[RF_SLOTS]; // exclusive prefixes of the item counts; slots past the group never match
 };
 
 __device__ __forceinline__ int rf_s16(int v) { return (int)(int16_t)v; }
 
-__device__ __forceinline__ int scan8(int v) // inclusive scan over lanes 0..7 of a DPP row
+// One strip of NT tiles for one horizontal position: `src` is the reference at row iy(-1) - 3, column ix - 3 of
+// the strip; jneed says which vertical positions this lane wants, tj[j] their tap windows (fraction * 2 + delta).
+// Adds the lane's costs into cost[sq[j]].
+template <int NT>
+__device__ __forceinline__ void ring_strip(gptr_t src, int stride, int fx, int jneed, const int tj[3], const uint32_t *taps_lds,
+                                           const uint8_t *f, int fstride, int metric, int *cost, const int sq[3])
 {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
-    return v;
-}
-
-// slot of item i and the slot's first item
-__device__ __forceinline__ int slot_of(const int pre[RF_SLOTS], int i, int &first)
-{
-    int g = 0;
-    first = 0;
+    constexpr int NP = 2 * NT + 4; // row pairs: rows 0 .. 4 NT + 7
+    uint32_t q[NP][4];
+    // ---- horizontal pass: rows 2p, 2p + 1 as vertical pairs ---------------------------------------------------------
+    if (__ballot(fx != 0) == 0)
+    {
+        // no lane of this pass filters horizontally: I = 64 (p - 128), the luma_p2s form
 #pragma unroll
-    for (int t = 1; t < RF_SLOTS; t++)
-        if (pre[t] <= i)
+        for (int p = 0; p < NP; p++)
         {
-            g = t;
-            first = pre[t];
+            const uint32_t a = ld4g(src + (2 * p) * stride + 3) ^ 0x80808080u, b = ld4g(src + (2 * p + 1) * stride + 3) ^ 0x80808080u;
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                const int va = __builtin_amdgcn_sbfe((int)a, 8 * x, 8), vb = __builtin_amdgcn_sbfe((int)b, 8 * x, 8);
+                q[p][x] = as_u32(as_s2(pack_s16(va, vb)) << 6); // v_pk_lshlrev_b16
+            }
         }
-    return g;
+    }
+    else
+    {
+        const uint32_t tlo = k_taps_s8[fx][0], thi = k_taps_s8[fx][1];
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+        {
+            int a[4], b[4];
+            uint32_t d0, d1, d2;
+            ld12g(src + (2 * p) * stride, d0, d1, d2);
+            tap8x4<0>(d0 ^ 0x80808080u, d1 ^ 0x80808080u, d2 ^ 0x80808080u, tlo, thi, a);
+            ld12g(src + (2 * p + 1) * stride, d0, d1, d2);
+            tap8x4<0>(d0 ^ 0x80808080u, d1 ^ 0x80808080u, d2 ^ 0x80808080u, tlo, thi, b);
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                q[p][x] = pack_s16(a[x], b[x]);
+        }
+    }
+    // ---- vertical pass + comparison per vertical position -----------------------------------------------------------
+    constexpr int seed = 16 * (2048 + (8192 << 6));
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+    {
+        if (__ballot((jneed >> j) & 1) == 0)
+            continue;
+        const uint32_t *tp = taps_lds + tj[j] * 12;
+        const uint4 t03 = *(const uint4 *)tp, t47 = *(const uint4 *)(tp + 4);
+        const uint2 t89 = *(const uint2 *)(tp + 8);
+        const uint32_t te[5] = { t03.x, t03.y, t03.z, t03.w, t47.x }, to[5] = { t47.y, t47.z, t47.w, t89.x, t89.y };
+        int v = 0;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+        {
+            uint32_t P[4][2];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+            {
+                const int u = 2 * t + (y >> 1);
+                const uint32_t *w = (y & 1) ? to : te;
+                int s[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                    s[x] = sdot2(q[u + 4][x], w[4], sdot2(q[u + 3][x], w[3], sdot2(q[u + 2][x], w[2], sdot2(q[u + 1][x], w[1], sdot2_first<seed>(q[u][x], w[0])))));
+                // upper halves = sums >> 12 (taps were x 16), as int16 pairs; then the clamp to 0..255
+                const s16x2 lo = { 0, 0 }, hi255 = { 255, 255 };
+                s16x2 p0 = as_s2(__builtin_amdgcn_perm((uint32_t)s[1], (uint32_t)s[0], 0x07060302));
+                s16x2 p1 = as_s2(__builtin_amdgcn_perm((uint32_t)s[3], (uint32_t)s[2], 0x07060302));
+                P[y][0] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(p0, lo), hi255));
+                P[y][1] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(p1, lo), hi255));
+            }
+            v += tile_metric<true>(f + 4 * t * fstride, fstride, P, metric);
+        }
+        if ((jneed >> j) & 1)
+            atomicAdd(&cost[sq[j]], v);
+    }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void refine_kernel(const DeviceTables *tabs, const x265_hip_refine_req *reqs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void refine_kernel(const DeviceTables *tabs, const x265_hip_refine_req *reqs,
                                                                                            int n, int32_t *out, uint32_t *counters, int parity, int rb)
 {
-    __shared__ RefineLds lds[4];
-    RefineLds &L = lds[threadIdx.x >> 6];
+    __shared__ RingLds lds[4];
+    __shared__ __attribute__((aligned(16))) uint32_t taps_lds[8 * 12];
+    if (threadIdx.x < 8 * 12)
+        taps_lds[threadIdx.x] = (&k_ring_taps[0][0])[threadIdx.x];
+    __syncthreads();
+    RingLds &L = lds[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
 
     // Work per batch is bounded: every wave looks at the same 64 requests spread over the list (multiples of the
-    // golden ratio, see cost_body) and halves rb until a batch holds about 1024 stage-B items by their mean.
+    // golden ratio, see cost_body) and halves rb until a batch holds about 1024 items by their mean.  (A list whose
+    // sizes come in long runs, e.g. sorted by PU size, defeats a size taken from a sample of the whole list: callers
+    // submit such lists one size at a time.  Deciding the length of a run where it is taken, from the request it
+    // starts with, was tried with a compare-and-swap hand-out and serialised the waves of a part: 3 us per run.)
     if (rb > 1)
     {
         const int si = n >= 64 ? (int)(((unsigned long long)((unsigned)lane * 0x9E3779B1u) * (unsigned long long)n) >> 32) : lane;
         int items = 0;
         if (si < n)
-            items = (reqs[si].pu_w >> 2) * ((reqs[si].pu_h + 7) >> 3) * 8;
+            items = 3 * (reqs[si].pu_w >> 2) * ((reqs[si].pu_h + 7) >> 3);
         for (int o = 32; o; o >>= 1)
             items += __shfl_xor(items, o);
         const int cnt = n < 64 ? n : 64;
@@ -139,35 +193,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
         nb = nwaves + uniform(nb);
         const int base = batch_of(b) * rb;
         const bool have = lane < rb && base + lane < n;
-        // ---- per request: addresses, geometry, cell count ------------------------------------------------
-        int ncell = 0;
+        int ns = 0; // strips of this lane's request
         if (have)
         {
             const PlaneDesc fp = tabs->planes[cur.fenc_plane], rp = tabs->planes[cur.ref_plane];
-            const int w = cur.pu_w, h = cur.pu_h;
-            const int lcw = (w & 15) == 0 ? 2 : (w & 7) == 0 ? 1 : 0, lch = (h & 15) == 0 ? 2 : (h & 7) == 0 ? 1 : 0;
-            const int ncx = w >> (2 + lcw), ncy = h >> (2 + lch);
-            const int step = (cur.pattern & X265_HIP_RING_HPEL) ? 2 : 1;
-            const int centre = (cur.pattern & X265_HIP_RING_CENTRE) ? 1 : 0;
-            const int ncand = ((cur.pattern & X265_HIP_RING_8) ? 8 : 4) + centre;
-            ncell = ncx * ncy;
+            const int tall = (cur.pu_h & 7) == 0;
+            ns = (cur.pu_w >> 2) * (cur.pu_h >> (2 + tall));
             L.fenc[lane] = fp.origin + (long)cur.pu_y * fp.stride + cur.pu_x;
             L.ref[lane] = rp.origin + (long)cur.pu_y * rp.stride + cur.pu_x;
             L.fstride[lane] = fp.stride;
             L.rstride[lane] = rp.stride;
-            L.geom[lane] = lcw | (lch << 2) | (ncx << 4) | ((lch >= 1) << 12) | ((cur.metric & 1) << 13);
+            L.info[lane] = (cur.pu_w >> 2) | (tall << 5) | ((cur.metric & 1) << 6) | (((cur.pattern & X265_HIP_RING_HPEL) ? 2 : 1) << 7) |
+                           (((cur.pattern & X265_HIP_RING_8) ? 1 : 0) << 9) | (((cur.pattern & X265_HIP_RING_CENTRE) ? 1 : 0) << 10);
             L.qmv[lane] = (int)(((uint32_t)(uint16_t)cur.qmv_y << 16) | (uint16_t)cur.qmv_x);
-            L.pat[lane] = step | (ncand << 4) | (centre << 8);
         }
+        if (lane < RF_BATCH)
         {
-            // exclusive prefix of the cell counts over lanes 0..15 (one DPP row)
-            int inc = ncell;
+            // inclusive scan over lanes 0..31: row_shr 1, 2, 4, 8 inside each 16-lane row, then the first row's total
+            int inc = ns;
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
-            if (lane < RF_BATCH)
-                L.pre[lane + 1] = inc;
+            const int row0 = __builtin_amdgcn_readlane(inc, 15);
+            if (lane >= 16)
+                inc += row0;
+            L.pre[lane + 1] = inc;
             if (lane == 0)
                 L.pre[0] = 0;
         }
@@ -180,237 +231,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
                 cur = reqs[nid];
         }
         wave_sync();
-        const int total_cells = L.pre[RF_BATCH];
-
-        // lane g < 8 describes cell c0 + g; the group is the longest prefix that fits the lanes and the LDS regions
-        auto form = [&](int c0, int set, Group &G) {
-            int g_req = 0, g_ipc = 0, g_apc = 0, g_zpc = 0, g_dw = 0, g_rdw = 0, g_xy = 0;
-            const int ci = c0 + lane;
-            const bool cell_ok = lane < RF_SLOTS && ci < total_cells;
-            if (cell_ok)
-            {
-#pragma unroll
-                for (int s = 8; s > 0; s >>= 1)
-                    if (L.pre[g_req + s] <= ci)
-                        g_req += s;
-                const int geom = L.geom[g_req], pat = L.pat[g_req];
-                const int lcw = geom & 3, lch = (geom >> 2) & 3, ncx = (geom >> 4) & 255;
-                const int cw = 4 << lcw, ch = 4 << lch, rows = ch + 9;
-                const int q = ci - L.pre[g_req];
-                const int qy = (int)(((float)q + 0.5f) * __builtin_amdgcn_rcpf((float)ncx)), qx = q - qy * ncx;
-                g_xy = (qx * cw) | ((qy * ch) << 16);
-                const int nstrip = (1 << lcw) * (lch == 2 ? 2 : 1);
-                const int nload = lcw ? 2 : 1; // 16-byte pieces of a raw row: cw + 11 bytes
-                g_ipc = ((pat >> 4) & 15) * nstrip;
-                g_apc = 3 * ((rows + 1) >> 1) * (1 << lcw);
-                g_zpc = rows * nload;
-                g_dw = 3 * rows * cw;
-                g_rdw = rows * nload * 4;
-            }
-            const int sc_ipc = scan8(g_ipc), sc_apc = scan8(g_apc), sc_zpc = scan8(g_zpc), sc_dw = scan8(g_dw), sc_rdw = scan8(g_rdw);
-            const bool fits = cell_ok && (lane == 0 || (sc_ipc <= 64 && sc_dw <= RF_PLANE_DW && sc_rdw <= RF_RAW_DW));
-            const int gsize = __builtin_ctzll(~__ballot(fits));
-            if (lane < gsize)
-            {
-                L.s_req[set][lane] = g_req;
-                L.s_xy[set][lane] = g_xy;
-                L.s_plane[set][lane] = sc_dw - g_dw;
-                L.s_raw[set][lane] = sc_rdw - g_rdw;
-            }
-            G.size = gsize;
-            G.zpre[0] = G.apre[0] = G.bpre[0] = 0;
-#pragma unroll
-            for (int g = 1; g < RF_SLOTS; g++)
-            {
-                G.zpre[g] = g < gsize ? __builtin_amdgcn_readlane(sc_zpc, g - 1) : 0x7fffffff;
-                G.apre[g] = g < gsize ? __builtin_amdgcn_readlane(sc_apc, g - 1) : 0x7fffffff;
-                G.bpre[g] = g < gsize ? __builtin_amdgcn_readlane(sc_ipc, g - 1) : 0x7fffffff;
-            }
-            G.total_z = __builtin_amdgcn_readlane(sc_zpc, gsize - 1);
-            G.total_a = __builtin_amdgcn_readlane(sc_apc, gsize - 1);
-            G.total_b = __builtin_amdgcn_readlane(sc_ipc, gsize - 1);
-        };
-
-        // stage 0, first half: this lane's raw 16-byte pieces of the group's reference windows into registers
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 rawv[RF_Z];
-        int rawdst[RF_Z];
-        auto issue0 = [&](int set, const Group &G) {
-#pragma unroll
-            for (int z = 0; z < RF_Z; z++)
-            {
-                const int i = lane + 64 * z;
-                rawdst[z] = -1;
-                if (i < G.total_z)
-                {
-                    int first;
-                    const int g = slot_of(G.zpre, i, first);
-                    const int r = L.s_req[set][g], xy = L.s_xy[set][g], geom = L.geom[r], q = L.qmv[r], step = L.pat[r] & 3;
-                    const int lnl = (geom & 3) ? 1 : 0;
-                    const int rem = i - first, row = rem >> lnl, hf = rem & lnl;
-                    const int cx = (int)(int16_t)q, cy = q >> 16;
-                    const int ix0 = rf_s16(cx - step) >> 2, rb_row = (rf_s16(cy - step) >> 2) - 3;
-                    const gptr_t p = as_global(L.ref[r]) + (long)((xy >> 16) + rb_row + row) * L.rstride[r] + (xy & 0xffff) + ix0 - 3;
-                    rawv[z] = *(const __attribute__((address_space(1))) u32x4 *)(p - ((unsigned)(uintptr_t)p & 3u) + 16 * hf);
-                    rawdst[z] = L.s_raw[set][g] + ((row << lnl) + hf) * 4;
-                }
-            }
-        };
-        auto store0 = [&]() {
-#pragma unroll
-            for (int z = 0; z < RF_Z; z++)
-                if (rawdst[z] >= 0)
-                    *(u32x4 *)(L.raw + rawdst[z]) = rawv[z];
-        };
-
-        Group G, GN;
-        int c0 = 0, set = 0;
-        form(c0, set, G);
-        wave_sync();
-        issue0(set, G);
-        for (;;)
+        const int S = L.pre[RF_BATCH]; // strips of the batch; items are (k, strip), k-major
+        for (int i = lane; i < 3 * S; i += 64)
         {
-            store0();
-            wave_sync();
-            // ---- stage A: horizontal pass, raw window -> int16 planes in both vertical pairings ------------------------
-            for (int i = lane; i < G.total_a; i += 64)
-            {
-                int first;
-                const int g = slot_of(G.apre, i, first);
-                const int r = L.s_req[set][g], xy = L.s_xy[set][g], geom = L.geom[r], q = L.qmv[r], step = L.pat[r] & 3;
-                const int lcw = geom & 3, lch = (geom >> 2) & 3, cw = 4 << lcw, rows = (4 << lch) + 9, ne = (rows + 1) >> 1;
-                const int lnl = lcw ? 1 : 0;
-                const int rem = i - first, xg = rem & ((1 << lcw) - 1), t = rem >> lcw;
-                const int k = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)ne)), m = t - k * ne;
-                const int cx = (int)(int16_t)q, cy = q >> 16;
-                const int qx = rf_s16(cx + (k - 1) * step), fx = qx & 3;
-                const int ix0 = rf_s16(cx - step) >> 2, rb_row = (rf_s16(cy - step) >> 2) - 3;
-                const int rstride = L.rstride[r];
-                // low address bits of raw row 0's first wanted byte: the alignment of a row inside its window
-                const unsigned a0 = (unsigned)(uintptr_t)L.ref[r] + (unsigned)(((xy >> 16) + rb_row) * rstride + (xy & 0xffff) + ix0 - 3);
-                const int r0 = 2 * m, r1 = min(2 * m + 1, rows - 1);
-                const uint32_t tlo = k_taps_s8[fx][0], thi = k_taps_s8[fx][1];
-                const uint32_t *const rawbase = L.raw + L.s_raw[set][g];
-                int a[4], bb[4];
-                auto hrow = [&](int row, int o[4]) {
-                    const int bo = ((a0 + (unsigned)(row * rstride)) & 3u) + ((qx >> 2) - ix0) + 4 * xg;
-                    const uint32_t *w = rawbase + (row << (2 + lnl)) + (bo >> 2);
-                    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-                    const unsigned sh = bo & 3;
-                    const uint32_t d0 = __builtin_amdgcn_alignbyte(w1, w0, sh), d1 = __builtin_amdgcn_alignbyte(w2, w1, sh),
-                                   d2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
-                    tap8x4<0>(d0 ^ 0x80808080u, d1 ^ 0x80808080u, d2 ^ 0x80808080u, tlo, thi, o);
-                };
-                hrow(r0, a);
-                hrow(r1, bb);
-                uint32_t *const plane = L.plane + L.s_plane[set][g] + k * rows * cw;
-                uint4 e;
-                e.x = pack_s16(a[0], bb[0]);
-                e.y = pack_s16(a[1], bb[1]);
-                e.z = pack_s16(a[2], bb[2]);
-                e.w = pack_s16(a[3], bb[3]);
-                *(uint4 *)(plane + m * cw + 4 * xg) = e; // E[m]
-                // O[m] = (row 2m+1, row 2m+2): this item's odd row is its low half, its even row the high half of O[m-1]
-                int16_t *const o = (int16_t *)(plane + ne * cw);
-                if (m < (rows >> 1)) // O has rows / 2 entries (rows is odd)
+            const int k = (i >= S) + (i >= 2 * S), si = i - k * S;
+            int r = 0;
 #pragma unroll
-                    for (int x = 0; x < 4; x++)
-                        o[2 * (m * cw + 4 * xg + x)] = (int16_t)bb[x];
-                if (m >= 1)
+            for (int s = 16; s > 0; s >>= 1)
+                if (L.pre[r + s] <= si)
+                    r += s;
+            const int t = si - L.pre[r];
+            const int info = L.info[r], ntx = info & 31, tall = (info >> 5) & 1, metric = (info >> 6) & 1, step = (info >> 7) & 3;
+            const int eight = (info >> 9) & 1, centre = (info >> 10) & 1;
+            const int ty = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)ntx)), tx = t - ty * ntx; // exact: t < 256, ntx <= 16
+            const int qm = L.qmv[r], cx = (int)(int16_t)qm, cy = qm >> 16;
+            const int qx = rf_s16(cx + (k - 1) * step);
+            const int iy0 = rf_s16(cy - step) >> 2; // integer row of the topmost vertical position
+            // which of the three vertical positions the pattern has in this column of the grid
+            const int jneed = eight ? (k == 1 && !centre ? 5 : 7) : (k == 1 ? (centre ? 7 : 5) : 2);
+            int tj[3], sq[3];
 #pragma unroll
-                    for (int x = 0; x < 4; x++)
-                        o[2 * ((m - 1) * cw + 4 * xg + x) + 1] = (int16_t)a[x];
-            }
-            // the next group: formed now, its raw loads fly during stage B
-            c0 += G.size;
-            const bool more = c0 < total_cells;
-            if (more)
+            for (int j = 0; j < 3; j++)
             {
-                form(c0, set ^ 1, GN);
-                wave_sync();
-                issue0(set ^ 1, GN);
+                const int qy = rf_s16(cy + (j - 1) * step);
+                tj[j] = (qy & 3) * 2 + ((qy >> 2) - iy0);
+                sq[j] = r * X265_HIP_RING_COSTS + k_sq_of[k][j];
             }
+            const int rstride = L.rstride[r], fstride = L.fstride[r];
+            const int rows = 4 << tall;
+            const gptr_t src = as_global(L.ref[r]) + (long)(rows * ty + iy0 - 3) * rstride + 4 * tx + (qx >> 2) - 3;
+            const uint8_t *f = L.fenc[r] + (long)(rows * ty) * fstride + 4 * tx;
+            if (tall)
+                ring_strip<2>(src, rstride, qx & 3, jneed, tj, taps_lds, f, fstride, metric, L.cost, sq);
             else
-            {
-#pragma unroll
-                for (int z = 0; z < RF_Z; z++)
-                    rawdst[z] = -1;
-                wave_sync();
-            }
-
-            // ---- stage B: vertical pass per candidate + comparison -----------------------------------------
-            for (int i = lane; i < G.total_b; i += 64)
-            {
-                int first;
-                const int g = slot_of(G.bpre, i, first);
-                const int r = L.s_req[set][g], xy = L.s_xy[set][g], geom = L.geom[r], q = L.qmv[r], pat = L.pat[r];
-                const int lcw = geom & 3, lch = (geom >> 2) & 3, cw = 4 << lcw, rows = (4 << lch) + 9, ne = (rows + 1) >> 1;
-                const int tall = (geom >> 12) & 1, metric = (geom >> 13) & 1, step = pat & 3;
-                const int lns = lcw + (lch == 2 ? 1 : 0); // log2(strips per cell)
-                const int rem = i - first, c = rem >> lns, st = rem & ((1 << lns) - 1);
-                const int sx = st & ((1 << lcw) - 1), sy = st >> lcw;
-                const int cand = c + 1 - ((pat >> 8) & 1); // index into square1: 0 is the centre
-                const int kj = k_sq_kj[cand], k = kj & 3, j = kj >> 2;
-                const int cy = q >> 16;
-                const int qy = rf_s16(cy + (j - 1) * step), fy = qy & 3;
-                const int rb_row = (rf_s16(cy - step) >> 2) - 3;
-                const int t0 = (qy >> 2) - 3 - rb_row + (sy << (2 + tall)); // plane row of output row 0's first tap
-                const uint32_t *const plane = L.plane + L.s_plane[set][g] + k * rows * cw + 4 * sx;
-                const int pa = t0 >> 1, odd = t0 & 1;
-                // rows y = 2u take pairs la[u .. u+3], rows y = 2u + 1 take lb[u .. u+3]
-                const uint32_t *const la = plane + ((odd ? ne : 0) + pa) * cw;
-                const uint32_t *const lb = plane + ((odd ? 0 : ne) + pa + odd) * cw;
-                const uint4 vt = *(const uint4 *)&k_vtaps16[fy][0];
-                constexpr int seed = 16 * (2048 + (8192 << 6));
-                const int fstride = L.fstride[r];
-                const uint8_t *f = L.fenc[r] + (long)((xy >> 16) + (sy << (2 + tall))) * fstride + (xy & 0xffff) + 4 * sx;
-                int v = 0;
-                auto rows4 = [&](int u0, uint32_t P[4][2]) {
-                    // output rows 2 u0 .. 2 u0 + 3 of the strip
-                    uint4 wa[5], wb[5];
-#pragma unroll
-                    for (int z = 0; z < 5; z++)
-                    {
-                        wa[z] = *(const uint4 *)(la + (u0 + z) * cw);
-                        wb[z] = *(const uint4 *)(lb + (u0 + z) * cw);
-                    }
-#pragma unroll
-                    for (int y = 0; y < 4; y++)
-                    {
-                        const uint4 *w = (y & 1) ? wb : wa;
-                        const int u = y >> 1;
-                        int s[4];
-                        s[0] = sdot2(w[u + 3].x, vt.w, sdot2(w[u + 2].x, vt.z, sdot2(w[u + 1].x, vt.y, sdot2_first<seed>(w[u].x, vt.x))));
-                        s[1] = sdot2(w[u + 3].y, vt.w, sdot2(w[u + 2].y, vt.z, sdot2(w[u + 1].y, vt.y, sdot2_first<seed>(w[u].y, vt.x))));
-                        s[2] = sdot2(w[u + 3].z, vt.w, sdot2(w[u + 2].z, vt.z, sdot2(w[u + 1].z, vt.y, sdot2_first<seed>(w[u].z, vt.x))));
-                        s[3] = sdot2(w[u + 3].w, vt.w, sdot2(w[u + 2].w, vt.z, sdot2(w[u + 1].w, vt.y, sdot2_first<seed>(w[u].w, vt.x))));
-                        // upper halves = sums >> 12 (taps were x 16), as int16 pairs; then the clamp to 0..255
-                        const s16x2 lo = { 0, 0 }, hi255 = { 255, 255 };
-                        s16x2 p0 = as_s2(__builtin_amdgcn_perm((uint32_t)s[1], (uint32_t)s[0], 0x07060302));
-                        s16x2 p1 = as_s2(__builtin_amdgcn_perm((uint32_t)s[3], (uint32_t)s[2], 0x07060302));
-                        p0 = __builtin_elementwise_min(__builtin_elementwise_max(p0, lo), hi255);
-                        p1 = __builtin_elementwise_min(__builtin_elementwise_max(p1, lo), hi255);
-                        P[y][0] = as_u32(p0);
-                        P[y][1] = as_u32(p1);
-                    }
-                };
-                {
-                    uint32_t P[4][2];
-                    rows4(0, P);
-                    v = tile_metric<true>(f, fstride, P, metric);
-                }
-                if (tall)
-                {
-                    uint32_t P[4][2];
-                    rows4(2, P);
-                    v += tile_metric<true>(f + 4 * fstride, fstride, P, metric);
-                }
-                atomicAdd(&L.cost[r * X265_HIP_RING_COSTS + cand], v);
-            }
-            if (!more)
-                break;
-            G = GN;
-            set ^= 1;
+                ring_strip<1>(src, rstride, qx & 3, jneed, tj, taps_lds, f, fstride, metric, L.cost, sq);
         }
         wave_sync();
         // ---- results: nine per request, INT_MAX where the pattern has no candidate ---------------------------------
@@ -419,8 +273,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
             const int r = i / X265_HIP_RING_COSTS, k = i - r * X265_HIP_RING_COSTS;
             if (base + r < n)
             {
-                const int pat = L.pat[r], centre = (pat >> 8) & 1, ncand = (pat >> 4) & 15;
-                const bool used = k == 0 ? centre != 0 : k <= ncand - centre;
+                const int info = L.info[r], ndirs = ((info >> 9) & 1) ? 8 : 4;
+                const bool used = k == 0 ? ((info >> 10) & 1) != 0 : k <= ndirs;
                 out[(long)(base + r) * X265_HIP_RING_COSTS + k] = used ? L.cost[i] : 0x7fffffff;
             }
         }

@@ -67,6 +67,13 @@ class SegmentRunner:
     def satd_requests(self, cur, refs):
         return synth.subpel_requests(self.w, self.h, self.plane_of(cur), [self.plane_of(r) for r in refs], self._motions(cur, refs))
 
+    def ring_requests(self, cur, refs):
+        """the same candidates as satd_requests() as ring requests (x265_hip_refine_batch: a half-pel and a quarter-pel
+        ring of 8 per PU and reference), as an encoder that works depth by depth produces them: one list per PU size
+        (64, 32, 16, 8), each submitted on its own"""
+        rq = synth.refine_requests(self.w, self.h, self.plane_of(cur), [self.plane_of(r) for r in refs], self._motions(cur, refs))
+        return [rq[rq["pu_w"] == s] for s in (64, 32, 16, 8)]
+
     def ctu_jobs(self, cur, ref, search_range=64, qp=30):
         """integer full search of every CTU of `cur` against `ref` (configs[1] at this picture size)"""
         from .lib import CTU_JOB
