@@ -352,6 +352,54 @@ int x265_hip_refine_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n, v
 #define X265_HIP_NOALLOC_MAX_REQUESTS (1 << 24)
 int x265_hip_cost_batch_device_noalloc(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs);
 
+/* One iteration of the (list, reference) loop of TEncSearch::predInterSearch (source/Lib/TLibEncoder/TEncSearch.cpp:
+ * 2306-2358) per job, on the device from the AMVP candidates to the motion vector:
+ *   1. every AMVP candidate is clipped (TComDataCU::clipMv, TLibCommon/TComDataCU.cpp:2502-2514) and the block
+ *      predicted at it from the reconstructed reference (xPredInterLumaBlk, TComPrediction.cpp:400-433) is compared
+ *      with the source block by SAD (bufSAD); the first minimum is the predictor (TEncSearch.cpp:2315-2336: the rate
+ *      term calcRdSADCost adds is the same for every candidate);
+ *   2. the search window around it: TEncSearch::xSetSearchRange (:2600-2617) with the frame-parallel clamp ref_lag
+ *      (m_refLagPixels, :110: the search range with frame threads, the picture height without);
+ *   3. MotionEstimate::motionEstimate with that predictor, window and the job's candidate vectors (:2340).
+ * What stays with the caller is the control plane around it: TComDataCU::fillMvpCand (the candidates come from
+ * neighbouring CUs' final vectors), the bit counting of xGetBlkBits / BitCost::bitcost / xCheckBestMVP (:2343-2347,
+ * 2565-2598: host floating-point tables over the two candidates, no pixels) and the choice between lists. */
+typedef struct x265_hip_inter_job
+{
+    int32_t fenc_plane;
+    int32_t ref_plane;  /* m_mref[list][ref]: what motionEstimate searches (the weighted copy where there is one) */
+    int32_t pred_plane; /* getRefPic(list, ref)->getPicYuvRec(): what the AMVP candidates are predicted from */
+    int16_t pu_x, pu_y;
+    uint8_t pu_w, pu_h, method, subme;
+    int16_t cu_x, cu_y; /* TComDataCU::getCUPelX / getCUPelY: clipMv is relative to the CU */
+    int16_t amvp[4];    /* AMVPInfo::m_mvCand[0..1], quarter-pel, x,y pairs */
+    int16_t merange;
+    int16_t ref_lag;    /* m_refLagPixels */
+    uint8_t num_amvp;   /* AMVPInfo::m_num: 1 or 2 */
+    uint8_t qp;
+    uint8_t num_mvc;
+    uint8_t pad;
+    int16_t mvc[2 * X265_HIP_MAX_MVC];
+} x265_hip_inter_job;
+
+typedef struct x265_hip_inter_result
+{
+    int32_t cost;       /* what motionEstimate returns */
+    int16_t mvx, mvy;   /* outmv */
+    int32_t amvp_sad[2]; /* bufSAD of the prediction at each clipped candidate (INT32_MAX for an absent one) */
+    int16_t mvmin_x, mvmin_y, mvmax_x, mvmax_y; /* the window of step 2, full-pel */
+    int16_t mvp_x, mvp_y; /* the predictor chosen in step 1 (as given, not clipped) */
+    uint8_t mvp_idx;
+    uint8_t pad[3];
+} x265_hip_inter_result;
+
+/* pic_width / pic_height: SPS picture size in luma samples (clipMv).  The `_device` form keeps an internal array of
+ * n motionEstimate jobs in device memory, grown on demand (so a call with more jobs than any before allocates). */
+int x265_hip_inter_search_batch(x265_hip_ctx *ctx, const x265_hip_inter_job *jobs, int n, int pic_width, int pic_height,
+                                x265_hip_inter_result *results);
+int x265_hip_inter_search_batch_device(x265_hip_ctx *ctx, const void *d_jobs, int n, int pic_width, int pic_height,
+                                       void *d_results);
+
 /* Exhaustive integer-pel search of every square PU (64,32,16,8: 85 per CTU) of the listed 64x64
  * CTUs over [mvmin, mvmax], SAD + mvcost, first minimum in raster order -- the integer stage of
  * motionEstimate with X265_FULL_SEARCH (motion.cpp:997-1032) started from bcost = INT_MAX, with

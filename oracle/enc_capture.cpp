@@ -39,9 +39,9 @@
 #include "lowres.h"
 #include "motion.h"
 #include "bitcost.h"
-#ifdef WITH_HIP
 #include "TLibCommon/TComPic.h"
 #include "TLibCommon/TComDataCU.h"
+#ifdef WITH_HIP
 #include "TLibCommon/TComPrediction.h"
 #endif
 #undef protected
@@ -59,6 +59,13 @@ int real_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const M
             const MV *mvc, int merange, MV &out) asm("__real_" ME_SYM);
 int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp, int numc,
             const MV *mvc, int merange, MV &out) asm("__wrap_" ME_SYM);
+
+/* TComDataCU::fillMvpCand is what predInterSearch calls right in front of the AMVP pick and motionEstimate
+ * (TEncSearch.cpp:2312): its candidates, the CU's position (what clipMv is relative to) and the reconstructed picture
+ * the candidates are predicted from are noted per thread and written out beside the motionEstimate call that follows. */
+#define FM_SYM "_ZN4x26510TComDataCU11fillMvpCandEjjiiPNS_8AMVPInfoEPNS_2MVE"
+int real_fm(TComDataCU *self, uint32_t partIdx, uint32_t partAddr, int picList, int refIdx, AMVPInfo *info, MV *mvc) asm("__real_" FM_SYM);
+int wrap_fm(TComDataCU *self, uint32_t partIdx, uint32_t partAddr, int picList, int refIdx, AMVPInfo *info, MV *mvc) asm("__wrap_" FM_SYM);
 
 #ifdef WITH_HIP
 #define MC_SYM "_ZN4x26514TComPrediction18motionCompensationEPNS_10TComDataCUEPNS_7TComYuvEiibb"
@@ -94,6 +101,26 @@ struct PlaneRec /* header of one snapshot in planes.bin, followed by `bytes` byt
 };
 #pragma pack(pop)
 static_assert(sizeof(CallRec) == 92, "layout read by gen_golden.py");
+#pragma pack(push, 1)
+struct AmvpRec /* amvp.bin: one per CallRec, in the same order (num_amvp 0 for the lookahead's calls) */
+{
+    int32_t pred_plane; /* snapshot id of getRefPic(list, ref)->getPicYuvRec() */
+    int16_t cu_x, cu_y;
+    int16_t amvp[4];
+    uint8_t num_amvp, pad[3];
+};
+#pragma pack(pop)
+static_assert(sizeof(AmvpRec) == 20, "layout read by gen_golden.py");
+struct AmvpNote
+{
+    bool valid;
+    int cu_x, cu_y, num;
+    MV cand[2];
+    const pixel *recon;
+    int recon_stride;
+};
+thread_local AmvpNote t_amvp;
+std::vector<AmvpRec> g_amvp;
 
 struct Snap
 {
@@ -482,6 +509,22 @@ void wrap_mc(TComPrediction *self, TComDataCU *cu, TComYuv *predYuv, int list, i
 }
 #endif
 
+int wrap_fm(TComDataCU *self, uint32_t partIdx, uint32_t partAddr, int picList, int refIdx, AMVPInfo *info, MV *mvc)
+{
+    const int n = real_fm(self, partIdx, partAddr, picList, refIdx, info, mvc);
+    AmvpNote &a = t_amvp;
+    a.valid = true;
+    a.cu_x = (int)self->getCUPelX();
+    a.cu_y = (int)self->getCUPelY();
+    a.num = info->m_num < 2 ? info->m_num : 2;
+    a.cand[0] = info->m_mvCand[0];
+    a.cand[1] = info->m_mvCand[1];
+    TComPicYuv *rec = self->getSlice()->getRefPic(picList, refIdx)->getPicYuvRec();
+    a.recon = rec->getLumaAddr();
+    a.recon_stride = rec->getStride();
+    return n;
+}
+
 int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp, int numc,
             const MV *mvc, int merange, MV &out)
 {
@@ -583,6 +626,18 @@ int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const M
     r.cost = cost;
     r.mvx = out.x, r.mvy = out.y;
     g_calls.push_back(r);
+    AmvpRec ar;
+    memset(&ar, 0, sizeof(ar));
+    if (!low && t_amvp.valid)
+    {
+        const AmvpNote &a = t_amvp;
+        ar.pred_plane = snapshot(a.recon, a.recon_stride, (g_height + 63) / 64 * 64);
+        ar.cu_x = (int16_t)a.cu_x, ar.cu_y = (int16_t)a.cu_y;
+        ar.num_amvp = (uint8_t)a.num;
+        for (int i = 0; i < 2; i++)
+            ar.amvp[2 * i] = a.cand[i].x, ar.amvp[2 * i + 1] = a.cand[i].y;
+    }
+    g_amvp.push_back(ar);
     return cost;
 }
 
@@ -734,6 +789,9 @@ int main(int argc, char **argv)
     fclose(g_planes);
     FILE *out = fopen((dir + "/calls.bin").c_str(), "wb");
     fwrite(g_calls.data(), sizeof(CallRec), g_calls.size(), out);
+    fclose(out);
+    out = fopen((dir + "/amvp.bin").c_str(), "wb");
+    fwrite(g_amvp.data(), sizeof(AmvpRec), g_amvp.size(), out);
     fclose(out);
     fprintf(stderr, "enc_capture: %d pictures in %.2f s, bitstream hash %016llx\n", got,
             (ts1.tv_sec - ts0.tv_sec) + (ts1.tv_nsec - ts0.tv_nsec) * 1e-9, (unsigned long long)hash);

@@ -193,6 +193,11 @@ CAPTURE_CALL = np.dtype([
 assert CAPTURE_CALL.itemsize == 92  # CallRec of oracle/enc_capture.cpp
 
 
+CAPTURE_AMVP = np.dtype([("pred_plane", "<i4"), ("cu_x", "<i2"), ("cu_y", "<i2"), ("amvp", "<i2", (4,)), ("num_amvp", "u1"),
+                         ("pad", "u1", (3,))])
+assert CAPTURE_AMVP.itemsize == 20  # AmvpRec of oracle/enc_capture.cpp
+
+
 def gen_encoder():
     """Route 3 of SURVEY.md 8(c), BASELINE configs[0] at fixture size: the reference ENCODER itself (--preset medium,
     built from its own sources by `make -C oracle capture`) encodes 40 pictures of the 416x240 synthetic sequence;
@@ -230,8 +235,21 @@ def gen_encoder():
     res = np.zeros(len(calls), pyoracle.ME_RESULT)
     res["cost"], res["mvx"], res["mvy"] = calls["cost"], calls["mvx"], calls["mvy"]
     geo = np.array([(len(b), o, s) for (b, o, s) in planes], np.int32)
+    # predInterSearch's (list, reference) iterations: what TComDataCU::fillMvpCand handed it in front of each
+    # full-resolution call (amvp.bin), as x265_hip_inter_job records; the reference's own predictor choice, search
+    # window, cost and vector are what the stage must reproduce (frame threads 1: m_refLagPixels = picture height)
+    amvp = np.fromfile(os.path.join(cap, "amvp.bin"), dtype=CAPTURE_AMVP)
+    assert len(amvp) == len(calls)
+    sel = np.nonzero((calls["lowres"] == 0) & (amvp["num_amvp"] > 0))[0]
+    ij = np.zeros(len(sel), pyoracle.INTER_JOB)
+    for k in ("fenc_plane", "ref_plane", "pu_x", "pu_y", "pu_w", "pu_h", "method", "subme", "merange", "num_mvc", "qp", "mvc"):
+        ij[k] = calls[k][sel]
+    for k in ("pred_plane", "cu_x", "cu_y", "amvp", "num_amvp"):
+        ij[k] = amvp[k][sel]
+    ij["ref_lag"] = H
     np.savez_compressed(os.path.join(OUT, "encoder_me.npz"), jobs=jobs, results=res, plane_geo=geo,
-                        plane_bytes=np.concatenate([b for (b, _, _) in planes]))
+                        plane_bytes=np.concatenate([b for (b, _, _) in planes]), inter_jobs=ij, inter_call=sel.astype(np.int32),
+                        pic_size=np.array([W, H], np.int32))
     print("encoder_me: %d full-resolution + %d lookahead calls, %d planes" % (int((calls["lowres"] == 0).sum()),
                                                                               int(calls["lowres"].sum()), len(planes)))
 
@@ -253,4 +271,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "encoder":
+        gen_encoder()
+    else:
+        main()

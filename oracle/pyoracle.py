@@ -57,6 +57,27 @@ PRED_REQ = np.dtype([
 assert PRED_REQ.itemsize == 28
 
 
+INTER_JOB = np.dtype([
+    ("fenc_plane", "<i4"), ("ref_plane", "<i4"), ("pred_plane", "<i4"),
+    ("pu_x", "<i2"), ("pu_y", "<i2"),
+    ("pu_w", "u1"), ("pu_h", "u1"), ("method", "u1"), ("subme", "u1"),
+    ("cu_x", "<i2"), ("cu_y", "<i2"),
+    ("amvp", "<i2", (4,)),
+    ("merange", "<i2"), ("ref_lag", "<i2"),
+    ("num_amvp", "u1"), ("qp", "u1"), ("num_mvc", "u1"), ("pad", "u1"),
+    ("mvc", "<i2", (2 * MAX_MVC,)),
+])
+assert INTER_JOB.itemsize == 88
+INTER_RESULT = np.dtype([
+    ("cost", "<i4"), ("mvx", "<i2"), ("mvy", "<i2"),
+    ("amvp_sad", "<i4", (2,)),
+    ("mvmin_x", "<i2"), ("mvmin_y", "<i2"), ("mvmax_x", "<i2"), ("mvmax_y", "<i2"),
+    ("mvp_x", "<i2"), ("mvp_y", "<i2"),
+    ("mvp_idx", "u1"), ("pad", "u1", (3,)),
+])
+assert INTER_RESULT.itemsize == 32
+
+
 class _Plane(C.Structure):
     _fields_ = [("origin", C.c_void_p), ("stride", C.c_ssize_t)]
 
@@ -193,6 +214,19 @@ class Checker:
         self._f("me_batch_ops")(self._planes(planes), tabs, _ptr(jobs), C.c_int(len(jobs)), _ptr(out), C.c_int(nthreads), _ptr(ops))
         return out, {"sad_ops": ops[0], "satd_ops": ops[1], "interp_ops": ops[2], "sad_candidates": ops[3],
                      "subpel_candidates": ops[4], "lane_ops": float(ops[:3].sum())}
+
+    def inter_search_batch(self, planes, costtabs, jobs, pic_w, pic_h):
+        """predInterSearch's (list, reference) iteration (oracle only): AMVP pick, search window, motionEstimate"""
+        jobs = np.ascontiguousarray(jobs, dtype=INTER_JOB)
+        out = np.zeros(len(jobs), INTER_RESULT)
+        tabs = (C.c_void_p * 256)()
+        keep = []
+        for qp, t in costtabs.items():
+            t = np.ascontiguousarray(t, np.uint16)
+            keep.append(t)
+            tabs[qp] = t.ctypes.data
+        self._f("inter_search_batch")(self._planes(planes), tabs, _ptr(jobs), C.c_int(len(jobs)), C.c_int(pic_w), C.c_int(pic_h), _ptr(out))
+        return out
 
     def cost_batch(self, planes, reqs, nthreads=1):
         reqs = np.ascontiguousarray(reqs, dtype=COST_REQ)

@@ -1531,6 +1531,67 @@ void x265o_me_batch(const x265o_plane *planes, const uint16_t *const *costtabs, 
     fan_out(me_slice, &a, n, nthreads);
 }
 
+/* ------------------------------------------------------------------------- */
+/* predInterSearch's (list, reference) iteration                              */
+
+/* ref: TComDataCU::clipMv, Lib/TLibCommon/TComDataCU.cpp:2502-2514 (g_maxCUSize 64, offset 8) */
+static void clip_mv(int *qx, int *qy, int cu_x, int cu_y, int pic_w, int pic_h)
+{
+    int xmax = (pic_w + 8 - cu_x - 1) << 2, xmin = (-64 - 8 - cu_x + 1) << 2;
+    int ymax = (pic_h + 8 - cu_y - 1) << 2, ymin = (-64 - 8 - cu_y + 1) << 2;
+    *qx = imin(xmax, *qx > xmin ? *qx : xmin);
+    *qy = imin(ymax, *qy > ymin ? *qy : ymin);
+}
+
+/* ref: TEncSearch::predInterSearch, Lib/TLibEncoder/TEncSearch.cpp:2315-2340 (AMVP pick by least SAD of the clipped
+ * candidates' predictions, first minimum), xSetSearchRange :2600-2617, then motionEstimate */
+void x265o_inter_search_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_inter_job *jobs, int n,
+                              int pic_w, int pic_h, x265o_inter_result *out)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const x265o_inter_job *q = &jobs[i];
+        x265o_inter_result *r = &out[i];
+        memset(r, 0, sizeof(*r));
+        int best = INT_MAX, pick = 0;
+        r->amvp_sad[0] = r->amvp_sad[1] = INT_MAX;
+        for (int k = 0; k < q->num_amvp && k < 2; k++)
+        {
+            int qx = q->amvp[2 * k], qy = q->amvp[2 * k + 1];
+            clip_mv(&qx, &qy, q->cu_x, q->cu_y, pic_w, pic_h);
+            int cost = x265o_subpel_cost(&planes[q->fenc_plane], &planes[q->pred_plane], q->pu_x, q->pu_y, q->pu_w, q->pu_h, qx, qy, X265O_SAD);
+            r->amvp_sad[k] = cost;
+            if (best > cost)
+            {
+                best = cost;
+                pick = k;
+            }
+        }
+        x265o_me_job m;
+        memset(&m, 0, sizeof(m));
+        m.fenc_plane = q->fenc_plane;
+        m.ref_plane = q->ref_plane;
+        m.pu_x = q->pu_x, m.pu_y = q->pu_y, m.pu_w = q->pu_w, m.pu_h = q->pu_h;
+        m.method = q->method, m.subme = q->subme, m.merange = q->merange, m.qp = q->qp, m.num_mvc = q->num_mvc;
+        memcpy(m.mvc, q->mvc, sizeof(m.mvc));
+        m.qmvp_x = q->amvp[2 * pick], m.qmvp_y = q->amvp[2 * pick + 1];
+        int px = m.qmvp_x, py = m.qmvp_y;
+        clip_mv(&px, &py, q->cu_x, q->cu_y, pic_w, pic_h);
+        int d = s16(q->merange << 2);
+        int lox = s16(px - d), loy = s16(py - d), hix = s16(px + d), hiy = s16(py + d);
+        clip_mv(&lox, &loy, q->cu_x, q->cu_y, pic_w, pic_h);
+        clip_mv(&hix, &hiy, q->cu_x, q->cu_y, pic_w, pic_h);
+        m.mvmin_x = (int16_t)(lox >> 2), m.mvmax_x = (int16_t)(hix >> 2);
+        m.mvmin_y = (int16_t)imin(loy >> 2, q->ref_lag), m.mvmax_y = (int16_t)imin(hiy >> 2, q->ref_lag);
+        mv_t mv;
+        r->cost = motion_estimate(&planes[m.fenc_plane], &planes[m.ref_plane], costtabs[m.qp], &m, &mv);
+        r->mvx = mv.x, r->mvy = mv.y;
+        r->mvmin_x = m.mvmin_x, r->mvmin_y = m.mvmin_y, r->mvmax_x = m.mvmax_x, r->mvmax_y = m.mvmax_y;
+        r->mvp_x = m.qmvp_x, r->mvp_y = m.qmvp_y;
+        r->mvp_idx = (uint8_t)pick;
+    }
+}
+
 /* x265o_me_batch plus the work model of the searches: ops5 = { sad lane-ops, satd lane-ops, interpolation lane-ops,
  * full-pel sad candidates, sub-pel (subpelCompare) candidates } summed over the list */
 void x265o_me_batch_ops(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_me_job *jobs, int n,

@@ -116,6 +116,31 @@ int  x265o_subpel_cost(const x265o_plane *fenc, const x265o_plane *ref, int x, i
 
 /* Batched front-ends.  costtabs[qp] points at 65536 entries (centre at +32768).
  * nthreads <= 1 runs inline. */
+/* one (list, reference) iteration of TEncSearch::predInterSearch (TEncSearch.cpp:2306-2358), same layout as
+ * x265_hip_inter_job / x265_hip_inter_result */
+typedef struct x265o_inter_job
+{
+    int32_t fenc_plane, ref_plane, pred_plane;
+    int16_t pu_x, pu_y;
+    uint8_t pu_w, pu_h, method, subme;
+    int16_t cu_x, cu_y;
+    int16_t amvp[4];
+    int16_t merange, ref_lag;
+    uint8_t num_amvp, qp, num_mvc, pad;
+    int16_t mvc[2 * X265O_MAX_MVC];
+} x265o_inter_job;
+typedef struct x265o_inter_result
+{
+    int32_t cost;
+    int16_t mvx, mvy;
+    int32_t amvp_sad[2];
+    int16_t mvmin_x, mvmin_y, mvmax_x, mvmax_y;
+    int16_t mvp_x, mvp_y;
+    uint8_t mvp_idx, pad[3];
+} x265o_inter_result;
+void x265o_inter_search_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_inter_job *jobs, int n,
+                              int pic_w, int pic_h, x265o_inter_result *out);
+
 void x265o_me_batch_ops(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_me_job *jobs, int n,
                         x265o_me_result *out, int nthreads, double *ops5);
 void x265o_cost_batch(const x265o_plane *planes, const x265o_cost_req *reqs, int n, int32_t *out, int nthreads);

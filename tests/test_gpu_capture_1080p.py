@@ -21,6 +21,9 @@ CALL = np.dtype([
     ("lowres", "u1"), ("pad", "u1", (3,)), ("cost", "<i4"), ("mvx", "<i2"), ("mvy", "<i2")])
 
 
+AMVP = np.dtype([("pred_plane", "<i4"), ("cu_x", "<i2"), ("cu_y", "<i2"), ("amvp", "<i2", (4,)), ("num_amvp", "u1"), ("pad", "u1", (3,))])
+
+
 @pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/enc_capture not built (needs the reference sources)")
 def test_reference_encoder_calls_at_1080p_replay_bit_exactly(tmp_path):
     from x265_amd import abi, lib, synth
@@ -59,6 +62,30 @@ def test_reference_encoder_calls_at_1080p_replay_bit_exactly(tmp_path):
     ctx.close()
     bad = np.nonzero((got["cost"] != calls["cost"]) | (got["mvx"] != calls["mvx"]) | (got["mvy"] != calls["mvy"]))[0]
     assert len(bad) == 0, (len(bad), len(calls), calls[bad[0]], got[bad[0]])
+    # the same full-resolution calls one step earlier: from the AMVP candidates TComDataCU::fillMvpCand returned
+    # (amvp.bin) through x265_hip_inter_search_batch, which must pick the predictor the reference picked, get
+    # xSetSearchRange's window and the same (cost, mv)
+    amvp = np.fromfile(tmp_path / "amvp.bin", dtype=AMVP)
+    assert len(amvp) == len(calls)
+    sel = np.nonzero((calls["lowres"] == 0) & (amvp["num_amvp"] > 0))[0]
+    ij = np.zeros(len(sel), abi.INTER_JOB)
+    for k in ("fenc_plane", "ref_plane", "pu_x", "pu_y", "pu_w", "pu_h", "method", "subme", "merange", "num_mvc", "qp", "mvc"):
+        ij[k] = calls[k][sel]
+    for k in ("pred_plane", "cu_x", "cu_y", "amvp", "num_amvp"):
+        ij[k] = amvp[k][sel]
+    ij["ref_lag"] = H  # one frame thread: m_refLagPixels is the picture height (TEncSearch.cpp:110)
+    ctx2 = lib.Context(0)
+    for q in np.unique(calls["qp"]):
+        ctx2.set_qp(int(q))
+    for i, (buf, origin, stride) in enumerate(planes):
+        ctx2.plane_upload(i, buf, stride, origin)
+    out = ctx2.inter_search_batch(ij, W, H)
+    ctx2.close()
+    c = calls[sel]
+    assert len(sel) > 10000 and 500 < (out["mvp_idx"] == 1).sum()
+    assert np.array_equal(out["mvp_x"], c["qmvp_x"]) and np.array_equal(out["mvp_y"], c["qmvp_y"])
+    for k in ("mvmin_x", "mvmin_y", "mvmax_x", "mvmax_y", "cost", "mvx", "mvy"):
+        assert np.array_equal(out[k], c[k]), k
     sizes = {int(s): int((calls["pu_w"][calls["lowres"] == 0] == s).sum()) for s in (8, 16, 32, 64)}
     print(f"{len(calls)} calls of a 1080p medium-preset encode replayed ({int(calls['lowres'].sum())} lookahead; full-resolution "
           f"block sizes {sizes}; QPs {np.unique(calls['qp']).tolist()}), 0 mismatches")

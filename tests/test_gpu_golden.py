@@ -157,6 +157,23 @@ def test_encoder_calls_reproduce_reference_fixture():
     ctx.close()
 
 
+def test_inter_search_stage_reproduces_the_reference_encoder():
+    """x265_hip_inter_search_batch on the predInterSearch iterations captured inside the reference encoder: the AMVP
+    candidate the reference picked, the window xSetSearchRange gave it, and motionEstimate's (cost, mv)"""
+    from test_oracle_golden import check_inter, inter_fixture
+    from x265_amd import abi, lib
+    planes, ij, mej, res, W, H = inter_fixture()
+    ij = ij.view(abi.INTER_JOB)
+    ctx = lib.Context(0)
+    for i, (buf, origin, stride) in enumerate(planes):
+        ctx.plane_upload(i, buf, stride, origin)
+    for q in np.unique(ij["qp"]):
+        ctx.set_qp(int(q))
+    out = ctx.inter_search_batch(ij, W, H)
+    check_inter(out, mej, res)
+    ctx.close()
+
+
 def test_distortions_reproduce_reference_fixtures(gpu_ctx):
     """dist.npz: sa8d_inter / sse_pp / satd / sad of predictions on the golden pictures (gpu_ctx holds them as planes
     0..2), computed by the reference build"""

@@ -663,3 +663,52 @@ def test_me_jobs_that_could_step_outside_a_tight_plane_are_refused(oracle):
     ctx.plane_upload(1, full.buf[:(need_rows - 3) * full.stride], full.stride, full.origin)
     ctx.me_batch(job)
     ctx.close()
+
+
+def test_inter_search_stage_vs_oracle(gpu_ctx, small_seq, costtabs, oracle):
+    """predInterSearch's (list, reference) iteration on the device (AMVP pick, xSetSearchRange, motionEstimate) against
+    the oracle: every partition, all search methods, one or two candidates (equal, near, far, outside the picture so
+    that clipMv acts), a frame-parallel lag clamp, predictions from another plane than the one searched"""
+    from x265_amd import abi
+    rng = np.random.default_rng(99)
+    W, H, n = 416, 240, 3000
+    jobs = np.zeros(n, abi.INTER_JOB)
+    for j in jobs:
+        w, h = abi.PARTS[int(rng.integers(1, 25))]
+        cu = max(w, h) if max(w, h) in (8, 16, 32, 64) else 64
+        cu = 8 if cu < 8 else cu
+        cx = int(rng.integers(0, (W - cu) // 8 + 1)) * 8
+        cy = int(rng.integers(0, (H - cu) // 8 + 1)) * 8
+        j["fenc_plane"], j["ref_plane"] = 1, int(rng.choice([0, 2]))
+        j["pred_plane"] = j["ref_plane"] if rng.integers(3) else int(rng.choice([0, 2]))
+        j["cu_x"], j["cu_y"] = cx, cy
+        j["pu_x"], j["pu_y"] = cx + int(rng.integers(0, (cu - w) // 4 + 1)) * 4, cy + int(rng.integers(0, (cu - h) // 4 + 1)) * 4
+        j["pu_w"], j["pu_h"] = w, h
+        j["method"], j["subme"] = int(rng.integers(0, 4)), int(rng.integers(0, 8))
+        j["merange"] = int(rng.choice([4, 8, 16, 57]))
+        j["ref_lag"] = H if rng.integers(3) else int(rng.choice([8, 16, 57]))
+        j["qp"] = int(rng.integers(20, 45))
+        j["num_amvp"] = 1 + int(rng.integers(0, 4) > 0)
+        kind = int(rng.integers(4))
+        base = (0, 0) if kind == 0 else (int(rng.integers(-40, 40)), int(rng.integers(-40, 40))) if kind == 1 else \
+            (int(rng.integers(-2500, 2500)), int(rng.integers(-1500, 1500)))
+        j["amvp"][0], j["amvp"][1] = base
+        if rng.integers(3):
+            j["amvp"][2], j["amvp"][3] = base[0] + int(rng.integers(-12, 13)), base[1] + int(rng.integers(-12, 13))
+        else:
+            j["amvp"][2], j["amvp"][3] = base
+        nm = int(rng.integers(0, 6))
+        j["num_mvc"] = nm
+        for c in range(nm):
+            j["mvc"][2 * c] = base[0] + int(rng.integers(-30, 30)) if rng.integers(3) else 0
+            j["mvc"][2 * c + 1] = base[1] + int(rng.integers(-30, 30)) if rng.integers(3) else 0
+    got = gpu_ctx.inter_search_batch(jobs, W, H)
+    want = oracle.inter_search_batch([p.as_tuple() for p in small_seq], costtabs, jobs, W, H)
+    assert (got["mvp_idx"] == 1).sum() > 100
+    bad = np.nonzero(got != want.view(got.dtype))[0]
+    assert len(bad) == 0, (len(bad), jobs[bad[0]], got[bad[0]], want[bad[0]])
+    for bad_job, match in ((("num_amvp", 0), "AMVP candidates"), (("pred_plane", 7), "not uploaded")):
+        jb = jobs[:4].copy()
+        jb[bad_job[0]][2] = bad_job[1]
+        with pytest.raises(Exception, match=match):
+            gpu_ctx.inter_search_batch(jb, W, H)

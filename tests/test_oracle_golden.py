@@ -206,6 +206,37 @@ def encoder_fixture():
     return planes, g["jobs"], g["results"]
 
 
+def inter_fixture():
+    """the predInterSearch iterations of encoder_me.npz: x265_hip_inter_job records made from what the reference
+    encoder's TComDataCU::fillMvpCand returned in front of each full-resolution call, and what the reference then did:
+    the predictor it picked (motionEstimate's qmvp), xSetSearchRange's window, cost and vector"""
+    g = np.load(os.path.join(GOLD, "encoder_me.npz"))
+    planes, jobs, res = encoder_fixture()
+    sel = g["inter_call"]
+    return planes, g["inter_jobs"], jobs[sel], res[sel], int(g["pic_size"][0]), int(g["pic_size"][1])
+
+
+def check_inter(out, mej, res):
+    assert np.array_equal(out["mvp_x"], mej["qmvp_x"]) and np.array_equal(out["mvp_y"], mej["qmvp_y"])
+    for k in ("mvmin_x", "mvmin_y", "mvmax_x", "mvmax_y"):
+        assert np.array_equal(out[k], mej[k]), k
+    for k in ("cost", "mvx", "mvy"):
+        assert np.array_equal(out[k], res[k]), k
+
+
+def test_inter_search_iterations_match_the_reference_encoder(oracle):
+    """AMVP pick by least SAD, xSetSearchRange and motionEstimate restated (x265o_inter_search_batch) against the
+    reference encoder's own choices: 2400 iterations, about a quarter of which pick the second candidate"""
+    from oracle import pyoracle
+    planes, ij, mej, res, W, H = inter_fixture()
+    ij = ij.view(pyoracle.INTER_JOB)
+    assert len(ij) == 2400 and (ij["amvp"][:, 0] != ij["amvp"][:, 2]).sum() > 1000
+    tabs = {int(q): oracle.bitcost_table(int(q)) for q in np.unique(ij["qp"])}
+    out = oracle.inter_search_batch(planes, tabs, ij, W, H)
+    assert 200 < (out["mvp_idx"] == 1).sum() < 2200
+    check_inter(out, mej, res)
+
+
 def test_encoder_calls_match_reference_fixture(oracle):
     """what the reference encoder itself asked of motionEstimate and got back: AMVP predictors and candidate lists,
     real search bounds and QPs, reconstructed references, the lookahead's lowres searches"""

@@ -84,3 +84,25 @@ def refine_as_cost_reqs(reqs):
     ndirs = np.where(reqs["pattern"] & RING_8, 8, 4)[:, None]
     used = np.where(k == 0, (reqs["pattern"] & RING_CENTRE)[:, None] != 0, k <= ndirs)
     return out, used
+
+
+# x265_hip_inter_job / x265_hip_inter_result: one (list, reference) iteration of predInterSearch
+INTER_JOB = np.dtype([
+    ("fenc_plane", "<i4"), ("ref_plane", "<i4"), ("pred_plane", "<i4"),
+    ("pu_x", "<i2"), ("pu_y", "<i2"),
+    ("pu_w", "u1"), ("pu_h", "u1"), ("method", "u1"), ("subme", "u1"),
+    ("cu_x", "<i2"), ("cu_y", "<i2"),
+    ("amvp", "<i2", (4,)),
+    ("merange", "<i2"), ("ref_lag", "<i2"),
+    ("num_amvp", "u1"), ("qp", "u1"), ("num_mvc", "u1"), ("pad", "u1"),
+    ("mvc", "<i2", (2 * MAX_MVC,)),
+])
+assert INTER_JOB.itemsize == 88
+INTER_RESULT = np.dtype([
+    ("cost", "<i4"), ("mvx", "<i2"), ("mvy", "<i2"),
+    ("amvp_sad", "<i4", (2,)),
+    ("mvmin_x", "<i2"), ("mvmin_y", "<i2"), ("mvmax_x", "<i2"), ("mvmax_y", "<i2"),
+    ("mvp_x", "<i2"), ("mvp_y", "<i2"),
+    ("mvp_idx", "u1"), ("pad", "u1", (3,)),
+])
+assert INTER_RESULT.itemsize == 32

@@ -81,6 +81,7 @@ struct x265_hip_ctx
     int plane_origin[X265_HIP_MAX_PLANES] = {};
     uint16_t *owned_tab[X265_HIP_MAX_QP] = {};
     Buf in, out;       // staging of the host-array batch calls
+    Buf mejobs;        // motionEstimate jobs made on the device by x265_hip_inter_search_batch (device side only is used)
     Buf prim_a, prim_b; // staging of the primitive thunks
 };
 
@@ -226,7 +227,7 @@ void x265_hip_ctx_destroy(x265_hip_ctx *c)
     for (int i = 0; i < X265_HIP_MAX_QP; i++)
         if (c->owned_tab[i])
             (void)hipFree(c->owned_tab[i]);
-    Buf *bufs[4] = { &c->in, &c->out, &c->prim_a, &c->prim_b };
+    Buf *bufs[5] = { &c->in, &c->out, &c->prim_a, &c->prim_b, &c->mejobs };
     for (Buf *b : bufs)
     {
         if (b->d)
@@ -587,11 +588,9 @@ static int check_displaced(const x265_hip_ctx *c, int id, int x, int y, int w, i
     return check_reach(c, id, bx, by, bx + w, by + h, what, i);
 }
 
-static int check_jobs(const x265_hip_ctx *c, const x265_hip_me_job *jobs, int n)
+static int check_job(const x265_hip_ctx *c, const x265_hip_me_job &j, int i)
 {
-    for (int i = 0; i < n; i++)
     {
-        const x265_hip_me_job &j = jobs[i];
         int r = check_block(c, j.fenc_plane, j.ref_plane, j.pu_w, j.pu_h, "me_job", i);
         if (r)
             return r;
@@ -637,6 +636,17 @@ static int check_jobs(const x265_hip_ctx *c, const x265_hip_me_job *jobs, int n)
     return 0;
 }
 
+static int check_jobs(const x265_hip_ctx *c, const x265_hip_me_job *jobs, int n)
+{
+    for (int i = 0; i < n; i++)
+    {
+        int r = check_job(c, jobs[i], i);
+        if (r)
+            return r;
+    }
+    return 0;
+}
+
 // ---- batched entry points -----------------------------------------------------------------------
 
 int x265_hip_me_batch_device(x265_hip_ctx *c, const void *d_jobs, int n, void *d_results)
@@ -671,6 +681,76 @@ int x265_hip_me_batch(x265_hip_ctx *c, const x265_hip_me_job *jobs, int n, x265_
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(*results), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(results, c->out.h, (size_t)n * sizeof(*results));
+    return X265_HIP_OK;
+}
+
+// ---- predInterSearch's (list, reference) iteration: AMVP pick, search window, motionEstimate -------------------------
+
+int x265_hip_inter_search_batch_device(x265_hip_ctx *c, const void *d_jobs, int n, int pic_w, int pic_h, void *d_results)
+{
+    if (!c || n < 0 || pic_w <= 0 || pic_h <= 0 || (n && (!d_jobs || !d_results)))
+        return fail(X265_HIP_EINVAL, "inter_search_batch_device: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    if (c->mejobs.cap < (size_t)n * sizeof(x265_hip_me_job))
+        HIP_TRY(hipStreamSynchronize(c->stream)); // an earlier launch may still read the buffer that is about to be replaced
+    if ((r = push_tabs(c)) || (r = ensure(c, c->mejobs, (size_t)n * sizeof(x265_hip_me_job))))
+        return r;
+    LAUNCH(launch_inter_search(c->dev_tabs, (const x265_hip_inter_job *)d_jobs, n, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d,
+                               (x265_hip_inter_result *)d_results, c->stream));
+    return X265_HIP_OK;
+}
+
+int x265_hip_inter_search_batch(x265_hip_ctx *c, const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h, x265_hip_inter_result *results)
+{
+    if (!c || n < 0 || pic_w <= 0 || pic_h <= 0 || (n && (!jobs || !results)))
+        return fail(X265_HIP_EINVAL, "inter_search_batch: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++)
+    {
+        const x265_hip_inter_job &q = jobs[i];
+        if (q.num_amvp < 1 || q.num_amvp > 2)
+            return fail(X265_HIP_EINVAL, "inter_job[%d]: %d AMVP candidates (1 or 2)", i, q.num_amvp);
+        if (q.pred_plane < 0 || q.pred_plane >= X265_HIP_MAX_PLANES || !c->host_tabs.planes[q.pred_plane].origin)
+            return fail(X265_HIP_EINVAL, "inter_job[%d]: plane %d not uploaded", i, q.pred_plane);
+        // every search the job can turn into (one per candidate) must pass the checks of a motionEstimate job, and the
+        // candidates' predictions must lie inside the plane they are made from
+        for (int k = 0; k < q.num_amvp; k++)
+        {
+            x265_hip_me_job m;
+            memset(&m, 0, sizeof(m));
+            m.fenc_plane = q.fenc_plane, m.ref_plane = q.ref_plane;
+            m.pu_x = q.pu_x, m.pu_y = q.pu_y, m.pu_w = q.pu_w, m.pu_h = q.pu_h;
+            m.method = q.method, m.subme = q.subme, m.merange = q.merange, m.qp = q.qp, m.num_mvc = q.num_mvc;
+            int lox, loy, hix, hiy;
+            search_window(q.amvp[2 * k], q.amvp[2 * k + 1], q.merange, q.ref_lag, q.cu_x, q.cu_y, pic_w, pic_h, lox, loy, hix, hiy);
+            m.mvmin_x = (int16_t)lox, m.mvmin_y = (int16_t)loy, m.mvmax_x = (int16_t)hix, m.mvmax_y = (int16_t)hiy;
+            int r = check_job(c, m, i);
+            if (r)
+                return r;
+            int qx = q.amvp[2 * k], qy = q.amvp[2 * k + 1];
+            clip_mv(qx, qy, q.cu_x, q.cu_y, pic_w, pic_h);
+            if ((r = check_displaced(c, q.pred_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, qx, qy, "inter_job", i)))
+                return r;
+        }
+    }
+    int r;
+    const size_t ob = (size_t)n * sizeof(*results);
+    if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*jobs))) || (r = ensure(c, c->out, ob)) ||
+        (r = ensure(c, c->mejobs, (size_t)n * sizeof(x265_hip_me_job))))
+        return r;
+    HIP_TRY(hipMemcpyAsync(c->in.d, jobs, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
+    LAUNCH(launch_inter_search(c->dev_tabs, (const x265_hip_inter_job *)c->in.d, n, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d,
+                               (x265_hip_inter_result *)c->out.d, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(results, c->out.h, ob);
     return X265_HIP_OK;
 }
 

@@ -66,6 +66,9 @@ struct PrimAddAvgArgs
 
 void launch_prim_addavg(const PrimAddAvgArgs &a, hipStream_t st);
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st);
+// the steps of predInterSearch in front of motionEstimate, then me_kernel on the jobs they produce (`mejobs`: n records of scratch)
+void launch_inter_search(const DeviceTables *tabs, const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h, x265_hip_me_job *mejobs,
+                         x265_hip_inter_result *out, hipStream_t st);
 // `counters`: X265HIP_COST_COUNTER_BYTES of zeroed device memory owned by the context (two alternating sets of
 // batch counters); `parity` flips with every launch that shares them, and such launches are ordered on one stream
 #define X265HIP_COST_COUNTER_BYTES (2 * 64 * 64)

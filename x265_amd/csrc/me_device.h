@@ -513,6 +513,38 @@ __device__ __forceinline__ int sse_strip(const uint8_t *f, int fstride, const ui
     return acc;
 }
 
+// ---- the caller's window arithmetic (host and device) ------------------------------------------------------
+// TComDataCU::clipMv (reference Lib/TLibCommon/TComDataCU.cpp:2502-2514): quarter-pel in and out, relative to the CU
+// at (cu_x, cu_y) of a pic_w x pic_h picture with 64x64 CTUs
+__host__ __device__ inline void clip_mv(int &qx, int &qy, int cu_x, int cu_y, int pic_w, int pic_h)
+{
+    const int xmax = (pic_w + 8 - cu_x - 1) << 2, xmin = (-64 - 8 - cu_x + 1) << 2;
+    const int ymax = (pic_h + 8 - cu_y - 1) << 2, ymin = (-64 - 8 - cu_y + 1) << 2;
+    qx = qx > xmax ? xmax : qx < xmin ? xmin : qx;
+    qy = qy > ymax ? ymax : qy < ymin ? ymin : qy;
+}
+
+// TEncSearch::xSetSearchRange (reference Lib/TLibEncoder/TEncSearch.cpp:2600-2617): full-pel window around the
+// clipped predictor; MV arithmetic is int16 in the reference (mv.h)
+__host__ __device__ inline void search_window(int mvpx, int mvpy, int merange, int ref_lag, int cu_x, int cu_y, int pic_w, int pic_h,
+                                              int &lox, int &loy, int &hix, int &hiy)
+{
+    clip_mv(mvpx, mvpy, cu_x, cu_y, pic_w, pic_h);
+    const int d = (int16_t)(merange << 2);
+    lox = (int16_t)(mvpx - d);
+    loy = (int16_t)(mvpy - d);
+    hix = (int16_t)(mvpx + d);
+    hiy = (int16_t)(mvpy + d);
+    clip_mv(lox, loy, cu_x, cu_y, pic_w, pic_h);
+    clip_mv(hix, hiy, cu_x, cu_y, pic_w, pic_h);
+    lox >>= 2;
+    loy >>= 2;
+    hix >>= 2;
+    hiy >>= 2;
+    loy = loy < ref_lag ? loy : ref_lag;
+    hiy = hiy < ref_lag ? hiy : ref_lag;
+}
+
 // ---- mvcost -----------------------------------------------------------------------------------
 
 // m_cost[v - mvp]; indices wrap inside the 65536-entry row (the reference reads outside its row

@@ -19,6 +19,7 @@
 // fetches or interpolates its reference tile in registers (me_device.h: full-pel, hpp, vpp, or
 // hps -> vsp over an 11x11 footprint), takes SAD or the 4x4 Hadamard against the PU's source tile
 // (LDS) and adds into the candidate's LDS slot.  Lane c meanwhile fetches candidate c's mv rate.
+#include <stddef.h>
 #include <type_traits>
 
 #include "kernels.h"
@@ -1127,7 +1128,7 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
 #define ME_XCD_CHUNK 1024 // about what one XCD holds at a time (768 waves): measured 16 .. 1024, larger is better
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
-                                                x265_hip_me_result *out)
+                                                x265_hip_me_result *out, int out_stride)
 {
     __shared__ WaveLds lds;
     if ((int)blockIdx.x >= n)
@@ -1151,7 +1152,78 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void me
         wv.lref3 = tabs->planes[j.ref_plane + 3].origin + off;
     }
     load_fenc(wv, fp.origin + (long)j.pu_y * fp.stride + j.pu_x, fp.stride);
-    motion_estimate(wv, j, &out[id]);
+    // results are out_stride bytes apart: 8 for x265_hip_me_result arrays, more when they head a larger record
+    motion_estimate(wv, j, (x265_hip_me_result *)((char *)out + (size_t)id * out_stride));
+}
+
+// The steps of predInterSearch in front of motionEstimate (reference Lib/TLibEncoder/TEncSearch.cpp:2315-2339), one wave
+// per job: the AMVP candidates are clipped and the block predicted at each of them from the reconstructed reference is
+// compared with the source block by SAD (q_eval: the pixels of xPredInterLumaBlk are subpelCompare's); the first
+// minimum is the predictor; xSetSearchRange gives the window.  The wave writes the motionEstimate job for me_kernel,
+// which runs behind it on the same stream, and the front of the result record.
+__global__ __launch_bounds__(64) void inter_prepare_kernel(const DeviceTables *tabs, const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h,
+                                                           x265_hip_me_job *mejobs, x265_hip_inter_result *out)
+{
+    __shared__ WaveLds lds;
+    if ((int)blockIdx.x >= n)
+        return;
+    const int id = xcd_chunked(blockIdx.x, n, ME_XCD_CHUNK);
+    const x265_hip_inter_job &j = jobs[id];
+    Wave wv;
+    wave_init(wv, &lds, j.pu_w, j.pu_h);
+    const PlaneDesc fp = tabs->planes[j.fenc_plane], pp = tabs->planes[j.pred_plane];
+    wv.stride = pp.stride;
+    wv.ref = pp.origin + (long)j.pu_y * pp.stride + j.pu_x;
+    load_fenc(wv, fp.origin + (long)j.pu_y * fp.stride + j.pu_x, fp.stride);
+    const int na = min((int)j.num_amvp, 2);
+    wv.nq = 0;
+    for (int k = 0; k < na; k++)
+    {
+        int qx = j.amvp[2 * k], qy = j.amvp[2 * k + 1];
+        clip_mv(qx, qy, j.cu_x, j.cu_y, pic_w, pic_h);
+        q_push(wv, qx, qy, MV_NONE);
+    }
+    q_eval(wv, X265_HIP_SAD);
+    const int c0 = q_cost(wv, 0), c1 = na > 1 ? q_cost(wv, 1) : 0x7fffffff;
+    const int pick = c1 < c0 ? 1 : 0; // "if (bestCost > cost)": the first minimum
+    const int mvpx = j.amvp[2 * pick], mvpy = j.amvp[2 * pick + 1];
+    int lox, loy, hix, hiy;
+    search_window(mvpx, mvpy, j.merange, j.ref_lag, j.cu_x, j.cu_y, pic_w, pic_h, lox, loy, hix, hiy);
+    if (wv.lane == 0)
+    {
+        x265_hip_me_job m;
+        m.fenc_plane = j.fenc_plane;
+        m.ref_plane = j.ref_plane;
+        m.pu_x = j.pu_x;
+        m.pu_y = j.pu_y;
+        m.pu_w = j.pu_w;
+        m.pu_h = j.pu_h;
+        m.method = j.method;
+        m.subme = j.subme;
+        m.mvmin_x = (int16_t)lox;
+        m.mvmin_y = (int16_t)loy;
+        m.mvmax_x = (int16_t)hix;
+        m.mvmax_y = (int16_t)hiy;
+        m.qmvp_x = (int16_t)mvpx;
+        m.qmvp_y = (int16_t)mvpy;
+        m.merange = j.merange;
+        m.qp = j.qp;
+        m.num_mvc = j.num_mvc;
+        for (int k = 0; k < 2 * X265_HIP_MAX_MVC; k++)
+            m.mvc[k] = j.mvc[k];
+        mejobs[id] = m;
+        x265_hip_inter_result &r = out[id];
+        r.amvp_sad[0] = c0;
+        r.amvp_sad[1] = c1;
+        r.mvmin_x = (int16_t)lox;
+        r.mvmin_y = (int16_t)loy;
+        r.mvmax_x = (int16_t)hix;
+        r.mvmax_y = (int16_t)hiy;
+        r.mvp_x = (int16_t)mvpx;
+        r.mvp_y = (int16_t)mvpy;
+        r.mvp_idx = (uint8_t)pick;
+        r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    }
 }
 
 // Cost requests in batches of `rb` (at most 32, see batch_requests) per wave.  Batches differ sevenfold in
@@ -1663,7 +1735,18 @@ static int cost_blocks(int n, int)
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st)
 {
     if (n > 0)
-        hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, st, tabs, jobs, n, out);
+        hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, st, tabs, jobs, n, out, (int)sizeof(x265_hip_me_result));
+}
+
+void launch_inter_search(const DeviceTables *tabs, const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h, x265_hip_me_job *mejobs,
+                         x265_hip_inter_result *out, hipStream_t st)
+{
+    if (n <= 0)
+        return;
+    hipLaunchKernelGGL(inter_prepare_kernel, dim3(n), dim3(64), 0, st, tabs, jobs, n, pic_w, pic_h, mejobs, out);
+    // (cost, mv) head the result record
+    static_assert(offsetof(x265_hip_inter_result, cost) == 0 && offsetof(x265_hip_inter_result, mvx) == 4, "x265_hip_me_result heads the record");
+    hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, st, tabs, mejobs, n, (x265_hip_me_result *)out, (int)sizeof(x265_hip_inter_result));
 }
 
 void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out, uint32_t *counters, int parity, hipStream_t st)

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from .abi import BIDIR_REQ, COST_REQ, ME_JOB, ME_RESULT, NUM_PARTS, PRED_REQ, REFINE_REQ, RING_COSTS
+from .abi import BIDIR_REQ, COST_REQ, INTER_JOB, INTER_RESULT, ME_JOB, ME_RESULT, NUM_PARTS, PRED_REQ, REFINE_REQ, RING_COSTS
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libx265_hip.so")
@@ -36,6 +36,7 @@ EXPORTS = [
     "x265_hip_bidir_cost_batch", "x265_hip_bidir_cost_batch_device",
     "x265_hip_dist_batch", "x265_hip_dist_batch_device", "x265_hip_predict_batch", "x265_hip_predict_batch_device",
     "x265_hip_cost_batch_device_noalloc", "x265_hip_refine_batch", "x265_hip_refine_batch_device",
+    "x265_hip_inter_search_batch", "x265_hip_inter_search_batch_device",
 ]
 
 
@@ -193,6 +194,16 @@ class Context:
         out = np.zeros(len(reqs), np.int32)
         _check(load().x265_hip_cost_batch(self._h, _p(reqs), C.c_int(len(reqs)), _p(out)))
         return out
+
+    def inter_search_batch(self, jobs, pic_width, pic_height):
+        jobs = np.ascontiguousarray(jobs, INTER_JOB)
+        out = np.zeros(len(jobs), INTER_RESULT)
+        _check(load().x265_hip_inter_search_batch(self._h, _p(jobs), C.c_int(len(jobs)), C.c_int(pic_width), C.c_int(pic_height), _p(out)))
+        return out
+
+    def inter_search_batch_device(self, d_jobs, n, pic_width, pic_height, d_results):
+        _check(load().x265_hip_inter_search_batch_device(self._h, C.c_void_p(d_jobs), C.c_int(n), C.c_int(pic_width),
+                                                         C.c_int(pic_height), C.c_void_p(d_results)))
 
     def refine_batch(self, reqs):
         reqs = np.ascontiguousarray(reqs, REFINE_REQ)
