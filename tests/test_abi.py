@@ -85,14 +85,15 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     costs several KB of HBM writes per motionEstimate call (seen once: 120 bytes per lane, caught by WRITE_SIZE).
     me_kernel is built for six waves per SIMD (80 VGPRs) and may spill a handful of dwords, nothing more; the cost
     kernels spill nothing (cost_kernel at six waves spilled 14 dwords, 100 MB of scratch writes per 1080p launch,
-    and was 8 % slower than at five waves without spills)."""
+    and was 8 % slower than at five waves without spills); refine_kernel at five waves keeps its 32 registers of filtered
+    rows and four rows in flight and spills nine dwords once per strip."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     src = os.path.join(ROOT, "x265_amd", "csrc")
-    allowed = {"me_kernel": 48}
+    allowed = {"me_kernel": 48, "refine_kernel": 48}
     seen = set()
     for name in ("me_kernel.hip", "fullsearch.hip", "refine.hip"):
         out = tmp_path / (name + ".s")

@@ -381,10 +381,22 @@ __device__ __forceinline__ void ref_tile(const uint8_t *ref, int stride, int xf,
 // exactly what the reference's 4x4 / 8x4 grouping yields (pixel.cpp:201-252).  All of it runs on packed
 // 16-bit pairs (|coefficient| <= 16 * 255); the last butterfly stage is folded into
 // |a + b| + |a - b| = 2 * max(|a|, |b|), which also supplies the division by two.
+// the source tile already in registers (one dword per row)
+__device__ __forceinline__ int tile_metric_rows(const uint32_t frow[4], const uint32_t P[4][2], int metric);
+
 template <bool F_GLOBAL = false> // source block in plane memory (true) or wherever `f` points, e.g. LDS (false)
 __device__ __forceinline__ int tile_metric(const uint8_t *f, int fstride, const uint32_t P[4][2], int metric)
 {
-    auto ldf = [&](int y) { return F_GLOBAL ? ld4g(as_global(f) + y * fstride) : ld4u(f + y * fstride); };
+    uint32_t frow[4];
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+        frow[y] = F_GLOBAL ? ld4g(as_global(f) + y * fstride) : ld4u(f + y * fstride);
+    return tile_metric_rows(frow, P, metric);
+}
+
+__device__ __forceinline__ int tile_metric_rows(const uint32_t frow[4], const uint32_t P[4][2], int metric)
+{
+    auto ldf = [&](int y) { return frow[y]; };
     if (metric == X265_HIP_SAD)
     {
         uint32_t acc = 0;

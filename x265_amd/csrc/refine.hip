@@ -31,6 +31,7 @@ namespace x265hip {
 #define RF_PARTS 64
 #define RF_CHUNK 8
 #define RF_MAX_BLOCKS (256 * 5)
+#define RF_AHEAD 4 // reference rows in flight per lane during the horizontal pass
 
 // 9-tap windows of the vertical filter x 16 as int16 pairs, per (fraction, delta): entries 0..4 serve even output
 // rows (C0,C1) (C2,C3) (C4,C5) (C6,C7) (C8,0), entries 5..9 odd ones (0,C0) (C1,C2) (C3,C4) (C5,C6) (C7,C8), where
@@ -70,6 +71,11 @@ __device__ __forceinline__ void ring_strip(gptr_t src, int stride, int fx, int j
 {
     constexpr int NP = 2 * NT + 4; // row pairs: rows 0 .. 4 NT + 7
     uint32_t q[NP][4];
+    // the source strip, fetched once for the three vertical positions and early, so that no comparison waits for it
+    uint32_t frow[4 * NT];
+#pragma unroll
+    for (int y = 0; y < 4 * NT; y++)
+        frow[y] = ld4g(as_global(f) + y * fstride);
     // ---- horizontal pass: rows 2p, 2p + 1 as vertical pairs ---------------------------------------------------------
     if (__ballot(fx != 0) == 0)
     {
@@ -88,19 +94,41 @@ __device__ __forceinline__ void ring_strip(gptr_t src, int stride, int fx, int j
     }
     else
     {
+        // rows are fetched RF_AHEAD ahead of their use as aligned 16-byte pieces (the compiler, left alone, waits for
+        // every load right where it issues it: sixteen exposed latencies per item)
         const uint32_t tlo = k_taps_s8[fx][0], thi = k_taps_s8[fx][1];
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int ROWS = 2 * NP;
+        auto fetch = [&](int r) {
+            const gptr_t p = src + r * stride;
+            return *(const __attribute__((address_space(1))) u32x4 *)(p - ((unsigned)(uintptr_t)p & 3u));
+        };
+        auto hrow = [&](int r, const u32x4 w, int o[4]) {
+            const unsigned sh = (unsigned)(uintptr_t)(src + r * stride) & 3u;
+            const uint32_t d0 = __builtin_amdgcn_alignbyte(w.y, w.x, sh), d1 = __builtin_amdgcn_alignbyte(w.z, w.y, sh),
+                           d2 = __builtin_amdgcn_alignbyte(w.w, w.z, sh);
+            tap8x4<0>(d0 ^ 0x80808080u, d1 ^ 0x80808080u, d2 ^ 0x80808080u, tlo, thi, o);
+        };
+        u32x4 ahead[RF_AHEAD];
+#pragma unroll
+        for (int r = 0; r < RF_AHEAD; r++)
+            ahead[r] = fetch(r);
 #pragma unroll
         for (int p = 0; p < NP; p++)
         {
             int a[4], b[4];
-            uint32_t d0, d1, d2;
-            ld12g(src + (2 * p) * stride, d0, d1, d2);
-            tap8x4<0>(d0 ^ 0x80808080u, d1 ^ 0x80808080u, d2 ^ 0x80808080u, tlo, thi, a);
-            ld12g(src + (2 * p + 1) * stride, d0, d1, d2);
-            tap8x4<0>(d0 ^ 0x80808080u, d1 ^ 0x80808080u, d2 ^ 0x80808080u, tlo, thi, b);
+            const u32x4 wa = ahead[(2 * p) % RF_AHEAD], wb = ahead[(2 * p + 1) % RF_AHEAD];
+            if (2 * p + RF_AHEAD < ROWS)
+                ahead[(2 * p) % RF_AHEAD] = fetch(2 * p + RF_AHEAD);
+            if (2 * p + 1 + RF_AHEAD < ROWS)
+                ahead[(2 * p + 1) % RF_AHEAD] = fetch(2 * p + 1 + RF_AHEAD);
+            __builtin_amdgcn_sched_barrier(0);
+            hrow(2 * p, wa, a);
+            hrow(2 * p + 1, wb, b);
 #pragma unroll
             for (int x = 0; x < 4; x++)
                 q[p][x] = pack_s16(a[x], b[x]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // ---- vertical pass + comparison per vertical position -----------------------------------------------------------
@@ -135,7 +163,7 @@ __device__ __forceinline__ void ring_strip(gptr_t src, int stride, int fx, int j
                 P[y][0] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(p0, lo), hi255));
                 P[y][1] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(p1, lo), hi255));
             }
-            v += tile_metric<true>(f + 4 * t * fstride, fstride, P, metric);
+            v += tile_metric_rows(frow + 4 * t, P, metric);
         }
         if ((jneed >> j) & 1)
             atomicAdd(&cost[sq[j]], v);
