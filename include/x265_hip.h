@@ -316,6 +316,36 @@ int x265_hip_me_batch(x265_hip_ctx *ctx, const x265_hip_me_job *jobs, int n, x26
 int x265_hip_me_batch_device(x265_hip_ctx *ctx, const void *d_jobs, int n, void *d_results);
 int x265_hip_cost_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs);
 
+/* The motion search of a whole lookahead frame cost estimate: what CostEstimate::estimateFrameCost
+ * (source/encoder/slicetype.cpp:1242-1340) has its rows do for one (picture, reference) pair, i.e. for one list of
+ * EstimateRow::estimateCUCost (:1512-1584).  Every 8x8 CU of the half-resolution picture is searched in reverse raster
+ * order; its search bounds are those of :1540-1544, its candidates the vectors just found for the CUs right of it,
+ * below it, below left and below right (:1556-1573), its predictor their median or the single candidate (:1575-1580),
+ * and the search is motionEstimate(ref, mvmin, mvmax, mvp, numc, mvc, merange, outmv) (:1582) on the Lowres reference.
+ * results[(j * height_in_cu + cuy) * width_in_cu + cux] is what the reference leaves in fenc->lowresMvCosts[list][dist]
+ * [cuXY] and fenc->lowresMvs[list][dist][cuXY].  The bidirectional and intra costs of estimateCUCost are separate
+ * requests (x265_hip_bidir_cost_batch with X265_HIP_LOWRES_REF; intra is out of scope).
+ * One launch runs the searches of a batch side by side, one wave per CU row (the reference's processRow, :1458-1499):
+ * a search is a chain of width_in_cu + 2 (height_in_cu - 1) dependent steps whatever the hardware, so throughput
+ * comes from the batch (all the (picture, reference) pairs a slice-type decision needs), not from one pair. */
+typedef struct x265_hip_lookahead_job
+{
+    int32_t fenc_plane; /* lowresPlane[0] of the picture being estimated (frames[b]) */
+    int32_t ref_plane;  /* lowresPlane[0..3] of the reference, or of its weighted copy (wfref0): four consecutive ids */
+    int16_t merange;    /* EstimateRow::m_merange: 16 (slicetype.h:76) */
+    uint8_t method;     /* X265_HIP_HEX in the reference (slicetype.h:73) */
+    uint8_t subme;      /* 1 in the reference (slicetype.h:74) */
+    uint8_t qp;         /* X265_LOOKAHEAD_QP = 12: which uploaded cost table */
+    uint8_t pad[3];
+} x265_hip_lookahead_job;
+
+int x265_hip_lookahead_batch(x265_hip_ctx *ctx, const x265_hip_lookahead_job *jobs, int njobs, int width_in_cu, int height_in_cu,
+                             x265_hip_me_result *results);
+/* device-resident jobs and results, asynchronous on the context stream; the records are the caller's contract.  A
+ * result whose cost is INT32_MAX means the launch gave up waiting (never observed; the host-array form reports it). */
+int x265_hip_lookahead_batch_device(x265_hip_ctx *ctx, const void *d_jobs, int njobs, int width_in_cu, int height_in_cu,
+                                    void *d_results);
+
 /* One ring of the sub-pel refinement of MotionEstimate::motionEstimate (motion.cpp:1047-1119) per request: the costs
  * subpelCompare(ref, centre + square1[i] * step, cmp) (motion.cpp:1126-1164; square1 at :71-73) for i = 1 .. 4 or 1 .. 8,
  * step 2 (half-pel ring) or 1 (quarter-pel ring), and optionally the centre itself (the SATD re-measure of

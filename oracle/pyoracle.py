@@ -78,6 +78,13 @@ INTER_RESULT = np.dtype([
 assert INTER_RESULT.itemsize == 32
 
 
+LOOKAHEAD_JOB = np.dtype([
+    ("fenc_plane", "<i4"), ("ref_plane", "<i4"), ("merange", "<i2"),
+    ("method", "u1"), ("subme", "u1"), ("qp", "u1"), ("pad", "u1", (3,)),
+])
+assert LOOKAHEAD_JOB.itemsize == 16
+
+
 class _Plane(C.Structure):
     _fields_ = [("origin", C.c_void_p), ("stride", C.c_ssize_t)]
 
@@ -226,6 +233,20 @@ class Checker:
             keep.append(t)
             tabs[qp] = t.ctypes.data
         self._f("inter_search_batch")(self._planes(planes), tabs, _ptr(jobs), C.c_int(len(jobs)), C.c_int(pic_w), C.c_int(pic_h), _ptr(out))
+        return out
+
+    def lookahead_batch(self, planes, costtabs, jobs, width_in_cu, height_in_cu, nthreads=1):
+        """whole-frame lookahead searches (oracle only): (n, height_in_cu, width_in_cu) results"""
+        jobs = np.ascontiguousarray(jobs, dtype=LOOKAHEAD_JOB)
+        out = np.zeros((len(jobs), height_in_cu, width_in_cu), ME_RESULT)
+        tabs = (C.c_void_p * 256)()
+        keep = []
+        for qp, t in costtabs.items():
+            t = np.ascontiguousarray(t, np.uint16)
+            keep.append(t)
+            tabs[qp] = t.ctypes.data
+        self._f("lookahead_batch")(self._planes(planes), tabs, _ptr(jobs), C.c_int(len(jobs)), C.c_int(width_in_cu),
+                                   C.c_int(height_in_cu), _ptr(out), C.c_int(nthreads))
         return out
 
     def cost_batch(self, planes, reqs, nthreads=1):

@@ -1592,6 +1592,110 @@ void x265o_inter_search_batch(const x265o_plane *planes, const uint16_t *const *
     }
 }
 
+/* ------------------------------------------------------------------------- */
+/* the lookahead's whole-frame motion search                                   */
+
+/* ref: median / median_mv, encoder/slicetype.cpp:40-55 (int16 arithmetic, branch-free) */
+static int16_t look_median(int16_t a, int16_t b, int16_t c)
+{
+    int16_t t = (int16_t)((a - b) & ((a - b) >> 31));
+    a = (int16_t)(a - t);
+    b = (int16_t)(b + t);
+    b = (int16_t)(b - ((b - c) & ((b - c) >> 31)));
+    b = (int16_t)(b + ((a - b) & ((a - b) >> 31)));
+    return b;
+}
+
+typedef struct
+{
+    const x265o_plane *planes;
+    const uint16_t *const *tabs;
+    const x265o_lookahead_job *jobs;
+    x265o_me_result *out;
+    int w, h, lo, hi;
+} look_arg;
+
+/* ref: EstimateRow::estimateCUCost, encoder/slicetype.cpp:1512-1584, the search of one list: bounds :1540-1544,
+ * candidates from the CUs already estimated :1556-1573, predictor :1575-1580, motionEstimate :1582; the CUs in the order
+ * CostEstimate::processRow's dependencies allow (:1458-1499): reverse raster is one such order */
+static void *look_slice(void *p)
+{
+    look_arg *a = (look_arg *)p;
+    const int W = a->w, H = a->h;
+    for (int i = a->lo; i < a->hi; i++)
+    {
+        const x265o_lookahead_job *lj = &a->jobs[i];
+        x265o_me_result *res = a->out + (size_t)i * W * H;
+        for (int cuy = H - 1; cuy >= 0; cuy--)
+            for (int cux = W - 1; cux >= 0; cux--)
+            {
+                x265o_me_result *mv = res + cuy * W + cux; /* fenc_mv */
+                x265o_me_job j;
+                memset(&j, 0, sizeof(j));
+                j.fenc_plane = lj->fenc_plane;
+                j.ref_plane = lj->ref_plane;
+                j.pu_x = (int16_t)(8 * cux), j.pu_y = (int16_t)(8 * cuy);
+                j.pu_w = j.pu_h = 8;
+                j.method = (uint8_t)(lj->method | X265O_LOWRES_REF);
+                j.subme = lj->subme, j.merange = lj->merange, j.qp = lj->qp;
+                j.mvmin_x = (int16_t)(-cux * 8 - 8), j.mvmin_y = (int16_t)(-cuy * 8 - 8);
+                j.mvmax_x = (int16_t)((W - cux - 1) * 8 + 8), j.mvmax_y = (int16_t)((H - cuy - 1) * 8 + 8);
+                int numc = 0; /* mvc[0] = mvc[2] = 0 by the memset */
+#define MVC(m) (j.mvc[2 * numc] = (m).mvx, j.mvc[2 * numc + 1] = (m).mvy, numc++)
+                if (cux < W - 1)
+                    MVC(mv[1]);
+                if (cuy < H - 1)
+                {
+                    MVC(mv[W]);
+                    if (cux > 0)
+                        MVC(mv[W - 1]);
+                    if (cux < W - 1)
+                        MVC(mv[W + 1]);
+                }
+#undef MVC
+                if (numc <= 1)
+                    j.qmvp_x = j.mvc[0], j.qmvp_y = j.mvc[1];
+                else
+                {
+                    j.qmvp_x = look_median(j.mvc[0], j.mvc[2], j.mvc[4]);
+                    j.qmvp_y = look_median(j.mvc[1], j.mvc[3], j.mvc[5]);
+                }
+                j.num_mvc = (uint8_t)numc;
+                mv_t best;
+                mv->cost = motion_estimate(&a->planes[j.fenc_plane], &a->planes[j.ref_plane], a->tabs[j.qp], &j, &best);
+                mv->mvx = best.x, mv->mvy = best.y;
+            }
+    }
+    return 0;
+}
+
+/* out[(i * height_in_cu + cuy) * width_in_cu + cux]; searches are independent of each other: threads take whole ones */
+void x265o_lookahead_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_lookahead_job *jobs, int n,
+                           int width_in_cu, int height_in_cu, x265o_me_result *out, int nthreads)
+{
+    if (nthreads > n)
+        nthreads = n;
+    if (nthreads < 1)
+        nthreads = 1;
+    pthread_t th[64];
+    look_arg args[64];
+    if (nthreads > 64)
+        nthreads = 64;
+    for (int t = 0; t < nthreads; t++)
+    {
+        look_arg a = { planes, costtabs, jobs, out, width_in_cu, height_in_cu, (int)((int64_t)n * t / nthreads),
+                       (int)((int64_t)n * (t + 1) / nthreads) };
+        args[t] = a;
+        if (nthreads == 1)
+            look_slice(&args[t]);
+        else
+            pthread_create(&th[t], 0, look_slice, &args[t]);
+    }
+    if (nthreads > 1)
+        for (int t = 0; t < nthreads; t++)
+            pthread_join(th[t], 0);
+}
+
 /* x265o_me_batch plus the work model of the searches: ops5 = { sad lane-ops, satd lane-ops, interpolation lane-ops,
  * full-pel sad candidates, sub-pel (subpelCompare) candidates } summed over the list */
 void x265o_me_batch_ops(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_me_job *jobs, int n,

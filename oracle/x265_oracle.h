@@ -141,6 +141,17 @@ typedef struct x265o_inter_result
 void x265o_inter_search_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_inter_job *jobs, int n,
                               int pic_w, int pic_h, x265o_inter_result *out);
 
+/* the motion search of a whole lookahead frame cost estimate, one (picture, reference) pair per job: EstimateRow::
+ * estimateCUCost's list loop (encoder/slicetype.cpp:1540-1584) over every 8x8 CU; same layout as x265_hip_lookahead_job */
+typedef struct x265o_lookahead_job
+{
+    int32_t fenc_plane, ref_plane;
+    int16_t merange;
+    uint8_t method, subme, qp, pad[3];
+} x265o_lookahead_job;
+void x265o_lookahead_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_lookahead_job *jobs, int n,
+                           int width_in_cu, int height_in_cu, x265o_me_result *out, int nthreads);
+
 void x265o_me_batch_ops(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_me_job *jobs, int n,
                         x265o_me_result *out, int nthreads, double *ops5);
 void x265o_cost_batch(const x265o_plane *planes, const x265o_cost_req *reqs, int n, int32_t *out, int nthreads);

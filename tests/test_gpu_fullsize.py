@@ -117,6 +117,36 @@ def test_cost_batch_large_random(hd, oracle):
     assert np.array_equal(got, want)
 
 
+def test_lookahead_whole_1080p_frames(hd, oracle):
+    """the lookahead's frame cost searches at 1080p (960x544 half-resolution planes made on the device, 120 x 68 CUs):
+    twelve (picture, reference) pairs in one launch, every CU of every pair equal to the oracle's"""
+    from x265_amd import abi
+    seq, planes, ctx = hd
+    ctx.set_qp(abi.LOOKAHEAD_QP)
+    low = []
+    for i, p in enumerate(planes):
+        geo = ctx.lowres_init(i, p.w, p.h, 16 + 4 * i)
+        low += oracle.lowres_planes(p.buf, p.origin, p.stride, p.w, p.h)[0]
+    W, H = geo.width // 8, geo.lines // 8
+    assert (W, H) == (120, 68)
+    pairs = [(a, b) for a in range(4) for b in range(4) if a != b]
+    lj = np.zeros(len(pairs), abi.LOOKAHEAD_JOB)
+    lj["fenc_plane"], lj["ref_plane"] = [16 + 4 * a for a, _ in pairs], [16 + 4 * b for _, b in pairs]
+    lj["merange"], lj["method"], lj["subme"], lj["qp"] = 16, abi.HEX, 1, abi.LOOKAHEAD_QP
+    got = ctx.lookahead_batch(lj, W, H)
+    oj = lj.copy()
+    oj["fenc_plane"] -= 16
+    oj["ref_plane"] -= 16
+    want = oracle.lookahead_batch(low, {12: oracle.bitcost_table(12)}, oj, W, H, nthreads=THREADS)
+    bad = np.argwhere(got != want.view(got.dtype))
+    assert len(bad) == 0, (len(bad), bad[0], got[tuple(bad[0])], want[tuple(bad[0])])
+    # the searches follow the synthetic motion (half of it, in quarter samples of the half-resolution picture: x 2)
+    dx, dy = seq.global_motion(3, 2)
+    k = pairs.index((3, 2))
+    hit = (np.abs(got[k]["mvx"] - 2 * dx) <= 4) & (np.abs(got[k]["mvy"] - 2 * dy) <= 4)
+    assert hit.mean() > 0.4
+
+
 @pytest.fixture(scope="module")
 def uhd():
     """four 3840x2160 pictures (plane ids 0..3) with the cost tables of QP 28..39"""

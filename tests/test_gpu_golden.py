@@ -174,6 +174,21 @@ def test_inter_search_stage_reproduces_the_reference_encoder():
     ctx.close()
 
 
+def test_lookahead_frames_reproduce_the_reference_encoder():
+    """x265_hip_lookahead_batch on the lookahead pictures captured inside the reference encoder: the three frame cost
+    estimates the capture holds completely (390 CUs each), every CU's cost and vector as the encoder's own"""
+    from test_oracle_golden import lookahead_fixture
+    from x265_amd import abi, lib
+    planes, lj, W, H, want = lookahead_fixture()
+    ctx = lib.Context(0)
+    for i, (buf, origin, stride) in enumerate(planes):
+        ctx.plane_upload(i, buf, stride, origin)
+    ctx.set_qp(abi.LOOKAHEAD_QP)
+    got = ctx.lookahead_batch(lj.view(abi.LOOKAHEAD_JOB), W, H)
+    assert np.array_equal(got, want.view(got.dtype))
+    ctx.close()
+
+
 def test_distortions_reproduce_reference_fixtures(gpu_ctx):
     """dist.npz: sa8d_inter / sse_pp / satd / sad of predictions on the golden pictures (gpu_ctx holds them as planes
     0..2), computed by the reference build"""

@@ -226,6 +226,59 @@ def test_lowres_planes_and_search(oracle, small_seq, costtabs):
     ctx.close()
 
 
+def test_lookahead_whole_frame_search(oracle, small_seq, costtabs):
+    """x265_hip_lookahead_batch against the oracle's restatement of estimateCUCost's search loop: every ordered pair of
+    the three small pictures (lowres planes made on the device), the reference's settings and a few others, in one
+    launch and one search at a time; every CU's (cost, mv) equal"""
+    from x265_amd import abi, lib
+    ctx = lib.Context(0)
+    low = []
+    for i, p in enumerate(small_seq):
+        ctx.plane_upload(20 + i, p.buf, p.stride, p.origin)
+        geo = ctx.lowres_init(20 + i, p.w, p.h, 4 * i)
+        low += oracle.lowres_planes(p.buf, p.origin, p.stride, p.w, p.h)[0]
+    for q in (12, 33):
+        ctx.costtab_upload(q, oracle.bitcost_table(q))
+    W, H = geo.width // 8, geo.lines // 8
+    jobs = []
+    for a in range(3):
+        for b in range(3):
+            if a != b:
+                jobs.append((4 * a, 4 * b, 16, abi.HEX, 1, 12))
+    jobs += [(0, 4, 16, abi.DIA, 0, 12), (4, 8, 8, abi.UMH, 1, 33), (8, 0, 32, abi.STAR, 2, 12), (0, 8, 16, abi.HEX, 5, 33),
+             (0, 0, 16, abi.HEX, 1, 12)]
+    lj = np.zeros(len(jobs), abi.LOOKAHEAD_JOB)
+    for k, (f, r, merange, method, subme, qp) in enumerate(jobs):
+        lj[k]["fenc_plane"], lj[k]["ref_plane"], lj[k]["merange"] = f, r, merange
+        lj[k]["method"], lj[k]["subme"], lj[k]["qp"] = method, subme, qp
+    want = oracle.lookahead_batch(low, {q: oracle.bitcost_table(q) for q in (12, 33)}, lj, W, H, nthreads=8)
+    assert len(np.unique(want["mvx"])) > 20 and (want["cost"] > 0).any()
+    got = ctx.lookahead_batch(lj, W, H)
+    bad = np.argwhere(got != want.view(got.dtype))
+    assert len(bad) == 0, (len(bad), bad[0], got[tuple(bad[0])], want[tuple(bad[0])])
+    for k in (0, 7, len(lj) - 1):
+        one = ctx.lookahead_batch(lj[k:k + 1], W, H)
+        assert np.array_equal(one[0], got[k])
+    # a picture narrower than the planes: only the CUs asked for are searched, with bounds of that size
+    small = ctx.lookahead_batch(lj[:2], 5, 3)
+    assert np.array_equal(small, oracle.lookahead_batch(low, {12: oracle.bitcost_table(12)}, lj[:2], 5, 3).view(small.dtype))
+    one_cu = ctx.lookahead_batch(lj[:1], 1, 1)
+    assert np.array_equal(one_cu, oracle.lookahead_batch(low, {12: oracle.bitcost_table(12)}, lj[:1], 1, 1).view(one_cu.dtype))
+    assert ctx.lookahead_batch(lj[:0], W, H).shape == (0, H, W)
+    # refused: a picture larger than the planes, a reference without its three half-pel planes, no cost table
+    with pytest.raises(lib.X265HipError, match="outside"):
+        ctx.lookahead_batch(lj[:1], W + 30, H)
+    bad_job = lj[:1].copy()
+    bad_job["ref_plane"] = 20
+    with pytest.raises(lib.X265HipError):
+        ctx.lookahead_batch(bad_job, W, H)
+    bad_job = lj[:1].copy()
+    bad_job["qp"] = 40
+    with pytest.raises(lib.X265HipError, match="cost table"):
+        ctx.lookahead_batch(bad_job, W, H)
+    ctx.close()
+
+
 def test_plane_weight_and_border(oracle, small_seq):
     """x265_hip_plane_weight against weight_pp + extendPicBorder, and x265_hip_plane_extend_border in place on a
     plane whose margins were wiped"""

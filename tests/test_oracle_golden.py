@@ -237,6 +237,46 @@ def test_inter_search_iterations_match_the_reference_encoder(oracle):
     check_inter(out, mej, res)
 
 
+def lookahead_fixture():
+    """the frame cost estimates encoder_me.npz holds completely: (planes, lookahead jobs, width and height in CUs, what
+    the reference encoder's own motionEstimate calls returned for every CU, shaped (n, H, W))"""
+    from oracle import pyoracle
+    g = np.load(os.path.join(GOLD, "encoder_me.npz"))
+    planes, jobs, res = encoder_fixture()
+    jobs = jobs.view(pyoracle.ME_JOB)
+    W, H = (int(g["pic_size"][0]) // 2 + 7) // 8, (int(g["pic_size"][1]) // 2 + 7) // 8
+    low = np.nonzero(jobs["method"] & 0x80)[0]
+    pairs = {}
+    for i in low:
+        pairs.setdefault((int(jobs["fenc_plane"][i]), int(jobs["ref_plane"][i])), []).append(i)
+    lj, want = [], []
+    for (f, r), idx in pairs.items():
+        idx = np.array(idx)
+        if len(idx) != W * H:
+            continue
+        j = jobs[idx]
+        assert (j["method"] == 0x81).all() and (j["subme"] == 1).all() and (j["merange"] == 16).all() and (j["qp"] == 12).all()
+        w = np.zeros((H, W), res.dtype)
+        w[j["pu_y"] // 8, j["pu_x"] // 8] = res[idx]
+        lj.append((f, r))
+        want.append(w)
+    out = np.zeros(len(lj), pyoracle.LOOKAHEAD_JOB)
+    out["fenc_plane"], out["ref_plane"] = [p[0] for p in lj], [p[1] for p in lj]
+    out["merange"], out["method"], out["subme"], out["qp"] = 16, 1, 1, 12
+    return planes, out, W, H, np.stack(want)
+
+
+def test_lookahead_frames_match_the_reference_encoder(oracle):
+    """estimateCUCost's search loop restated (x265o_lookahead_batch: bounds, candidates from the CUs already done, median
+    predictor, motionEstimate) against the frame cost estimates the capture holds completely: every CU's cost and
+    vector as the reference encoder's own calls returned them"""
+    planes, lj, W, H, want = lookahead_fixture()
+    assert len(lj) == 3 and (W, H) == (26, 15)
+    got = oracle.lookahead_batch(planes, {12: oracle.bitcost_table(12)}, lj, W, H)
+    assert np.array_equal(got, want.view(got.dtype))
+    assert len(np.unique(got["mvx"])) > 5
+
+
 def test_encoder_calls_match_reference_fixture(oracle):
     """what the reference encoder itself asked of motionEstimate and got back: AMVP predictors and candidate lists,
     real search bounds and QPs, reconstructed references, the lookahead's lowres searches"""

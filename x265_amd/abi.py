@@ -106,3 +106,11 @@ INTER_RESULT = np.dtype([
     ("mvp_idx", "u1"), ("pad", "u1", (3,)),
 ])
 assert INTER_RESULT.itemsize == 32
+
+# x265_hip_lookahead_job: the motion search of one (picture, reference) pair of a lookahead frame cost estimate
+LOOKAHEAD_JOB = np.dtype([
+    ("fenc_plane", "<i4"), ("ref_plane", "<i4"), ("merange", "<i2"),
+    ("method", "u1"), ("subme", "u1"), ("qp", "u1"), ("pad", "u1", (3,)),
+])
+assert LOOKAHEAD_JOB.itemsize == 16
+LOOKAHEAD_QP = 12  # X265_LOOKAHEAD_QP

@@ -82,6 +82,7 @@ struct x265_hip_ctx
     uint16_t *owned_tab[X265_HIP_MAX_QP] = {};
     Buf in, out;       // staging of the host-array batch calls
     Buf mejobs;        // motionEstimate jobs made on the device by x265_hip_inter_search_batch (device side only is used)
+    Buf look;          // x265_hip_lookahead_batch: row counters (64 bytes per search) behind one status word
     Buf prim_a, prim_b; // staging of the primitive thunks
 };
 
@@ -227,7 +228,7 @@ void x265_hip_ctx_destroy(x265_hip_ctx *c)
     for (int i = 0; i < X265_HIP_MAX_QP; i++)
         if (c->owned_tab[i])
             (void)hipFree(c->owned_tab[i]);
-    Buf *bufs[5] = { &c->in, &c->out, &c->prim_a, &c->prim_b, &c->mejobs };
+    Buf *bufs[6] = { &c->in, &c->out, &c->prim_a, &c->prim_b, &c->mejobs, &c->look };
     for (Buf *b : bufs)
     {
         if (b->d)
@@ -750,6 +751,88 @@ int x265_hip_inter_search_batch(x265_hip_ctx *c, const x265_hip_inter_job *jobs,
                                (x265_hip_inter_result *)c->out.d, c->stream));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(results, c->out.h, ob);
+    return X265_HIP_OK;
+}
+
+// ---- whole-frame lookahead search ----------------------------------------------------------------------------------
+
+#define LOOK_HEAD 64 // bytes in front of the row counters: the status word
+
+static int lookahead_launch(x265_hip_ctx *c, const void *d_jobs, int njobs, int w_cu, int h_cu, void *d_results)
+{
+    int r;
+    const size_t need = LOOK_HEAD + (size_t)njobs * 64;
+    if (c->look.cap < need)
+        HIP_TRY(hipStreamSynchronize(c->stream)); // an earlier launch may still count in the buffer that is about to be replaced
+    if ((r = push_tabs(c)) || (r = ensure(c, c->look, need)))
+        return r;
+    HIP_TRY(hipMemsetAsync(c->look.d, 0, need, c->stream));
+    HIP_TRY(hipMemsetAsync(d_results, 0xff, (size_t)njobs * w_cu * h_cu * sizeof(x265_hip_me_result), c->stream));
+    LAUNCH(launch_lookahead(c->dev_tabs, (const x265_hip_lookahead_job *)d_jobs, njobs, w_cu, h_cu, (uint32_t *)((char *)c->look.d + LOOK_HEAD),
+                            (x265_hip_me_result *)d_results, (int *)c->look.d, c->stream));
+    return 0;
+}
+
+static int lookahead_args(const x265_hip_ctx *c, int njobs, int w_cu, int h_cu, const void *a, const void *b, const char *who)
+{
+    if (!c || njobs < 0 || w_cu < 1 || h_cu < 1 || w_cu > 4096 || h_cu > 4096 || (njobs && (!a || !b)))
+        return fail(X265_HIP_EINVAL, "%s: bad argument", who);
+    if ((long)njobs * h_cu > (1l << 24))
+        return fail(X265_HIP_EINVAL, "%s: %d searches of %d rows are more than one launch takes (2^24 rows)", who, njobs, h_cu);
+    return 0;
+}
+
+int x265_hip_lookahead_batch_device(x265_hip_ctx *c, const void *d_jobs, int njobs, int w_cu, int h_cu, void *d_results)
+{
+    int r = lookahead_args(c, njobs, w_cu, h_cu, d_jobs, d_results, "lookahead_batch_device");
+    if (r || njobs == 0)
+        return r;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    return lookahead_launch(c, d_jobs, njobs, w_cu, h_cu, d_results);
+}
+
+int x265_hip_lookahead_batch(x265_hip_ctx *c, const x265_hip_lookahead_job *jobs, int njobs, int w_cu, int h_cu, x265_hip_me_result *results)
+{
+    int r = lookahead_args(c, njobs, w_cu, h_cu, jobs, results, "lookahead_batch");
+    if (r || njobs == 0)
+        return r;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < njobs; i++)
+    {
+        // every CU's window spans the same samples of the reference, [-8, 8 (W - 1) + 8] x [-8, 8 (H - 1) + 8] for the
+        // block's origin (slicetype.cpp:1540-1544): the four corner CUs are put through the checks of a motionEstimate job
+        for (int corner = 0; corner < 4; corner++)
+        {
+            const int cux = (corner & 1) ? w_cu - 1 : 0, cuy = (corner & 2) ? h_cu - 1 : 0;
+            x265_hip_me_job m;
+            memset(&m, 0, sizeof(m));
+            m.fenc_plane = jobs[i].fenc_plane, m.ref_plane = jobs[i].ref_plane;
+            m.pu_x = (int16_t)(8 * cux), m.pu_y = (int16_t)(8 * cuy), m.pu_w = m.pu_h = 8;
+            m.method = (uint8_t)(jobs[i].method | X265_HIP_LOWRES_REF), m.subme = jobs[i].subme, m.merange = jobs[i].merange, m.qp = jobs[i].qp;
+            m.mvmin_x = (int16_t)(-8 * cux - 8), m.mvmin_y = (int16_t)(-8 * cuy - 8);
+            m.mvmax_x = (int16_t)((w_cu - cux - 1) * 8 + 8), m.mvmax_y = (int16_t)((h_cu - cuy - 1) * 8 + 8);
+            if (jobs[i].method & X265_HIP_LOWRES_REF)
+                return fail(X265_HIP_EINVAL, "lookahead_job[%d]: method %d (the Lowres flag is implied)", i, jobs[i].method);
+            if ((r = check_job(c, m, i)))
+                return r;
+        }
+    }
+    const size_t ncu = (size_t)njobs * w_cu * h_cu, ob = ncu * sizeof(*results);
+    if ((r = ensure(c, c->in, (size_t)njobs * sizeof(*jobs))) || (r = ensure(c, c->out, ob)))
+        return r;
+    HIP_TRY(hipMemcpyAsync(c->in.d, jobs, (size_t)njobs * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
+    if ((r = lookahead_launch(c, c->in.d, njobs, w_cu, h_cu, c->out.d)))
+        return r;
+    int status = 0;
+    HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->look.h, c->look.d, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    status = *(const int *)c->look.h;
+    if (status)
+        return fail(X265_HIP_ERUNTIME, "lookahead_batch: a row gave up waiting for the row below it");
     memcpy(results, c->out.h, ob);
     return X265_HIP_OK;
 }

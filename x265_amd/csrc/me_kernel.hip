@@ -337,7 +337,8 @@ enum State
     ST_RASTER, ST_POST, ST_HPEL, ST_REM, ST_QPEL_BEGIN, ST_QPEL, ST_LOWRES_HPEL, ST_LOWRES_QPEL, ST_DONE
 };
 
-__device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_result *out)
+// (cost, vector) come back wave-uniform in rcost / rmx / rmy
+__device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_job &j, int &rcost, int &rmx, int &rmy)
 {
     // integer-stage state, all wave-uniform
     const int lox = j.mvmin_x, loy = j.mvmin_y, hix = j.mvmax_x, hiy = j.mvmax_y; // full-pel, inclusive
@@ -1116,6 +1117,15 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
         }
     }
 #undef IN_RANGE
+    rcost = bcost;
+    rmx = bx;
+    rmy = by;
+}
+
+__device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_result *out)
+{
+    int bcost, bx, by;
+    motion_estimate_uv(wv, j, bcost, bx, by);
     if (wv.lane == 0)
     {
         out->cost = bcost;
@@ -1223,6 +1233,184 @@ __global__ __launch_bounds__(64) void inter_prepare_kernel(const DeviceTables *t
         r.mvp_y = (int16_t)mvpy;
         r.mvp_idx = (uint8_t)pick;
         r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    }
+}
+
+// ---- whole-frame lookahead search (x265_hip_lookahead_batch) ----------------------------------------------------------
+// CostEstimate::estimateFrameCost's motion search of one (picture, reference) pair: every 8x8 CU of the half-resolution
+// picture, in reverse raster order, with the predictor and the candidates taken from the CUs already estimated
+// (EstimateRow::estimateCUCost, reference encoder/slicetype.cpp:1540-1582).  CU (x, y) needs (x + 1, y), (x, y + 1),
+// (x - 1, y + 1) and (x + 1, y + 1): a row is a chain from right to left, and a row can follow the row below it two
+// CUs behind -- the reference runs one pool job per row that way (CostEstimate::processRow, :1458-1499).  Here one
+// wave takes a row.  Its own previous vector and the two vectors of the row below that it has already seen stay in
+// registers; the only thing it waits for is the (cost, vector) word of CU (x - 1, y + 1), which the wave of the row
+// below publishes with one 8-byte store.  That word is asked for one CU ahead (the load flies during the search), as
+// is the next CU's source block, so a step of the chain is the latency of one search.
+// Result words start as all ones (the launch clears them so): a cost of -1 reads "not there yet".
+// Rows are handed out through one counter per search, bottom row first, so a wave only ever waits for waves that
+// took their rows before it did and are therefore running or done: every wave reaches its exit.  A wave that polls
+// LOOK_SPIN_LIMIT times in vain (never seen) raises status[0], fills the rest of its row with INT32_MAX and leaves.
+#define LOOK_SPIN_LIMIT (1 << 22)
+
+typedef unsigned long long look_word; // x265_hip_me_result as one word: cost in the low half, then mvx, mvy
+
+__device__ __forceinline__ look_word look_load(const look_word *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int look_median(int a, int b, int c) // median(), slicetype.cpp:40-49
+{
+    return max(min(a, b), min(max(a, b), c));
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lookahead_kernel(const DeviceTables *tabs, const x265_hip_lookahead_job *jobs,
+                                                                                               int njobs, int W, int H, uint32_t *tickets,
+                                                                                               look_word *results, int *status)
+{
+    __shared__ WaveLds lds;
+    __shared__ x265_hip_me_job jl;
+    const int job = blockIdx.x % njobs;
+    const int lane = threadIdx.x & 63;
+    int ticket = 0;
+    if (lane == 0)
+        ticket = (int)atomicAdd(&tickets[job * 16], 1u);
+    ticket = uniform(ticket);
+    if (ticket >= H)
+        return;
+    const int cuy = H - 1 - ticket;
+    const x265_hip_lookahead_job &lj = jobs[job];
+    Wave wv;
+    wave_init(wv, &lds, 8, 8);
+    const PlaneDesc fp = tabs->planes[lj.fenc_plane], rp = tabs->planes[lj.ref_plane];
+    const uint8_t *const r1 = tabs->planes[lj.ref_plane + 1].origin, *const r2 = tabs->planes[lj.ref_plane + 2].origin,
+                  *const r3 = tabs->planes[lj.ref_plane + 3].origin;
+    wv.stride = rp.stride;
+    wv.tab = tabs->costtab[lj.qp];
+    wv.lowres = true;
+    if (lane == 0)
+    {
+        jl.fenc_plane = lj.fenc_plane;
+        jl.ref_plane = lj.ref_plane;
+        jl.pu_w = jl.pu_h = 8;
+        jl.method = lj.method | X265_HIP_LOWRES_REF;
+        jl.subme = lj.subme;
+        jl.merange = lj.merange;
+        jl.qp = lj.qp;
+        jl.pu_y = (int16_t)(8 * cuy);
+        jl.mvmin_y = (int16_t)(-8 * cuy - 8);
+        jl.mvmax_y = (int16_t)((H - cuy - 1) * 8 + 8);
+    }
+    look_word *const mine = results + ((size_t)job * H + cuy) * W;
+    const look_word *const below = mine + W; // only read when cuy < H - 1
+    const bool has_below = cuy < H - 1;
+    int spins = 0;
+    bool dead = false;
+    // the vector of a CU of the row below, x | y << 16, once it is there
+    auto wait_mv = [&](int cux, look_word v) {
+        while ((int)(uint32_t)v == -1)
+        {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > LOOK_SPIN_LIMIT || (!(spins & 1023) && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+            {
+                dead = true;
+                return 0;
+            }
+            v = look_load(&below[cux]);
+        }
+        return (int)(uint32_t)(v >> 32);
+    };
+    // source block of CU cux: lanes 0..15 hold one dword each (row lane / 2, half lane & 1)
+    const uint8_t *const frow = fp.origin + (long)(8 * cuy) * fp.stride;
+    auto fetch_fenc = [&](int cux) {
+        return lane < 16 ? ld4g(as_global(frow) + (lane >> 1) * fp.stride + 8 * cux + 4 * (lane & 1)) : 0u;
+    };
+    uint32_t fnext = fetch_fenc(W - 1);
+    int right = 0, b_c = 0, b_r = 0, b_l = 0; // (x + 1, y), (x, y + 1), (x + 1, y + 1), (x - 1, y + 1)
+    if (has_below)
+    {
+        b_c = wait_mv(W - 1, look_load(&below[W - 1]));
+        if (W > 1 && !dead)
+            b_l = wait_mv(W - 2, look_load(&below[W - 2]));
+    }
+    for (int cux = W - 1; cux >= 0 && !dead; cux--)
+    {
+        // next step's word of the row below and source block: in flight during this search
+        const bool want_next = has_below && cux >= 2;
+        look_word vnext = ~0ull;
+        if (want_next)
+            vnext = look_load(&below[cux - 2]);
+        if (lane < 16)
+            *(uint32_t *)(lds.fenc + (lane >> 1) * 64 + 4 * (lane & 1)) = fnext;
+        if (cux > 0)
+            fnext = fetch_fenc(cux - 1);
+        // Reverse-order MV prediction (slicetype.cpp:1556-1580): mvc[0] and mvc[2] start as zero
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0, numc = 0;
+        auto push = [&](int v) {
+            if (numc == 0)
+                c0 = v;
+            else if (numc == 1)
+                c1 = v;
+            else if (numc == 2)
+                c2 = v;
+            else
+                c3 = v;
+            numc++;
+        };
+        if (cux < W - 1)
+            push(right);
+        if (has_below)
+        {
+            push(b_c);
+            if (cux > 0)
+                push(b_l);
+            if (cux < W - 1)
+                push(b_r);
+        }
+        int mvpx = (int16_t)c0, mvpy = c0 >> 16;
+        if (numc > 1)
+        {
+            mvpx = look_median((int16_t)c0, (int16_t)c1, (int16_t)c2);
+            mvpy = look_median(c0 >> 16, c1 >> 16, c2 >> 16);
+        }
+        if (lane == 0)
+        {
+            jl.pu_x = (int16_t)(8 * cux);
+            jl.mvmin_x = (int16_t)(-8 * cux - 8);
+            jl.mvmax_x = (int16_t)((W - cux - 1) * 8 + 8);
+            jl.qmvp_x = (int16_t)mvpx;
+            jl.qmvp_y = (int16_t)mvpy;
+            jl.num_mvc = (uint8_t)numc;
+            jl.mvc[0] = (int16_t)c0, jl.mvc[1] = (int16_t)(c0 >> 16);
+            jl.mvc[2] = (int16_t)c1, jl.mvc[3] = (int16_t)(c1 >> 16);
+            jl.mvc[4] = (int16_t)c2, jl.mvc[5] = (int16_t)(c2 >> 16);
+            jl.mvc[6] = (int16_t)c3, jl.mvc[7] = (int16_t)(c3 >> 16);
+        }
+        const long off = (long)(8 * cuy) * rp.stride + 8 * cux;
+        wv.ref = rp.origin + off;
+        wv.lref1 = r1 + off;
+        wv.lref2 = r2 + off;
+        wv.lref3 = r3 + off;
+        wv.mvpx = mvpx;
+        wv.mvpy = mvpy;
+        wave_sync();
+        int cost, mx, my;
+        motion_estimate_uv(wv, jl, cost, mx, my);
+        right = (int)((uint32_t)(mx & 0xffff) | ((uint32_t)my << 16));
+        if (lane == 0)
+            __hip_atomic_store(&mine[cux], (look_word)(uint32_t)cost | ((look_word)(uint32_t)right << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b_r = b_c;
+        b_c = b_l;
+        if (want_next)
+            b_l = wait_mv(cux - 2, vnext);
+        wave_sync(); // the search's last LDS reads are over before the next block is written
+    }
+    if (dead && lane == 0)
+    {
+        __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int x = W - 1; x >= 0; x--)
+            if ((int)(uint32_t)look_load(&mine[x]) == -1)
+                __hip_atomic_store(&mine[x], (look_word)0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1747,6 +1935,16 @@ void launch_inter_search(const DeviceTables *tabs, const x265_hip_inter_job *job
     // (cost, mv) head the result record
     static_assert(offsetof(x265_hip_inter_result, cost) == 0 && offsetof(x265_hip_inter_result, mvx) == 4, "x265_hip_me_result heads the record");
     hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, st, tabs, mejobs, n, (x265_hip_me_result *)out, (int)sizeof(x265_hip_inter_result));
+}
+
+void launch_lookahead(const DeviceTables *tabs, const x265_hip_lookahead_job *jobs, int njobs, int w_cu, int h_cu, uint32_t *tickets,
+                      x265_hip_me_result *results, int *status, hipStream_t st)
+{
+    static_assert(sizeof(x265_hip_me_result) == sizeof(look_word) && offsetof(x265_hip_me_result, cost) == 0 &&
+                      offsetof(x265_hip_me_result, mvx) == 4 && offsetof(x265_hip_me_result, mvy) == 6,
+                  "a result is published as one 8-byte word");
+    if (njobs > 0)
+        hipLaunchKernelGGL(lookahead_kernel, dim3(njobs * h_cu), dim3(64), 0, st, tabs, jobs, njobs, w_cu, h_cu, tickets, (look_word *)results, status);
 }
 
 void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out, uint32_t *counters, int parity, hipStream_t st)

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from .abi import BIDIR_REQ, COST_REQ, INTER_JOB, INTER_RESULT, ME_JOB, ME_RESULT, NUM_PARTS, PRED_REQ, REFINE_REQ, RING_COSTS
+from .abi import BIDIR_REQ, COST_REQ, INTER_JOB, INTER_RESULT, LOOKAHEAD_JOB, ME_JOB, ME_RESULT, NUM_PARTS, PRED_REQ, REFINE_REQ, RING_COSTS
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libx265_hip.so")
@@ -37,6 +37,7 @@ EXPORTS = [
     "x265_hip_dist_batch", "x265_hip_dist_batch_device", "x265_hip_predict_batch", "x265_hip_predict_batch_device",
     "x265_hip_cost_batch_device_noalloc", "x265_hip_refine_batch", "x265_hip_refine_batch_device",
     "x265_hip_inter_search_batch", "x265_hip_inter_search_batch_device",
+    "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device",
 ]
 
 
@@ -200,6 +201,17 @@ class Context:
         out = np.zeros(len(jobs), INTER_RESULT)
         _check(load().x265_hip_inter_search_batch(self._h, _p(jobs), C.c_int(len(jobs)), C.c_int(pic_width), C.c_int(pic_height), _p(out)))
         return out
+
+    def lookahead_batch(self, jobs, width_in_cu, height_in_cu):
+        """(n, height_in_cu, width_in_cu) results: the whole-frame searches of the lookahead"""
+        jobs = np.ascontiguousarray(jobs, LOOKAHEAD_JOB)
+        out = np.zeros((len(jobs), height_in_cu, width_in_cu), ME_RESULT)
+        _check(load().x265_hip_lookahead_batch(self._h, _p(jobs), C.c_int(len(jobs)), C.c_int(width_in_cu), C.c_int(height_in_cu), _p(out)))
+        return out
+
+    def lookahead_batch_device(self, d_jobs, n, width_in_cu, height_in_cu, d_results):
+        _check(load().x265_hip_lookahead_batch_device(self._h, C.c_void_p(d_jobs), C.c_int(n), C.c_int(width_in_cu),
+                                                      C.c_int(height_in_cu), C.c_void_p(d_results)))
 
     def inter_search_batch_device(self, d_jobs, n, pic_width, pic_height, d_results):
         _check(load().x265_hip_inter_search_batch_device(self._h, C.c_void_p(d_jobs), C.c_int(n), C.c_int(pic_width),
