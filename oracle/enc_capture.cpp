@@ -20,8 +20,14 @@
  *   X265_USE_HIP_ME=1      every MotionEstimate::motionEstimate call, the lookahead's included -> x265_hip_me_batch
  *   X265_USE_HIP_MC=1      the luma block of every TComPrediction::motionCompensation call -> x265_hip_predict_batch
  *   X265_USE_HIP_PLANES=1  Lowres::init -> x265_hip_lowres_init, MotionReference::applyWeight -> x265_hip_plane_weight
+ *   X265_USE_HIP_LOOKAHEAD=1|2  the lookahead's motion search a whole frame at a time: the first lowres motionEstimate call
+ *                          of a frame cost estimate's list (CU (W-1, H-1), slicetype.cpp:1458-1499) runs
+ *                          x265_hip_lookahead_batch for the (picture, reference) pair, and this and every later call of
+ *                          the pair is answered from its results.  1: the reference's own search also runs and is
+ *                          compared; 2: it does not run at all (timing).
  * All four member functions are intercepted with ld --wrap; the bitstream hash printed at the end must not change.
  */
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <stdint.h>
@@ -303,6 +309,90 @@ int device_low_ref(pixel *const planes[4], int stride, int lines)
 #endif
 
 #ifdef WITH_HIP
+/* X265_USE_HIP_LOOKAHEAD: whole-frame lookahead searches (see the head of this file) */
+namespace {
+int g_hip_look = 0;
+long g_look_frames = 0, g_look_mismatch = 0;
+std::atomic<long> g_look_calls(0);
+double g_look_seconds = 0;
+std::map<std::pair<const void *, const void *>, std::vector<x265_hip_me_result> > g_look;
+
+int look_answer(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp, int numc, const MV *mvc,
+                int merange, MV &out)
+{
+    const int stride = (int)self->fencLumaStride;
+    /* Lookahead::Lookahead, slicetype.cpp:62-63; Lowres::create, lowres.cpp:33-48 */
+    const int W = ((g_width / 2) + 7) >> 3, H = ((g_height / 2) + 7) >> 3, lines = ((g_height / 2) + 7) / 8 * 8;
+    const int cux = (int)(self->blockOffset % stride) / 8, cuy = (int)(self->blockOffset / stride) / 8;
+    const std::pair<const void *, const void *> key((const void *)self->fencplane, (const void *)ref);
+    /* A pair's results are looked up under the lock once per thread and search: the vector a pair's results live in
+     * is never reallocated (its size is the picture's), and a pair is searched again only after the encoder has
+     * finished the estimate that used the previous results. */
+    static thread_local std::pair<const void *, const void *> t_key;
+    static thread_local const x265_hip_me_result *t_res = nullptr;
+    if (cux == W - 1 && cuy == H - 1)
+    {
+        std::lock_guard<std::mutex> g(g_mu);
+        x265_hip_lookahead_job j;
+        memset(&j, 0, sizeof(j));
+        j.fenc_plane = device_low_src(self->fencplane, stride, lines);
+        j.ref_plane = device_low_ref(ref->lowresPlane, ref->lumaStride, lines);
+        j.merange = (int16_t)merange;
+        j.method = (uint8_t)self->searchMethod;
+        j.subme = (uint8_t)self->subpelRefine;
+        j.qp = (uint8_t)qp_of(self->m_cost);
+        if (!g_qp_set[1][j.qp])
+        {
+            x265_hip_costtab_set_qp(g_ctx_low, j.qp);
+            g_qp_set[1][j.qp] = true;
+        }
+        std::vector<x265_hip_me_result> &v = g_look[key];
+        v.resize((size_t)W * H);
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        if (x265_hip_lookahead_batch(g_ctx_low, &j, 1, W, H, v.data()) != X265_HIP_OK)
+        {
+            fprintf(stderr, "lookahead_batch: %s\n", x265_hip_last_error());
+            abort();
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        g_look_seconds += (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+        g_look_frames++;
+        t_key = key;
+        t_res = v.data();
+    }
+    else if (!t_res || t_key != key)
+    {
+        std::lock_guard<std::mutex> g(g_mu);
+        std::map<std::pair<const void *, const void *>, std::vector<x265_hip_me_result> >::iterator it = g_look.find(key);
+        if (it == g_look.end())
+        {
+            fprintf(stderr, "enc_capture: lowres call for CU (%d, %d) before the frame's first CU\n", cux, cuy);
+            abort();
+        }
+        t_key = key;
+        t_res = it->second.data();
+    }
+    const x265_hip_me_result r = t_res[(size_t)cuy * W + cux];
+    g_look_calls++;
+    if (g_hip_look == 1)
+    {
+        MV own;
+        const int cost = real_me(self, ref, mvmin, mvmax, qmvp, numc, mvc, merange, own);
+        if (cost != r.cost || own.x != r.mvx || own.y != r.mvy)
+        {
+            std::lock_guard<std::mutex> g(g_mu);
+            g_look_mismatch++;
+        }
+    }
+    out.x = r.mvx;
+    out.y = r.mvy;
+    return r.cost;
+}
+} // namespace
+#endif
+
+#ifdef WITH_HIP
 /* X265_USE_HIP_PLANES=1: the planes the encoder produces for the search are produced again on the device, compared
  * with the reference's and written over them: the four lookahead planes of every Lowres::init (lowres.cpp:129-175)
  * by x265_hip_lowres_init, and every weighted reference plane MotionReference::applyWeight completes
@@ -528,6 +618,10 @@ int wrap_fm(TComDataCU *self, uint32_t partIdx, uint32_t partAddr, int picList, 
 int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp, int numc,
             const MV *mvc, int merange, MV &out)
 {
+#ifdef WITH_HIP
+    if (g_hip_look && ref->isLowres)
+        return look_answer(self, ref, mvmin, mvmax, qmvp, numc, mvc, merange, out);
+#endif
     int cost = real_me(self, ref, mvmin, mvmax, qmvp, numc, mvc, merange, out);
     std::lock_guard<std::mutex> g(g_mu);
 #ifdef WITH_HIP
@@ -721,7 +815,19 @@ int main(int argc, char **argv)
         g_hip_mc = g_hip_sparse = true;
         fprintf(stderr, "enc_capture: motionCompensation (luma) answered by x265_hip_predict_batch\n");
     }
-    if (getenv("X265_USE_HIP_ME"))
+    if (getenv("X265_USE_HIP_LOOKAHEAD"))
+    {
+        if (x265_hip_ctx_create(0, &g_ctx_low) != X265_HIP_OK)
+        {
+            fprintf(stderr, "x265_hip_ctx_create: %s\n", x265_hip_last_error());
+            return 1;
+        }
+        g_hip_look = atoi(getenv("X265_USE_HIP_LOOKAHEAD")) == 2 ? 2 : 1;
+        g_hip_sparse = true;
+        fprintf(stderr, "enc_capture: the lookahead's motion searches answered a frame at a time by x265_hip_lookahead_batch%s\n",
+                g_hip_look == 2 ? " (the reference's own search does not run)" : "");
+    }
+    if (getenv("X265_USE_HIP_ME") && !g_hip_look)
     {
         if ((!g_ctx && x265_hip_ctx_create(0, &g_ctx) != X265_HIP_OK) || x265_hip_ctx_create(0, &g_ctx_low) != X265_HIP_OK)
         {
@@ -802,6 +908,10 @@ int main(int argc, char **argv)
     if (g_hip_mc)
         fprintf(stderr, "enc_capture: %ld motionCompensation luma blocks predicted on the GPU (%ld weighted, %ld bi-directional), %ld differed from the reference's own pixels, %ld left alone\n",
                 g_mc_calls, g_mc_weighted, g_mc_bi, g_mc_mismatch, g_mc_skipped);
+    if (g_hip_look)
+        fprintf(stderr, "enc_capture: %ld lookahead frame searches on the GPU in %.3f s (%.3f ms each, upload and download included), %ld lowres motionEstimate calls answered from them, %ld differed from the reference's own answer%s\n",
+                g_look_frames, g_look_seconds, g_look_frames ? 1e3 * g_look_seconds / g_look_frames : 0.0, g_look_calls.load(), g_look_mismatch,
+                g_hip_look == 2 ? " (not compared in this mode)" : "");
     if (g_hip_me)
     {
         fprintf(stderr, "enc_capture: %ld motionEstimate calls answered on the GPU, %ld differed from the reference's own answer\n",

@@ -89,3 +89,39 @@ def test_reference_encoder_calls_at_1080p_replay_bit_exactly(tmp_path):
     sizes = {int(s): int((calls["pu_w"][calls["lowres"] == 0] == s).sum()) for s in (8, 16, 32, 64)}
     print(f"{len(calls)} calls of a 1080p medium-preset encode replayed ({int(calls['lowres'].sum())} lookahead; full-resolution "
           f"block sizes {sizes}; QPs {np.unique(calls['qp']).tolist()}), 0 mismatches")
+
+
+ENC_HIP = os.path.join(ROOT, "oracle", "_ref", "enc_hip")
+
+
+@pytest.mark.skipif(not os.path.exists(ENC_HIP), reason="oracle/_ref/enc_hip not built (needs the reference sources)")
+@pytest.mark.parametrize("fade", [False, True])
+def test_whole_frame_lookahead_inside_the_reference_encoder(tmp_path, fade):
+    """the reference encoder with every lookahead frame cost search done by one x265_hip_lookahead_batch launch
+    (X265_USE_HIP_LOOKAHEAD=1: each of its lowres motionEstimate calls is answered from the launch's results and also
+    run by the reference itself and compared): no call may differ and the bitstream must be the one the unmodified
+    encoder writes; with `fade` the clip fades to black so that the lookahead searches weighted references"""
+    import re
+    from x265_amd import synth
+    W, H, N = 640, 360, 12
+    seq = synth.Sequence(W, H, seed=11, n_patches=3)
+    clip = tmp_path / "in.yuv"
+    with open(clip, "wb") as f:
+        for i in range(N):
+            y = seq.frame(i).astype(np.float64)
+            if fade and i >= N // 3:
+                y = y * max(0.15, 1.0 - 0.05 * (i - N // 3)) + 0.5
+            f.write(np.clip(y, 0, 255).astype(np.uint8).tobytes())
+            f.write(bytes([128]) * (W * H // 2))
+    args = [ENC_HIP, str(clip), str(W), str(H), str(N), str(tmp_path), "0", "0", "0", "8", "1"]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("X265_USE_HIP")}
+    plain = subprocess.run(args, capture_output=True, text=True, timeout=100, env=env)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    hip = subprocess.run(args, capture_output=True, text=True, timeout=100, env=dict(env, X265_USE_HIP_LOOKAHEAD="1"))
+    assert hip.returncode == 0, hip.stderr[-2000:]
+    h0, h1 = re.search(r"hash ([0-9a-f]+)", plain.stderr), re.search(r"hash ([0-9a-f]+)", hip.stderr)
+    assert h0 and h1 and h0.group(1) == h1.group(1), (plain.stderr[-500:], hip.stderr[-500:])
+    m = re.search(r"(\d+) lookahead frame searches on the GPU.* (\d+) lowres motionEstimate calls answered from them, (\d+) differed", hip.stderr)
+    assert m, hip.stderr[-1000:]
+    frames, calls, differed = (int(v) for v in m.groups())
+    assert frames >= 10 and calls == frames * ((W // 2 + 7) // 8) * ((H // 2 + 7) // 8) and differed == 0, hip.stderr[-1000:]
