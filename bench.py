@@ -225,6 +225,34 @@ def main():
               "me_frames_per_s": len(a_me) / h_me * 1e3, "me_calls_per_s": sum(p.n_me for p in a_me) / h_me * 1e3,
               "fullsearch_candidates_per_s": sum(p.fs_units for p in a_fs) / h_fs * 1e3,
               "fullsearch_frac_of_sad_peak": sum(p.fs_pos for p in a_fs) * 4096 / (h_fs * 1e-3) / SAD_PX_PEAK}
+        # the lookahead's whole-frame searches on the half-resolution planes of the same four pictures (120 x 68 CUs):
+        # 96 (picture, reference) pairs per launch -- what a slice-type decision over a 20-picture window asks for --
+        # and one pair alone (a chain of 120 + 2 x 67 dependent searches)
+        ctx.set_qp(abi.LOOKAHEAD_QP)
+        for i in range(4):
+            geo = ctx.lowres_init(i, 1920, 1080, 16 + 4 * i)
+        lw, lh = geo.width // 8, geo.lines // 8
+        lpairs = [(a, b) for a in range(4) for b in range(4) if a != b] * 8
+        lj = np.zeros(len(lpairs), abi.LOOKAHEAD_JOB)
+        lj["fenc_plane"], lj["ref_plane"] = [16 + 4 * a for a, _ in lpairs], [16 + 4 * b for _, b in lpairs]
+        lj["merange"], lj["method"], lj["subme"], lj["qp"] = 16, abi.HEX, 1, abi.LOOKAHEAD_QP
+        d_lj = torch.from_numpy(lj.view(np.uint8).copy()).to(dev)
+        o_lj = torch.empty(len(lj) * lw * lh * 8, dtype=torch.uint8, device=dev)
+
+        def run_look(s):
+            ctx.lookahead_batch_device(d_lj.data_ptr(), len(lj), lw, lh, o_lj.data_ptr())
+
+        def run_look1(s):
+            ctx.lookahead_batch_device(d_lj.data_ptr(), 1, lw, lh, o_lj.data_ptr())
+        _, h_lk, _ = leg(run_look, args.steps, 0)
+        _, h_lk1, _ = leg(run_look1, args.steps, 0)
+        hd["lookahead"] = {"workload": "x265_hip_lookahead_batch: HEX / subme 1 / merange 16 searches of every 8x8 CU of a 960x544 "
+                                       "lowres picture in the reference's dependency order, 96 (picture, reference) pairs per launch",
+                           "searches_per_s": len(lj) * args.steps / h_lk * 1e3, "cus_per_s": len(lj) * lw * lh * args.steps / h_lk * 1e3,
+                           "ms_per_launch": h_lk / args.steps, "single_search_ms": h_lk1 / args.steps,
+                           "chain_steps": lw + 2 * (lh - 1)}
+        for i in range(16):
+            ctx.plane_release(16 + i)
         for r in hrunners:
             r.release()
 

@@ -20,8 +20,8 @@ import torch
 import bench
 from x265_amd import abi, lib, synth
 
-LANE_PEAK = 3.93e13  # 32-bit integer VALU lane-ops/s: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (measured 3.65e13)
-PX_PEAK = 1.34e14    # measured byte-SAD pixel rate (profiles/r01_ubench_valu.txt)
+LANE_PEAK = bench.VALU_PEAK  # 7.86e13 32-bit VALU lane-ops/s (MI355X_MICROARCH.md; DESIGN.md 4: the kernels' own forms issue at half of it)
+PX_PEAK = bench.SAD_PX_PEAK  # 1.57e14 pixel-ops/s
 
 
 def timed(ext, ctx, fn, reps):
@@ -53,9 +53,8 @@ def run(w, h, tag):
         ctx.set_qp(q)
     res = {"picture": f"{w}x{h}"}
 
-    bench.W, bench.H = w, h
-    fj = bench.build_ctu_jobs(seq, 3, 2, 3, 2)
-    vp = bench.valid_pus_per_ctu()
+    fj = bench.build_ctu_jobs(seq, 3, 2, 3, 2, size=(w, h))
+    vp = bench.valid_pus_per_ctu(w, h)
     npos = (fj["mvmax_x"].astype(np.int64) - fj["mvmin_x"] + 1) * (fj["mvmax_y"].astype(np.int64) - fj["mvmin_y"] + 1)
     d = torch.from_numpy(fj.view(np.uint8).copy()).to(dev)
     o = torch.empty(len(fj) * lib.PUS_PER_CTU * 8, dtype=torch.uint8, device=dev)
@@ -155,7 +154,32 @@ def run(w, h, tag):
     res["host_array_fullsearch"] = {"ctus": len(fj), "ms_per_picture_per_ref": ms,
                                     "candidates_per_s": float((npos * vp).sum()) / ms * 1e3}
 
+    # the sub-pel stage as rings (x265_hip_refine_batch), one launch per PU size, device-resident and through the
+    # host-array entry point (request upload, kernel, cost download, synchronous: the PCIe-inclusive rate)
+    rr = synth.refine_requests(w, h, 3, refs, mot)
+    by_size = [rr[rr["pu_w"] == sz] for sz in (64, 32, 16, 8)]
+    dr = [torch.from_numpy(q.view(np.uint8).copy()).to(dev) for q in by_size]
+    orr = torch.empty(len(rr) * abi.RING_COSTS, dtype=torch.int32, device=dev)
+
+    def rings():
+        off = 0
+        for q, dq in zip(by_size, dr):
+            ctx.refine_batch_device(dq.data_ptr(), len(q), orr.data_ptr() + 4 * abi.RING_COSTS * off)
+            off += len(q)
+    ms = timed(ext, ctx, rings, 10)
+    res["satd_rings"] = {"ring_requests": len(rr), "candidates": 8 * len(rr), "ms": ms, "candidates_per_s": 8 * len(rr) / ms * 1e3}
+    for q in by_size:
+        ctx.refine_batch(q)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        for q in by_size:
+            ctx.refine_batch(q)
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    res["host_array_refine_batch"] = {"ring_requests": len(rr), "ms_per_picture": ms, "candidates_per_s": 8 * len(rr) / ms * 1e3,
+                                      "bytes_up": 20 * len(rr), "bytes_down": 36 * len(rr)}
+
     rq = synth.subpel_requests(w, h, 3, refs, mot)
+    res["satd_rings"]["frac_of_valu_peak"] = synth.satd_lane_ops(rq) / (res["satd_rings"]["ms"] * 1e-3) / LANE_PEAK
     d = torch.from_numpy(rq.view(np.uint8).copy()).to(dev)
     o = torch.empty(len(rq), dtype=torch.int32, device=dev)
     ms = timed(ext, ctx, lambda: ctx.cost_batch_device(d.data_ptr(), len(rq), o.data_ptr()), 5)

@@ -10,11 +10,15 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def ours(name):
     return "x265hip::" in name
+
+
+def short(name):
+    return name.split("(")[0].replace("x265hip::", "")
 
 
 def find(pattern):
@@ -25,38 +29,102 @@ def find(pattern):
 
 
 def pmc(pattern):
-    """per kernel and counter: mean over launches"""
+    """per kernel and counter: the launches in dispatch order"""
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(find(pattern))):
+    rows = list(csv.DictReader(open(find(pattern))))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for r in rows:
         if ours(r["Kernel_Name"]):
-            acc[(r["Kernel_Name"].split("(")[0].replace("x265hip::", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+            acc[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return acc
 
 
-# 1. kernel stats of the bench run (rocprofv3 --kernel-trace --stats)
+def mean(v):
+    return sum(v) / len(v)
+
+
+# 1. kernel stats of the bench run (rocprofv3 --kernel-trace --stats) and of the 4K driver
 shutil.copy(find("stats/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats.csv"))
+shutil.copy(find("stats4k/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats_prof4k.csv"))
 shutil.copy(os.path.join(SRC, "bench_under_rocprof.json"), os.path.join(DST, f"{tag}_bench_under_rocprof.json"))
-# 2. SQ counters, our kernels only
-sq, cnt = pmc("pmc_sq/**/*counter_collection.csv")
+shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{tag}_bench.json"))
+# per-launch durations of the 4K driver by kernel; refine_kernel per PU size (dispatch order: 64, 32, 16, 8)
+trace = list(csv.DictReader(open(find("stats4k/**/*kernel_trace.csv"))))
+trace.sort(key=lambda r: int(r["Dispatch_Id"]))
+dur = collections.defaultdict(list)
+for r in trace:
+    if ours(r["Kernel_Name"]):
+        dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
+# 2. SQ counters, our kernels only: mean per launch; refine_kernel also per PU size
+sq = pmc("pmc_sq/**/*counter_collection.csv")
 with open(os.path.join(DST, f"{tag}_pmc_sq.csv"), "w") as f:
     f.write("kernel,counter,mean_per_launch,launches\n")
     for (k, c) in sorted(sq):
-        f.write(f"{k},{c},{sq[(k, c)]:.0f},{cnt[(k, c)]}\n")
-# 3. HBM traffic
-fe, _ = pmc("pmc_fetch/**/*counter_collection.csv")
-wr, _ = pmc("pmc_write/**/*counter_collection.csv")
-traffic = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/prof_me.py (one 1080p picture: "
-                   "510 CTU full searches with one reference; 128700 motionEstimate calls, HEX subme 2, 3 references; the "
-                   "picture's 2.06 M sub-pel SATD candidates through cost_kernel and as sa8d through dist_kernel; one "
-                   "bi-directional prediction of the picture in 16x16 blocks), mean per "
-                   "launch, KiB as reported.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane "
-                   "streaming reads; fullsearch2_kernel stages with 16-B loads, so fetch_kib_corrected = 2 x raw for it; "
-                   "me_kernel / cost_kernel read 4 B per lane (uncalibrated width): raw and 2 x raw are both given."}
+        v = sq[(k, c)]
+        f.write(f"{k},{c},{mean(v):.0f},{len(v)}\n")
+        if k == "refine_kernel":
+            for i, s in enumerate((64, 32, 16, 8)):
+                f.write(f"{k}[pu {s}],{c},{mean(v[i::4]):.0f},{len(v[i::4])}\n")
+# 3. HBM traffic (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE in separate passes, KiB units; on gfx950 FETCH_SIZE counts
+# half of what 16-byte-per-lane streaming reads move: raw and 2 x raw are both given, the corrected figure is the one
+# quoted for kernels that stage with 16-byte loads)
+fe = pmc("pmc_fetch/**/*counter_collection.csv")
+wr = pmc("pmc_write/**/*counter_collection.csv")
+import ast
+run = next(ast.literal_eval(l) for l in open(os.path.join(SRC, "pmc_fetch.log")) if l.startswith("{"))
+traffic = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/prof_4k.py (one 4K P picture against "
+                   "3 references: rings of 8 per PU size through refine_kernel, the same candidates as single requests through "
+                   "cost_kernel, 516 k motionEstimate calls through me_kernel, 2040 CTU full searches, 12 lookahead frame searches of "
+                   "240 x 135 CUs), mean per launch, bytes = KiB x 1024.  *_4k keys: bytes per bench step, as bench.py's `traffic` "
+                   "(refine_kernel: the four launches of a step added up); fetch is given raw and x 2 (gfx950: FETCH_SIZE reports half "
+                   "the bytes of 16-byte-per-lane reads; refine_kernel and fullsearch2_kernel read 16 bytes per lane, cost_kernel "
+                   "and me_kernel mostly 4), hbm_bytes = corrected fetch + write for the 16-byte kernels, raw fetch + write otherwise",
+           "workload": run}
+wide = {"refine_kernel", "fullsearch2_kernel"}
 for k in sorted({k for (k, _) in fe}):
-    traffic[k] = {"fetch_kib_raw": fe[(k, "FETCH_SIZE")], "fetch_kib_corrected": 2 * fe[(k, "FETCH_SIZE")],
-                  "write_kib": wr.get((k, "WRITE_SIZE"))}
+    f_, w_ = fe[(k, "FETCH_SIZE")], wr.get((k, "WRITE_SIZE"), [0.0])
+    per_step = 4 if k == "refine_kernel" else 1
+    fb, wb = mean(f_) * 1024 * per_step, mean(w_) * 1024 * per_step
+    d = {"launches_per_step": per_step, "fetch_bytes_raw": fb, "fetch_bytes_x2": 2 * fb, "write_bytes": wb,
+         "hbm_bytes": (2 * fb if k in wide else fb) + wb, "kernel_us_mean": mean(dur[k]) * per_step if k in dur else None}
+    if k == "refine_kernel":
+        d["per_pu_size"] = {str(s): {"fetch_bytes_raw": mean(f_[i::4]) * 1024, "write_bytes": mean(w_[i::4]) * 1024,
+                                     "kernel_us": mean(dur[k][i::4])} for i, s in enumerate((64, 32, 16, 8))}
+    traffic[k + "_4k_detail"] = d
+    traffic[k + "_4k"] = d["hbm_bytes"]
 json.dump(traffic, open(os.path.join(DST, f"{tag}_traffic.json"), "w"), indent=1)
-# 4. the rest
-for a, b in (("ubench_valu.txt", f"{tag}_ubench_valu.txt"), ("configs.json", f"{tag}_configs.json"), ("bench.json", f"{tag}_bench.json")):
-    shutil.copy(os.path.join(SRC, a), os.path.join(DST, b))
 print("wrote", sorted(p for p in os.listdir(DST) if p.startswith(tag)))
+
+# 4. the bench run's timed launches, leg by leg, from the kernel trace of the same run: the legs run one after the other
+# (rings, single requests, motionEstimate, full search at 4K; then 1080p), so the last `steps` launches (x 4 for the
+# rings) of a kernel in front of the next leg's first launch are the timed ones.  Compared with the HIP-event times
+# bench.py printed in that run.
+bt = list(csv.DictReader(open(find("stats/**/*kernel_trace.csv"))))
+bt.sort(key=lambda r: int(r["Dispatch_Id"]))
+seqk = [(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6) for r in bt if ours(r["Kernel_Name"])]
+line = json.loads(open(os.path.join(SRC, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+K = line["steps"]
+order = ["refine_kernel", "cost_kernel", "me_kernel", "fullsearch2_kernel"]
+legs, pos = {}, 0
+for i, k in enumerate(order):
+    nxt = order[i + 1] if i + 1 < len(order) else "refine_kernel"
+    start = pos
+    while pos < len(seqk) and seqk[pos][0] == k:
+        pos += 1
+    block = [d for _, d in seqk[start:pos]]
+    per = 4 if k == "refine_kernel" else 1
+    timed = block[-K * per:]
+    legs[k] = {"launches_in_leg": len(block), "timed_launches": len(timed), "trace_ms_per_step": sum(timed) / K,
+               "trace_mean_launch_us": 1e3 * sum(timed) / len(timed)}
+    assert seqk[pos][0] == nxt, (k, seqk[pos][0])
+legs["refine_kernel"]["bench_kernel_ms"] = line["roofline"]["kernel_ms"]
+legs["cost_kernel"]["bench_kernel_ms"] = line["satd_single_requests"]["roofline"]["kernel_ms"]
+legs["me_kernel"]["bench_kernel_ms"] = line["me_stage"]["kernel_ms_per_frame"]
+legs["fullsearch2_kernel"]["bench_kernel_ms"] = line["fullsearch"]["roofline"]["kernel_ms"]
+for k in legs:
+    legs[k]["ratio_events_over_trace"] = legs[k]["bench_kernel_ms"] / legs[k]["trace_ms_per_step"]
+json.dump({"note": "4K legs of `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline`: kernel time per step from the "
+                   "trace's own timestamps (timed launches only) beside the HIP-event time bench.py printed in the same run "
+                   "(events bracket the launches, so they also hold the gaps between them)", "steps": K, "legs": legs},
+          open(os.path.join(DST, f"{tag}_bench_legs_from_trace.json"), "w"), indent=1)
+print(json.dumps(legs, indent=1))
