@@ -22,6 +22,8 @@
 // A first version that staged the horizontal passes in LDS (cells of 16 x 16, both vertical pairings, groups of cells
 // per wave) issued 1.65 x the VALU instructions of cost_kernel for the same candidates (profiles/r02_refine_lds_pmc.txt:
 // the staging pass and the cell bookkeeping cost as much as they saved) and was dropped for this register form.
+#include <stdlib.h>
+
 #include "kernels.h"
 #include "me_device.h"
 
@@ -73,17 +75,23 @@ __device__ __forceinline__ void ring_strip(gptr_t src, int stride, int fx, int j
     uint32_t q[NP][4];
     // the source strip, fetched once for the three vertical positions and early, so that no comparison waits for it
     uint32_t frow[4 * NT];
+    {
+        gptr_t fp = as_global(f);
+        const long lf = fstride;
 #pragma unroll
-    for (int y = 0; y < 4 * NT; y++)
-        frow[y] = ld4g(as_global(f) + y * fstride);
+        for (int y = 0; y < 4 * NT; y++, fp += lf)
+            frow[y] = ld4g(fp);
+    }
     // ---- horizontal pass: rows 2p, 2p + 1 as vertical pairs ---------------------------------------------------------
     if (__ballot(fx != 0) == 0)
     {
         // no lane of this pass filters horizontally: I = 64 (p - 128), the luma_p2s form
+        gptr_t rp = src + 3;
+        const long lstride = stride;
 #pragma unroll
-        for (int p = 0; p < NP; p++)
+        for (int p = 0; p < NP; p++, rp += 2 * lstride)
         {
-            const uint32_t a = ld4g(src + (2 * p) * stride + 3) ^ 0x80808080u, b = ld4g(src + (2 * p + 1) * stride + 3) ^ 0x80808080u;
+            const uint32_t a = ld4g(rp) ^ 0x80808080u, b = ld4g(rp + lstride) ^ 0x80808080u;
 #pragma unroll
             for (int x = 0; x < 4; x++)
             {
@@ -99,15 +107,20 @@ __device__ __forceinline__ void ring_strip(gptr_t src, int stride, int fx, int j
         const uint32_t tlo = k_taps_s8[fx][0], thi = k_taps_s8[fx][1];
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         constexpr int ROWS = 2 * NP;
-        auto fetch = [&](int r) {
-            const gptr_t p = src + r * stride;
-            return *(const __attribute__((address_space(1))) u32x4 *)(p - ((unsigned)(uintptr_t)p & 3u));
+        // a row's 12 bytes straight from their byte address (three dwords; the aligned 16-byte form needs three
+        // v_alignbyte per row to undo the alignment, and this kernel is short of VALU slots, not of load bandwidth)
+        gptr_t next = src;
+        const long lstride = stride;
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        auto fetch = [&](int) {
+            u32x3 w3;
+            __builtin_memcpy(&w3, (const void *)next, 12);
+            next += lstride;
+            const u32x4 w = { w3.x, w3.y, w3.z, 0 };
+            return w;
         };
-        auto hrow = [&](int r, const u32x4 w, int o[4]) {
-            const unsigned sh = (unsigned)(uintptr_t)(src + r * stride) & 3u;
-            const uint32_t d0 = __builtin_amdgcn_alignbyte(w.y, w.x, sh), d1 = __builtin_amdgcn_alignbyte(w.z, w.y, sh),
-                           d2 = __builtin_amdgcn_alignbyte(w.w, w.z, sh);
-            tap8x4<0>(d0 ^ 0x80808080u, d1 ^ 0x80808080u, d2 ^ 0x80808080u, tlo, thi, o);
+        auto hrow = [&](int, const u32x4 w, int o[4]) {
+            tap8x4<0>(w.x ^ 0x80808080u, w.y ^ 0x80808080u, w.z ^ 0x80808080u, tlo, thi, o);
         };
         u32x4 ahead[RF_AHEAD];
 #pragma unroll
@@ -171,7 +184,7 @@ __device__ __forceinline__ void ring_strip(gptr_t src, int stride, int fx, int j
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void refine_kernel(const DeviceTables *tabs, const x265_hip_refine_req *reqs,
-                                                                                           int n, int32_t *out, uint32_t *counters, int parity, int rb)
+                                                                                           int n, int32_t *out, uint32_t *counters, int parity, int rb, int max_items, int max_items_one)
 {
     __shared__ RingLds lds[4];
     __shared__ __attribute__((aligned(16))) uint32_t taps_lds[8 * 12];
@@ -182,20 +195,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void r
     const int lane = threadIdx.x & 63;
 
     // Work per batch is bounded: every wave looks at the same 64 requests spread over the list (multiples of the
-    // golden ratio, see cost_body) and halves rb until a batch holds about 1024 items by their mean.  (A list whose
-    // sizes come in long runs, e.g. sorted by PU size, defeats a size taken from a sample of the whole list: callers
-    // submit such lists one size at a time.  Deciding the length of a run where it is taken, from the request it
-    // starts with, was tried with a compare-and-swap hand-out and serialised the waves of a part: 3 us per run.)
+    // golden ratio, see cost_body) and halves rb until a batch holds about max_items items by their mean: 1024 for a
+    // list of mixed PU sizes, 256 (three or four passes of the item loop) when the sample shows one size only -- a list
+    // of one size in batches of a thousand items is little more than one batch per wave of the chip, and the launch
+    // then ends with most waves idle (per-size lists at 4K: 0.205 ms -> 0.185 ms); mixed lists need the longer
+    // batches (at 256 their idle lanes cost a third).  (A list whose sizes come in long runs, e.g. sorted by PU
+    // size, defeats a size taken from a sample of the whole list: callers submit such lists one size at a time.
+    // Deciding the length of a run where it is taken, from the request it starts with, was tried with a
+    // compare-and-swap hand-out and serialised the waves of a part: 3 us per run.)
     if (rb > 1)
     {
         const int si = n >= 64 ? (int)(((unsigned long long)((unsigned)lane * 0x9E3779B1u) * (unsigned long long)n) >> 32) : lane;
+        const int cnt = n < 64 ? n : 64;
         int items = 0;
         if (si < n)
             items = 3 * (reqs[si].pu_w >> 2) * ((reqs[si].pu_h + 7) >> 3);
+        const bool one_size = __ballot(lane < cnt && items != __shfl(items, 0)) == 0;
         for (int o = 32; o; o >>= 1)
             items += __shfl_xor(items, o);
-        const int cnt = n < 64 ? n : 64;
-        while (rb > 1 && items * rb > 1024 * cnt)
+        const int bound = one_size ? max_items_one : max_items;
+        while (rb > 1 && items * rb > bound * cnt)
             rb >>= 1;
         rb = uniform(rb);
     }
@@ -321,7 +340,10 @@ void launch_refine(const DeviceTables *tabs, const x265_hip_refine_req *reqs, in
     int blocks = (n + 3) / 4;
     if (blocks > RF_MAX_BLOCKS)
         blocks = RF_MAX_BLOCKS;
-    hipLaunchKernelGGL(refine_kernel, dim3(blocks), dim3(256), 0, st, tabs, reqs, n, out, counters, parity, rb);
+    // batch bounds (items per batch by the list's mean), see the kernel; the environment overrides are for experiments
+    static const int max_items = getenv("X265_RF_ITEMS") ? atoi(getenv("X265_RF_ITEMS")) : 1024;
+    static const int max_items_one = getenv("X265_RF_ITEMS1") ? atoi(getenv("X265_RF_ITEMS1")) : 256;
+    hipLaunchKernelGGL(refine_kernel, dim3(blocks), dim3(256), 0, st, tabs, reqs, n, out, counters, parity, rb, max_items, max_items_one);
 }
 
 } // namespace x265hip
