@@ -351,8 +351,7 @@ int x265_hip_lookahead_batch_device(x265_hip_ctx *ctx, const void *d_jobs, int n
  * step 2 (half-pel ring) or 1 (quarter-pel ring), and optionally the centre itself (the SATD re-measure of
  * motion.cpp:1082-1086).  Same pixels and same sad / satd as nine x265_hip_cost_req, but the interpolation is shared:
  * the candidates are a 3 x 3 grid, so three horizontal passes serve all nine (x265_amd/csrc/refine.hip).  No rate
- * term is added.  The stride of a reference plane must be a multiple of 4 (every TComPicYuv / Lowres stride is a
- * multiple of 32).  costs[9 i + k] is candidate k of request i in square1's order (k = 0 the centre, 1 (0,-1), 2 (0,1),
+ * term is added.  costs[9 i + k] is candidate k of request i in square1's order (k = 0 the centre, 1 (0,-1), 2 (0,1),
  * 3 (-1,0), 4 (1,0), 5 (-1,-1), 6 (-1,1), 7 (1,-1), 8 (1,1)); entries the pattern does not ask for are INT32_MAX. */
 #define X265_HIP_RING_QPEL   0x01 /* candidates at centre + square1[i]     */
 #define X265_HIP_RING_HPEL   0x02 /* candidates at centre + square1[i] * 2 */

@@ -940,10 +940,6 @@ int x265_hip_refine_batch(x265_hip_ctx *c, const x265_hip_refine_req *reqs, int 
         if (q.metric > X265_HIP_SATD || (ring != X265_HIP_RING_QPEL && ring != X265_HIP_RING_HPEL) ||
             (q.pattern & ~(X265_HIP_RING_QPEL | X265_HIP_RING_HPEL | X265_HIP_RING_8 | X265_HIP_RING_CENTRE)))
             return fail(X265_HIP_EINVAL, "refine_req[%d]: unknown metric %d / pattern 0x%x", i, q.metric, q.pattern);
-        // the ring kernel fetches a strip's rows as aligned 16-byte pieces with one alignment for the whole strip
-        if (c->host_tabs.planes[q.ref_plane].stride & 3)
-            return fail(X265_HIP_EINVAL, "refine_req[%d]: the stride of reference plane %d (%d) is not a multiple of 4", i, q.ref_plane,
-                        c->host_tabs.planes[q.ref_plane].stride);
         // the kernel stages rows (cy - step) >> 2 - 3 .. + h + 5 and, per horizontal position, columns ix - 3 .. ix + w + 4
         const int step = ring == X265_HIP_RING_HPEL ? 2 : 1;
         const long x0 = q.pu_x + ((q.qmv_x - step) >> 2), x1 = q.pu_x + ((q.qmv_x + step) >> 2) + q.pu_w;

@@ -381,6 +381,42 @@ __device__ __forceinline__ void ref_tile(const uint8_t *ref, int stride, int xf,
 // exactly what the reference's 4x4 / 8x4 grouping yields (pixel.cpp:201-252).  All of it runs on packed
 // 16-bit pairs (|coefficient| <= 16 * 255); the last butterfly stage is folded into
 // |a + b| + |a - b| = 2 * max(|a|, |b|), which also supplies the division by two.
+// 4x4 Hadamard SATD of differences held as 16-bit pairs: a[y] = columns (0, 1), b[y] = columns (2, 3) of row y
+__device__ __forceinline__ int satd4x4_pairs(const s16x2 a[4], const s16x2 b[4])
+{
+    // columns: 4-point Hadamard down the rows, two columns per register
+    s16x2 ra[4], rb[4];
+    {
+        const s16x2 s01 = a[0] + a[1], t01 = a[0] - a[1], s23 = a[2] + a[3], t23 = a[2] - a[3];
+        ra[0] = s01 + s23;
+        ra[1] = t01 + t23;
+        ra[2] = s01 - s23;
+        ra[3] = t01 - t23;
+    }
+    {
+        const s16x2 s01 = b[0] + b[1], t01 = b[0] - b[1], s23 = b[2] + b[3], t23 = b[2] - b[3];
+        rb[0] = s01 + s23;
+        rb[1] = t01 + t23;
+        rb[2] = s01 - s23;
+        rb[3] = t01 - t23;
+    }
+    // rows: (v0, v1), (v2, v3) -> s = (v0 + v2, v1 + v3), t = (v0 - v2, v1 - v3); the outputs are
+    // s.lo +- s.hi and t.lo +- t.hi, whose absolute sums are 2 max(|s.lo|, |s.hi|) + 2 max(|t.lo|, |t.hi|)
+    s16x2 sum = { 0, 0 };
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+    {
+        const uint32_t s = as_u32(ra[y] + rb[y]), t = as_u32(ra[y] - rb[y]);
+        const s16x2 u = as_s2(__builtin_amdgcn_perm(t, s, 0x05040100)); // (s.lo, t.lo)
+        const s16x2 v = as_s2(__builtin_amdgcn_perm(t, s, 0x07060302)); // (s.hi, t.hi)
+        const s16x2 mx = __builtin_elementwise_max(u, v), mn = __builtin_elementwise_min(u, v);
+        const s16x2 zero = { 0, 0 };
+        sum += __builtin_elementwise_max(mx, zero - mn);
+    }
+    const uint32_t su = as_u32(sum);
+    return (int)((su & 0xffffu) + (su >> 16));
+}
+
 // the source tile already in registers (one dword per row)
 __device__ __forceinline__ int tile_metric_rows(const uint32_t frow[4], const uint32_t P[4][2], int metric);
 
@@ -413,37 +449,29 @@ __device__ __forceinline__ int tile_metric_rows(const uint32_t frow[4], const ui
         a[y] = as_s2(__builtin_amdgcn_perm(0, fv, 0x0c010c00)) - as_s2(P[y][0]);
         b[y] = as_s2(__builtin_amdgcn_perm(0, fv, 0x0c030c02)) - as_s2(P[y][1]);
     }
-    // columns: 4-point Hadamard down the rows, two columns per register
-    s16x2 ra[4], rb[4];
+    return satd4x4_pairs(a, b);
+}
+
+// the same with the source tile already unpacked to 16-bit pairs (fa[y] = (x0, x1), fb[y] = (x2, x3)): for callers that
+// compare one source tile with several predictions
+__device__ __forceinline__ int tile_metric_pairs(const uint32_t fa[4], const uint32_t fb[4], const uint32_t P[4][2], int metric)
+{
+    if (metric == X265_HIP_SAD)
     {
-        const s16x2 s01 = a[0] + a[1], t01 = a[0] - a[1], s23 = a[2] + a[3], t23 = a[2] - a[3];
-        ra[0] = s01 + s23;
-        ra[1] = t01 + t23;
-        ra[2] = s01 - s23;
-        ra[3] = t01 - t23;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+            acc = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(fb[y], fa[y], 0x06040200), __builtin_amdgcn_perm(P[y][1], P[y][0], 0x06040200), acc);
+        return (int)acc;
     }
-    {
-        const s16x2 s01 = b[0] + b[1], t01 = b[0] - b[1], s23 = b[2] + b[3], t23 = b[2] - b[3];
-        rb[0] = s01 + s23;
-        rb[1] = t01 + t23;
-        rb[2] = s01 - s23;
-        rb[3] = t01 - t23;
-    }
-    // rows: (v0, v1), (v2, v3) -> s = (v0 + v2, v1 + v3), t = (v0 - v2, v1 - v3); the outputs are
-    // s.lo +- s.hi and t.lo +- t.hi, whose absolute sums are 2 max(|s.lo|, |s.hi|) + 2 max(|t.lo|, |t.hi|)
-    s16x2 sum = { 0, 0 };
+    s16x2 a[4], b[4];
 #pragma unroll
     for (int y = 0; y < 4; y++)
     {
-        const uint32_t s = as_u32(ra[y] + rb[y]), t = as_u32(ra[y] - rb[y]);
-        const s16x2 u = as_s2(__builtin_amdgcn_perm(t, s, 0x05040100)); // (s.lo, t.lo)
-        const s16x2 v = as_s2(__builtin_amdgcn_perm(t, s, 0x07060302)); // (s.hi, t.hi)
-        const s16x2 mx = __builtin_elementwise_max(u, v), mn = __builtin_elementwise_min(u, v);
-        const s16x2 zero = { 0, 0 };
-        sum += __builtin_elementwise_max(mx, zero - mn);
+        a[y] = as_s2(fa[y]) - as_s2(P[y][0]);
+        b[y] = as_s2(fb[y]) - as_s2(P[y][1]);
     }
-    const uint32_t su = as_u32(sum);
-    return (int)((su & 0xffffu) + (su >> 16));
+    return satd4x4_pairs(a, b);
 }
 
 // ---- mode-decision distortions of an 8-row strip ---------------------------------------------------

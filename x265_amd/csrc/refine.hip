@@ -32,7 +32,13 @@ namespace x265hip {
 #define RF_BATCH 32 // requests per batch (at most)
 #define RF_PARTS 64
 #define RF_CHUNK 8
-#define RF_MAX_BLOCKS (256 * 5)
+#ifndef RF_WAVES
+#define RF_WAVES 4 // waves per SIMD the kernel is compiled for (128 VGPRs)
+#endif
+#ifndef RF_SHIFTED_TAPS
+#define RF_SHIFTED_TAPS 1
+#endif
+#define RF_MAX_BLOCKS (256 * RF_WAVES)
 #define RF_AHEAD 4 // reference rows in flight per lane during the horizontal pass
 
 // 9-tap windows of the vertical filter x 16 as int16 pairs, per (fraction, delta): entries 0..4 serve even output
@@ -119,9 +125,29 @@ __device__ __forceinline__ void ring_strip(gptr_t src, int stride, int fx, int j
             const u32x4 w = { w3.x, w3.y, w3.z, 0 };
             return w;
         };
+#if RF_SHIFTED_TAPS
+        // the taps of pixel x laid over the row's 12 bytes (bytes x .. x + 7): eleven dot products per row and no
+        // byte shifts of the data, against eight dot products and six shifts
+        uint32_t T[4][3];
+#pragma unroll
+        for (int x = 1; x < 4; x++)
+        {
+            T[x][0] = tlo << (8 * x);
+            T[x][1] = __builtin_amdgcn_alignbyte(thi, tlo, 4 - x);
+            T[x][2] = thi >> (32 - 8 * x);
+        }
+        auto hrow = [&](int, const u32x4 w, int o[4]) {
+            const uint32_t d0 = w.x ^ 0x80808080u, d1 = w.y ^ 0x80808080u, d2 = w.z ^ 0x80808080u;
+            o[0] = __builtin_amdgcn_sdot4((int)d0, (int)tlo, sdot4_first<0>(d1, thi), false);
+#pragma unroll
+            for (int x = 1; x < 4; x++)
+                o[x] = __builtin_amdgcn_sdot4((int)d0, (int)T[x][0], __builtin_amdgcn_sdot4((int)d1, (int)T[x][1], sdot4_first<0>(d2, T[x][2]), false), false);
+        };
+#else
         auto hrow = [&](int, const u32x4 w, int o[4]) {
             tap8x4<0>(w.x ^ 0x80808080u, w.y ^ 0x80808080u, w.z ^ 0x80808080u, tlo, thi, o);
         };
+#endif
         u32x4 ahead[RF_AHEAD];
 #pragma unroll
         for (int r = 0; r < RF_AHEAD; r++)
@@ -146,6 +172,14 @@ __device__ __forceinline__ void ring_strip(gptr_t src, int stride, int fx, int j
     }
     // ---- vertical pass + comparison per vertical position -----------------------------------------------------------
     constexpr int seed = 16 * (2048 + (8192 << 6));
+    // the source strip as 16-bit pairs, once for the (up to) three comparisons
+    uint32_t fa[4 * NT], fb[4 * NT];
+#pragma unroll
+    for (int y = 0; y < 4 * NT; y++)
+    {
+        fa[y] = __builtin_amdgcn_perm(0, frow[y], 0x0c010c00);
+        fb[y] = __builtin_amdgcn_perm(0, frow[y], 0x0c030c02);
+    }
 #pragma unroll
     for (int j = 0; j < 3; j++)
     {
@@ -176,14 +210,14 @@ __device__ __forceinline__ void ring_strip(gptr_t src, int stride, int fx, int j
                 P[y][0] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(p0, lo), hi255));
                 P[y][1] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(p1, lo), hi255));
             }
-            v += tile_metric_rows(frow + 4 * t, P, metric);
+            v += tile_metric_pairs(fa + 4 * t, fb + 4 * t, P, metric);
         }
         if ((jneed >> j) & 1)
             atomicAdd(&cost[sq[j]], v);
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void refine_kernel(const DeviceTables *tabs, const x265_hip_refine_req *reqs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RF_WAVES))) void refine_kernel(const DeviceTables *tabs, const x265_hip_refine_req *reqs,
                                                                                            int n, int32_t *out, uint32_t *counters, int parity, int rb, int max_items, int max_items_one)
 {
     __shared__ RingLds lds[4];
