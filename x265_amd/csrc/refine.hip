@@ -31,7 +31,9 @@ namespace x265hip {
 
 #define RF_BATCH 32 // requests per batch (at most)
 #define RF_PARTS 64
+#ifndef RF_CHUNK
 #define RF_CHUNK 8
+#endif
 #ifndef RF_WAVES
 #define RF_WAVES 4 // waves per SIMD the kernel is compiled for (128 VGPRs)
 #endif
