@@ -76,6 +76,13 @@ const char *x265_hip_last_error(void); /* thread-local text of the last failure 
 /* the context's hipStream_t, for callers that time or order work with HIP events */
 void *x265_hip_ctx_stream(x265_hip_ctx *ctx);
 int x265_hip_ctx_sync(x265_hip_ctx *ctx);
+/* Record-check mode, a debugging aid for callers of the *_device entry points.  Those take their records on trust
+ * (a record that names a missing plane or reaches outside one makes the kernel fault the GPU).  With the mode on --
+ * by this call, or with X265_HIP_CHECK_RECORDS=1 in the environment when the context is created -- every *_device
+ * call first waits for the context's stream, copies the records back to the host and puts them through the checks of
+ * the host-array form; a bad record then returns X265_HIP_EINVAL / X265_HIP_ERANGE with a message and nothing is
+ * launched.  It costs a synchronisation and a copy per call: not for production runs.  No counterpart in the reference. */
+int x265_hip_ctx_check_records(x265_hip_ctx *ctx, int on);
 
 /* ---- (1) primitive level ---------------------------------------------------------------------- */
 

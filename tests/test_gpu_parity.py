@@ -765,3 +765,42 @@ def test_inter_search_stage_vs_oracle(gpu_ctx, small_seq, costtabs, oracle):
         jb[bad_job[0]][2] = bad_job[1]
         with pytest.raises(Exception, match=match):
             gpu_ctx.inter_search_batch(jb, W, H)
+
+
+def test_record_check_mode_refuses_bad_device_records(gpu_ctx, small_seq):
+    """x265_hip_ctx_check_records: with the mode on, the *_device entry points validate device-resident records like the
+    host-array forms and return an error instead of launching (a record reaching outside its plane would otherwise
+    fault the GPU); good lists still run and give the usual results"""
+    from x265_amd import abi, lib, synth
+    from x265_amd.hipmem import DeviceBuffer
+    W, H = small_seq[0].w, small_seq[0].h
+    rng = np.random.default_rng(77)
+    jobs = random_me_jobs(rng, 200, abi.HEX, 2, W, H, abi.ME_JOB, synth.search_range, abi.PARTS)
+    want = gpu_ctx.me_batch(jobs)
+    d_out = DeviceBuffer(8 * len(jobs))
+    gpu_ctx.check_records(True)
+    try:
+        d_jobs = DeviceBuffer.from_array(jobs)
+        gpu_ctx.me_batch_device(d_jobs.ptr, len(jobs), d_out.ptr)
+        gpu_ctx.sync()
+        assert np.array_equal(d_out.download(abi.ME_RESULT), want)
+        bad = jobs.copy()
+        bad["mvmax_y"][17] = 30000  # a window that reaches far below the plane
+        d_bad = DeviceBuffer.from_array(bad)
+        with pytest.raises(lib.X265HipError, match=r"me_job\[17\]"):
+            gpu_ctx.me_batch_device(d_bad.ptr, len(bad), d_out.ptr)
+        rq = np.zeros(4, abi.COST_REQ)
+        rq["fenc_plane"], rq["ref_plane"], rq["pu_w"], rq["pu_h"], rq["metric"] = 1, 0, 16, 16, abi.SATD
+        rq["pu_x"], rq["pu_y"] = 32, 32
+        rq["qmv_y"][2] = 4 * (H + 500)
+        d_rq, d_c = DeviceBuffer.from_array(rq), DeviceBuffer(16)
+        with pytest.raises(lib.X265HipError, match=r"cost_req\[2\]"):
+            gpu_ctx.cost_batch_device(d_rq.ptr, 4, d_c.ptr)
+        rr = np.zeros(2, abi.REFINE_REQ)
+        rr["fenc_plane"], rr["ref_plane"], rr["pu_w"], rr["pu_h"], rr["metric"] = 1, 7, 8, 8, abi.SATD  # plane 7: not uploaded
+        rr["pattern"] = abi.RING_HPEL
+        d_rr, d_c9 = DeviceBuffer.from_array(rr), DeviceBuffer(72)
+        with pytest.raises(lib.X265HipError, match="not uploaded"):
+            gpu_ctx.refine_batch_device(d_rr.ptr, 2, d_c9.ptr)
+    finally:
+        gpu_ctx.check_records(False)

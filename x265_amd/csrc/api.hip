@@ -76,6 +76,7 @@ struct x265_hip_ctx
     bool tabs_dirty = true;
     uint32_t *batch_counter = nullptr; // batch counters of the cost kernels (two sets, see launch_cost)
     int batch_parity = 0;
+    bool check_records = false; // record-check mode of the device-array entry points
     void *owned_plane[X265_HIP_MAX_PLANES] = {};
     size_t plane_bytes[X265_HIP_MAX_PLANES] = {};
     int plane_origin[X265_HIP_MAX_PLANES] = {};
@@ -206,6 +207,7 @@ int x265_hip_ctx_create(int device, x265_hip_ctx **out)
         x265_hip_ctx_destroy(c);
         return fail(X265_HIP_ERUNTIME, "context setup: %s", hipGetErrorString(e));
     }
+    c->check_records = getenv("X265_HIP_CHECK_RECORDS") && atoi(getenv("X265_HIP_CHECK_RECORDS")) != 0;
     if (fullsearch2_setup() != 0)
     {
         x265_hip_ctx_destroy(c);
@@ -246,6 +248,15 @@ void x265_hip_ctx_destroy(x265_hip_ctx *c)
 }
 
 void *x265_hip_ctx_stream(x265_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int x265_hip_ctx_check_records(x265_hip_ctx *c, int on)
+{
+    if (!c)
+        return fail(X265_HIP_EINVAL, "null context");
+    std::lock_guard<std::mutex> g(c->mu);
+    c->check_records = on != 0;
+    return X265_HIP_OK;
+}
 
 int x265_hip_ctx_sync(x265_hip_ctx *c)
 {
@@ -648,6 +659,220 @@ static int check_jobs(const x265_hip_ctx *c, const x265_hip_me_job *jobs, int n)
     return 0;
 }
 
+// ---- validation of whole request lists (the host-array entry points; the device-array ones in record-check mode) --
+
+static int validate_cost(const x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n)
+{
+    for (int i = 0; i < n; i++)
+    {
+        int r = check_block(c, reqs[i].fenc_plane, reqs[i].ref_plane, reqs[i].pu_w, reqs[i].pu_h, "cost_req", i);
+        if (r)
+            return r;
+        if (reqs[i].metric > X265_HIP_SATD)
+            return fail(X265_HIP_EINVAL, "cost_req[%d]: unknown metric %d", i, reqs[i].metric);
+        if ((r = check_inside(c, reqs[i].fenc_plane, reqs[i].pu_x, reqs[i].pu_y, reqs[i].pu_w, reqs[i].pu_h, "cost_req", i)) ||
+            (r = check_displaced(c, reqs[i].ref_plane, reqs[i].pu_x, reqs[i].pu_y, reqs[i].pu_w, reqs[i].pu_h, reqs[i].qmv_x,
+                                 reqs[i].qmv_y, "cost_req", i)))
+            return r;
+    }
+    return 0;
+}
+
+static int validate_refine(const x265_hip_ctx *c, const x265_hip_refine_req *reqs, int n)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const x265_hip_refine_req &q = reqs[i];
+        int r = check_block(c, q.fenc_plane, q.ref_plane, q.pu_w, q.pu_h, "refine_req", i);
+        if (r)
+            return r;
+        const int ring = q.pattern & (X265_HIP_RING_QPEL | X265_HIP_RING_HPEL);
+        if (q.metric > X265_HIP_SATD || (ring != X265_HIP_RING_QPEL && ring != X265_HIP_RING_HPEL) ||
+            (q.pattern & ~(X265_HIP_RING_QPEL | X265_HIP_RING_HPEL | X265_HIP_RING_8 | X265_HIP_RING_CENTRE)))
+            return fail(X265_HIP_EINVAL, "refine_req[%d]: unknown metric %d / pattern 0x%x", i, q.metric, q.pattern);
+        // the kernel stages rows (cy - step) >> 2 - 3 .. + h + 5 and, per horizontal position, columns ix - 3 .. ix + w + 4
+        const int step = ring == X265_HIP_RING_HPEL ? 2 : 1;
+        const long x0 = q.pu_x + ((q.qmv_x - step) >> 2), x1 = q.pu_x + ((q.qmv_x + step) >> 2) + q.pu_w;
+        const long y0 = q.pu_y + ((q.qmv_y - step) >> 2), y1 = y0 + q.pu_h + 2;
+        if ((r = check_inside(c, q.fenc_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, "refine_req", i)) ||
+            (r = check_reach(c, q.ref_plane, x0, y0, x1, y1, "refine_req", i)))
+            return r;
+    }
+    return 0;
+}
+
+static int validate_dist(const x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n)
+{
+    for (int i = 0; i < n; i++)
+    {
+        int r = check_block(c, reqs[i].fenc_plane, reqs[i].ref_plane, reqs[i].pu_w, reqs[i].pu_h, "dist_req", i);
+        if (r)
+            return r;
+        if (reqs[i].metric > X265_HIP_SSE)
+            return fail(X265_HIP_EINVAL, "dist_req[%d]: unknown metric %d", i, reqs[i].metric);
+        if ((r = check_inside(c, reqs[i].fenc_plane, reqs[i].pu_x, reqs[i].pu_y, reqs[i].pu_w, reqs[i].pu_h, "dist_req", i)) ||
+            (r = check_displaced(c, reqs[i].ref_plane, reqs[i].pu_x, reqs[i].pu_y, reqs[i].pu_w, reqs[i].pu_h, reqs[i].qmv_x,
+                                 reqs[i].qmv_y, "dist_req", i)))
+            return r;
+    }
+    return 0;
+}
+
+static int validate_pred(const x265_hip_ctx *c, const x265_hip_pred_req *reqs, int n)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const x265_hip_pred_req &q = reqs[i];
+        int r = check_block(c, q.dst_plane, q.ref0_plane, q.pu_w, q.pu_h, "pred_req", i);
+        if (r || (q.ref1_plane >= 0 && (r = check_block(c, q.dst_plane, q.ref1_plane, q.pu_w, q.pu_h, "pred_req", i))))
+            return r;
+        if (q.dst_plane == q.ref0_plane || q.dst_plane == q.ref1_plane)
+            return fail(X265_HIP_EINVAL, "pred_req[%d]: the destination plane is one of the references", i);
+        if (q.ref1_plane == X265_HIP_PRED_WEIGHTED &&
+            (q.log2_denom > 7 || q.qmv1_x < -128 || q.qmv1_x > 255 || q.qmv1_y < -128 || q.qmv1_y > 127))
+            return fail(X265_HIP_EINVAL, "pred_req[%d]: weight %d / offset %d / log2 denominator %d out of range", i, q.qmv1_x,
+                        q.qmv1_y, q.log2_denom);
+        if ((r = check_inside(c, q.dst_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, "pred_req", i)) ||
+            (r = check_displaced(c, q.ref0_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv0_x, q.qmv0_y, "pred_req", i)) ||
+            (q.ref1_plane >= 0 &&
+             (r = check_displaced(c, q.ref1_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv1_x, q.qmv1_y, "pred_req", i))))
+            return r;
+    }
+    return 0;
+}
+
+static int validate_bidir(const x265_hip_ctx *c, const x265_hip_bidir_req *reqs, int n)
+{
+    for (int i = 0; i < n; i++)
+    {
+        int r = check_block(c, reqs[i].fenc_plane, reqs[i].ref0_plane, reqs[i].pu_w, reqs[i].pu_h, "bidir_req", i);
+        if (r || (r = check_block(c, reqs[i].fenc_plane, reqs[i].ref1_plane, reqs[i].pu_w, reqs[i].pu_h, "bidir_req", i)))
+            return r;
+        const x265_hip_bidir_req &q = reqs[i];
+        if ((q.metric & ~(X265_HIP_LOWRES_REF | X265_HIP_MC_AVG)) > X265_HIP_SSE ||
+            (q.metric & (X265_HIP_LOWRES_REF | X265_HIP_MC_AVG)) == (X265_HIP_LOWRES_REF | X265_HIP_MC_AVG))
+            return fail(X265_HIP_EINVAL, "bidir_req[%d]: unknown metric %d", i, q.metric);
+        if (q.metric & X265_HIP_LOWRES_REF)
+        {
+            // Lowres references: the lookahead's 8x8 CU, four planes of one stride per reference
+            if (q.pu_w != 8 || q.pu_h != 8)
+                return fail(X265_HIP_EINVAL, "bidir_req[%d]: lowres references take 8x8 blocks only (lowres.h:64)", i);
+            for (int rp : { q.ref0_plane, q.ref1_plane })
+            {
+                if (rp + 3 >= X265_HIP_MAX_PLANES)
+                    return fail(X265_HIP_EINVAL, "bidir_req[%d]: lowres planes %d..%d out of range", i, rp, rp + 3);
+                for (int k = 1; k < 4; k++)
+                    if (!c->host_tabs.planes[rp + k].origin || c->host_tabs.planes[rp + k].stride != c->host_tabs.planes[rp].stride ||
+                        c->plane_bytes[rp + k] != c->plane_bytes[rp] || c->plane_origin[rp + k] != c->plane_origin[rp])
+                        return fail(X265_HIP_EINVAL, "bidir_req[%d]: lowres plane %d missing or of another layout", i, rp + k);
+            }
+        }
+        if ((r = check_inside(c, q.fenc_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, "bidir_req", i)) ||
+            (r = check_displaced(c, q.ref0_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv0_x, q.qmv0_y, "bidir_req", i)) ||
+            (r = check_displaced(c, q.ref1_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv1_x, q.qmv1_y, "bidir_req", i)))
+            return r;
+    }
+    return 0;
+}
+
+static int validate_ctu(const x265_hip_ctx *c, const x265_hip_ctu_job *jobs, int n)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const x265_hip_ctu_job &j = jobs[i];
+        int r = check_block(c, j.fenc_plane, j.ref_plane, 64, 64, "ctu_job", i);
+        if (r)
+            return r;
+        if (j.qp >= X265_HIP_MAX_QP || !c->host_tabs.costtab[j.qp])
+            return fail(X265_HIP_EINVAL, "ctu_job[%d]: no cost table uploaded for qp %d", i, j.qp);
+        if (j.mvmin_x > j.mvmax_x || j.mvmin_y > j.mvmax_y)
+            return fail(X265_HIP_EINVAL, "ctu_job[%d]: empty search range", i);
+        if (j.mvmax_x - j.mvmin_x > 131 || j.mvmax_y - j.mvmin_y > 131)
+            return fail(X265_HIP_ERANGE, "ctu_job[%d]: window wider than 132 positions", i);
+        if ((r = check_inside(c, j.fenc_plane, j.ctu_x, j.ctu_y, 64, 64, "ctu_job", i)) ||
+            (r = check_reach(c, j.ref_plane, j.ctu_x + j.mvmin_x, j.ctu_y + j.mvmin_y, j.ctu_x + j.mvmax_x + 64,
+                             j.ctu_y + j.mvmax_y + 64, "ctu_job", i)))
+            return r;
+    }
+    return 0;
+}
+
+static int validate_inter(const x265_hip_ctx *c, const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const x265_hip_inter_job &q = jobs[i];
+        if (q.num_amvp < 1 || q.num_amvp > 2)
+            return fail(X265_HIP_EINVAL, "inter_job[%d]: %d AMVP candidates (1 or 2)", i, q.num_amvp);
+        if (q.pred_plane < 0 || q.pred_plane >= X265_HIP_MAX_PLANES || !c->host_tabs.planes[q.pred_plane].origin)
+            return fail(X265_HIP_EINVAL, "inter_job[%d]: plane %d not uploaded", i, q.pred_plane);
+        // every search the job can turn into (one per candidate) must pass the checks of a motionEstimate job, and the
+        // candidates' predictions must lie inside the plane they are made from
+        for (int k = 0; k < q.num_amvp; k++)
+        {
+            x265_hip_me_job m;
+            memset(&m, 0, sizeof(m));
+            m.fenc_plane = q.fenc_plane, m.ref_plane = q.ref_plane;
+            m.pu_x = q.pu_x, m.pu_y = q.pu_y, m.pu_w = q.pu_w, m.pu_h = q.pu_h;
+            m.method = q.method, m.subme = q.subme, m.merange = q.merange, m.qp = q.qp, m.num_mvc = q.num_mvc;
+            int lox, loy, hix, hiy;
+            search_window(q.amvp[2 * k], q.amvp[2 * k + 1], q.merange, q.ref_lag, q.cu_x, q.cu_y, pic_w, pic_h, lox, loy, hix, hiy);
+            m.mvmin_x = (int16_t)lox, m.mvmin_y = (int16_t)loy, m.mvmax_x = (int16_t)hix, m.mvmax_y = (int16_t)hiy;
+            int r = check_job(c, m, i);
+            if (r)
+                return r;
+            int qx = q.amvp[2 * k], qy = q.amvp[2 * k + 1];
+            clip_mv(qx, qy, q.cu_x, q.cu_y, pic_w, pic_h);
+            if ((r = check_displaced(c, q.pred_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, qx, qy, "inter_job", i)))
+                return r;
+        }
+    }
+    return 0;
+}
+
+static int validate_lookahead(const x265_hip_ctx *c, const x265_hip_lookahead_job *jobs, int njobs, int w_cu, int h_cu)
+{
+    for (int i = 0; i < njobs; i++)
+    {
+        // every CU's window spans the same samples of the reference, [-8, 8 (W - 1) + 8] x [-8, 8 (H - 1) + 8] for the
+        // block's origin (slicetype.cpp:1540-1544): the four corner CUs are put through the checks of a motionEstimate job
+        for (int corner = 0; corner < 4; corner++)
+        {
+            const int cux = (corner & 1) ? w_cu - 1 : 0, cuy = (corner & 2) ? h_cu - 1 : 0;
+            x265_hip_me_job m;
+            memset(&m, 0, sizeof(m));
+            m.fenc_plane = jobs[i].fenc_plane, m.ref_plane = jobs[i].ref_plane;
+            m.pu_x = (int16_t)(8 * cux), m.pu_y = (int16_t)(8 * cuy), m.pu_w = m.pu_h = 8;
+            m.method = (uint8_t)(jobs[i].method | X265_HIP_LOWRES_REF), m.subme = jobs[i].subme, m.merange = jobs[i].merange, m.qp = jobs[i].qp;
+            m.mvmin_x = (int16_t)(-8 * cux - 8), m.mvmin_y = (int16_t)(-8 * cuy - 8);
+            m.mvmax_x = (int16_t)((w_cu - cux - 1) * 8 + 8), m.mvmax_y = (int16_t)((h_cu - cuy - 1) * 8 + 8);
+            if (jobs[i].method & X265_HIP_LOWRES_REF)
+                return fail(X265_HIP_EINVAL, "lookahead_job[%d]: method %d (the Lowres flag is implied)", i, jobs[i].method);
+            int r = check_job(c, m, i);
+            if (r)
+                return r;
+        }
+    }
+    return 0;
+}
+
+// Record-check mode (x265_hip_ctx_check_records, or X265_HIP_CHECK_RECORDS=1 in the environment when the context is
+// made): the device-array entry points, which otherwise take their records on trust, wait for the stream, copy the
+// records back and put them through the checks of the host-array form before anything is launched.  A debugging aid:
+// a bad record then gives an error code and a message instead of a GPU memory fault.
+extern "C++" {
+template <typename T, typename F>
+static int checked_records(x265_hip_ctx *c, const void *d_recs, int n, F validate)
+{
+    if (!c->check_records || n <= 0)
+        return 0;
+    std::vector<T> host((size_t)n);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(host.data(), d_recs, (size_t)n * sizeof(T), hipMemcpyDeviceToHost));
+    return validate(host.data());
+}
+} // extern "C++"
+
 // ---- batched entry points -----------------------------------------------------------------------
 
 int x265_hip_me_batch_device(x265_hip_ctx *c, const void *d_jobs, int n, void *d_results)
@@ -656,6 +881,11 @@ int x265_hip_me_batch_device(x265_hip_ctx *c, const void *d_jobs, int n, void *d
         return fail(X265_HIP_EINVAL, "me_batch_device: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = checked_records<x265_hip_me_job>(c, d_jobs, n, [&](const x265_hip_me_job *h) { return check_jobs(c, h, n); });
+        if (vr)
+            return vr;
+    }
     int r = push_tabs(c);
     if (r)
         return r;
@@ -695,6 +925,11 @@ int x265_hip_inter_search_batch_device(x265_hip_ctx *c, const void *d_jobs, int 
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = checked_records<x265_hip_inter_job>(c, d_jobs, n, [&](const x265_hip_inter_job *h) { return validate_inter(c, h, n, pic_w, pic_h); });
+        if (vr)
+            return vr;
+    }
     int r;
     if (c->mejobs.cap < (size_t)n * sizeof(x265_hip_me_job))
         HIP_TRY(hipStreamSynchronize(c->stream)); // an earlier launch may still read the buffer that is about to be replaced
@@ -713,33 +948,10 @@ int x265_hip_inter_search_batch(x265_hip_ctx *c, const x265_hip_inter_job *jobs,
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    for (int i = 0; i < n; i++)
     {
-        const x265_hip_inter_job &q = jobs[i];
-        if (q.num_amvp < 1 || q.num_amvp > 2)
-            return fail(X265_HIP_EINVAL, "inter_job[%d]: %d AMVP candidates (1 or 2)", i, q.num_amvp);
-        if (q.pred_plane < 0 || q.pred_plane >= X265_HIP_MAX_PLANES || !c->host_tabs.planes[q.pred_plane].origin)
-            return fail(X265_HIP_EINVAL, "inter_job[%d]: plane %d not uploaded", i, q.pred_plane);
-        // every search the job can turn into (one per candidate) must pass the checks of a motionEstimate job, and the
-        // candidates' predictions must lie inside the plane they are made from
-        for (int k = 0; k < q.num_amvp; k++)
-        {
-            x265_hip_me_job m;
-            memset(&m, 0, sizeof(m));
-            m.fenc_plane = q.fenc_plane, m.ref_plane = q.ref_plane;
-            m.pu_x = q.pu_x, m.pu_y = q.pu_y, m.pu_w = q.pu_w, m.pu_h = q.pu_h;
-            m.method = q.method, m.subme = q.subme, m.merange = q.merange, m.qp = q.qp, m.num_mvc = q.num_mvc;
-            int lox, loy, hix, hiy;
-            search_window(q.amvp[2 * k], q.amvp[2 * k + 1], q.merange, q.ref_lag, q.cu_x, q.cu_y, pic_w, pic_h, lox, loy, hix, hiy);
-            m.mvmin_x = (int16_t)lox, m.mvmin_y = (int16_t)loy, m.mvmax_x = (int16_t)hix, m.mvmax_y = (int16_t)hiy;
-            int r = check_job(c, m, i);
-            if (r)
-                return r;
-            int qx = q.amvp[2 * k], qy = q.amvp[2 * k + 1];
-            clip_mv(qx, qy, q.cu_x, q.cu_y, pic_w, pic_h);
-            if ((r = check_displaced(c, q.pred_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, qx, qy, "inter_job", i)))
-                return r;
-        }
+        int vr = validate_inter(c, jobs, n, pic_w, pic_h);
+        if (vr)
+            return vr;
     }
     int r;
     const size_t ob = (size_t)n * sizeof(*results);
@@ -790,6 +1002,8 @@ int x265_hip_lookahead_batch_device(x265_hip_ctx *c, const void *d_jobs, int njo
         return r;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    if ((r = checked_records<x265_hip_lookahead_job>(c, d_jobs, njobs, [&](const x265_hip_lookahead_job *h) { return validate_lookahead(c, h, njobs, w_cu, h_cu); })))
+        return r;
     return lookahead_launch(c, d_jobs, njobs, w_cu, h_cu, d_results);
 }
 
@@ -800,26 +1014,8 @@ int x265_hip_lookahead_batch(x265_hip_ctx *c, const x265_hip_lookahead_job *jobs
         return r;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    for (int i = 0; i < njobs; i++)
-    {
-        // every CU's window spans the same samples of the reference, [-8, 8 (W - 1) + 8] x [-8, 8 (H - 1) + 8] for the
-        // block's origin (slicetype.cpp:1540-1544): the four corner CUs are put through the checks of a motionEstimate job
-        for (int corner = 0; corner < 4; corner++)
-        {
-            const int cux = (corner & 1) ? w_cu - 1 : 0, cuy = (corner & 2) ? h_cu - 1 : 0;
-            x265_hip_me_job m;
-            memset(&m, 0, sizeof(m));
-            m.fenc_plane = jobs[i].fenc_plane, m.ref_plane = jobs[i].ref_plane;
-            m.pu_x = (int16_t)(8 * cux), m.pu_y = (int16_t)(8 * cuy), m.pu_w = m.pu_h = 8;
-            m.method = (uint8_t)(jobs[i].method | X265_HIP_LOWRES_REF), m.subme = jobs[i].subme, m.merange = jobs[i].merange, m.qp = jobs[i].qp;
-            m.mvmin_x = (int16_t)(-8 * cux - 8), m.mvmin_y = (int16_t)(-8 * cuy - 8);
-            m.mvmax_x = (int16_t)((w_cu - cux - 1) * 8 + 8), m.mvmax_y = (int16_t)((h_cu - cuy - 1) * 8 + 8);
-            if (jobs[i].method & X265_HIP_LOWRES_REF)
-                return fail(X265_HIP_EINVAL, "lookahead_job[%d]: method %d (the Lowres flag is implied)", i, jobs[i].method);
-            if ((r = check_job(c, m, i)))
-                return r;
-        }
-    }
+    if ((r = validate_lookahead(c, jobs, njobs, w_cu, h_cu)))
+        return r;
     const size_t ncu = (size_t)njobs * w_cu * h_cu, ob = ncu * sizeof(*results);
     if ((r = ensure(c, c->in, (size_t)njobs * sizeof(*jobs))) || (r = ensure(c, c->out, ob)))
         return r;
@@ -843,6 +1039,11 @@ int x265_hip_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void 
         return fail(X265_HIP_EINVAL, "cost_batch_device: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = checked_records<x265_hip_cost_req>(c, d_reqs, n, [&](const x265_hip_cost_req *h) { return validate_cost(c, h, n); });
+        if (vr)
+            return vr;
+    }
     int r = push_tabs(c);
     if (r)
         return r;
@@ -865,6 +1066,11 @@ int x265_hip_cost_batch_device_noalloc(x265_hip_ctx *c, const void *d_reqs, int 
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = checked_records<x265_hip_cost_req>(c, d_reqs, n, [&](const x265_hip_cost_req *h) { return validate_cost(c, h, n); });
+        if (vr)
+            return vr;
+    }
     uint32_t *const ptr = c->device < X265HIP_MAX_DEVICES ? g_scratch_ptr[c->device] : nullptr;
     if (!ptr)
         return fail(X265_HIP_ERUNTIME, "cost_batch_device_noalloc: no scratch address for device %d", c->device);
@@ -884,17 +1090,10 @@ int x265_hip_cost_batch(x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n, i
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    for (int i = 0; i < n; i++)
     {
-        int r = check_block(c, reqs[i].fenc_plane, reqs[i].ref_plane, reqs[i].pu_w, reqs[i].pu_h, "cost_req", i);
-        if (r)
-            return r;
-        if (reqs[i].metric > X265_HIP_SATD)
-            return fail(X265_HIP_EINVAL, "cost_req[%d]: unknown metric %d", i, reqs[i].metric);
-        if ((r = check_inside(c, reqs[i].fenc_plane, reqs[i].pu_x, reqs[i].pu_y, reqs[i].pu_w, reqs[i].pu_h, "cost_req", i)) ||
-            (r = check_displaced(c, reqs[i].ref_plane, reqs[i].pu_x, reqs[i].pu_y, reqs[i].pu_w, reqs[i].pu_h, reqs[i].qmv_x,
-                                 reqs[i].qmv_y, "cost_req", i)))
-            return r;
+        int vr = validate_cost(c, reqs, n);
+        if (vr)
+            return vr;
     }
     int r;
     if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))) ||
@@ -915,6 +1114,11 @@ int x265_hip_refine_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, voi
         return fail(X265_HIP_EINVAL, "refine_batch_device: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = checked_records<x265_hip_refine_req>(c, d_reqs, n, [&](const x265_hip_refine_req *h) { return validate_refine(c, h, n); });
+        if (vr)
+            return vr;
+    }
     int r = push_tabs(c);
     if (r)
         return r;
@@ -930,23 +1134,10 @@ int x265_hip_refine_batch(x265_hip_ctx *c, const x265_hip_refine_req *reqs, int 
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    for (int i = 0; i < n; i++)
     {
-        const x265_hip_refine_req &q = reqs[i];
-        int r = check_block(c, q.fenc_plane, q.ref_plane, q.pu_w, q.pu_h, "refine_req", i);
-        if (r)
-            return r;
-        const int ring = q.pattern & (X265_HIP_RING_QPEL | X265_HIP_RING_HPEL);
-        if (q.metric > X265_HIP_SATD || (ring != X265_HIP_RING_QPEL && ring != X265_HIP_RING_HPEL) ||
-            (q.pattern & ~(X265_HIP_RING_QPEL | X265_HIP_RING_HPEL | X265_HIP_RING_8 | X265_HIP_RING_CENTRE)))
-            return fail(X265_HIP_EINVAL, "refine_req[%d]: unknown metric %d / pattern 0x%x", i, q.metric, q.pattern);
-        // the kernel stages rows (cy - step) >> 2 - 3 .. + h + 5 and, per horizontal position, columns ix - 3 .. ix + w + 4
-        const int step = ring == X265_HIP_RING_HPEL ? 2 : 1;
-        const long x0 = q.pu_x + ((q.qmv_x - step) >> 2), x1 = q.pu_x + ((q.qmv_x + step) >> 2) + q.pu_w;
-        const long y0 = q.pu_y + ((q.qmv_y - step) >> 2), y1 = y0 + q.pu_h + 2;
-        if ((r = check_inside(c, q.fenc_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, "refine_req", i)) ||
-            (r = check_reach(c, q.ref_plane, x0, y0, x1, y1, "refine_req", i)))
-            return r;
+        int vr = validate_refine(c, reqs, n);
+        if (vr)
+            return vr;
     }
     const size_t ob = (size_t)n * X265_HIP_RING_COSTS * sizeof(int32_t);
     int r;
@@ -966,6 +1157,11 @@ int x265_hip_dist_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void 
         return fail(X265_HIP_EINVAL, "dist_batch_device: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = checked_records<x265_hip_cost_req>(c, d_reqs, n, [&](const x265_hip_cost_req *h) { return validate_dist(c, h, n); });
+        if (vr)
+            return vr;
+    }
     int r = push_tabs(c);
     if (r)
         return r;
@@ -981,17 +1177,10 @@ int x265_hip_dist_batch(x265_hip_ctx *c, const x265_hip_cost_req *reqs, int n, i
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    for (int i = 0; i < n; i++)
     {
-        int r = check_block(c, reqs[i].fenc_plane, reqs[i].ref_plane, reqs[i].pu_w, reqs[i].pu_h, "dist_req", i);
-        if (r)
-            return r;
-        if (reqs[i].metric > X265_HIP_SSE)
-            return fail(X265_HIP_EINVAL, "dist_req[%d]: unknown metric %d", i, reqs[i].metric);
-        if ((r = check_inside(c, reqs[i].fenc_plane, reqs[i].pu_x, reqs[i].pu_y, reqs[i].pu_w, reqs[i].pu_h, "dist_req", i)) ||
-            (r = check_displaced(c, reqs[i].ref_plane, reqs[i].pu_x, reqs[i].pu_y, reqs[i].pu_w, reqs[i].pu_h, reqs[i].qmv_x,
-                                 reqs[i].qmv_y, "dist_req", i)))
-            return r;
+        int vr = validate_dist(c, reqs, n);
+        if (vr)
+            return vr;
     }
     int r;
     if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))) ||
@@ -1011,6 +1200,11 @@ int x265_hip_predict_batch_device(x265_hip_ctx *c, const void *d_reqs, int n)
         return fail(X265_HIP_EINVAL, "predict_batch_device: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = checked_records<x265_hip_pred_req>(c, d_reqs, n, [&](const x265_hip_pred_req *h) { return validate_pred(c, h, n); });
+        if (vr)
+            return vr;
+    }
     int r = push_tabs(c);
     if (r)
         return r;
@@ -1026,23 +1220,10 @@ int x265_hip_predict_batch(x265_hip_ctx *c, const x265_hip_pred_req *reqs, int n
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    for (int i = 0; i < n; i++)
     {
-        const x265_hip_pred_req &q = reqs[i];
-        int r = check_block(c, q.dst_plane, q.ref0_plane, q.pu_w, q.pu_h, "pred_req", i);
-        if (r || (q.ref1_plane >= 0 && (r = check_block(c, q.dst_plane, q.ref1_plane, q.pu_w, q.pu_h, "pred_req", i))))
-            return r;
-        if (q.dst_plane == q.ref0_plane || q.dst_plane == q.ref1_plane)
-            return fail(X265_HIP_EINVAL, "pred_req[%d]: the destination plane is one of the references", i);
-        if (q.ref1_plane == X265_HIP_PRED_WEIGHTED &&
-            (q.log2_denom > 7 || q.qmv1_x < -128 || q.qmv1_x > 255 || q.qmv1_y < -128 || q.qmv1_y > 127))
-            return fail(X265_HIP_EINVAL, "pred_req[%d]: weight %d / offset %d / log2 denominator %d out of range", i, q.qmv1_x,
-                        q.qmv1_y, q.log2_denom);
-        if ((r = check_inside(c, q.dst_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, "pred_req", i)) ||
-            (r = check_displaced(c, q.ref0_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv0_x, q.qmv0_y, "pred_req", i)) ||
-            (q.ref1_plane >= 0 &&
-             (r = check_displaced(c, q.ref1_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv1_x, q.qmv1_y, "pred_req", i))))
-            return r;
+        int vr = validate_pred(c, reqs, n);
+        if (vr)
+            return vr;
     }
     int r;
     if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))))
@@ -1059,6 +1240,11 @@ int x265_hip_bidir_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n,
         return fail(X265_HIP_EINVAL, "bidir_cost_batch_device: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = checked_records<x265_hip_bidir_req>(c, d_reqs, n, [&](const x265_hip_bidir_req *h) { return validate_bidir(c, h, n); });
+        if (vr)
+            return vr;
+    }
     int r = push_tabs(c);
     if (r)
         return r;
@@ -1074,34 +1260,10 @@ int x265_hip_bidir_cost_batch(x265_hip_ctx *c, const x265_hip_bidir_req *reqs, i
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    for (int i = 0; i < n; i++)
     {
-        int r = check_block(c, reqs[i].fenc_plane, reqs[i].ref0_plane, reqs[i].pu_w, reqs[i].pu_h, "bidir_req", i);
-        if (r || (r = check_block(c, reqs[i].fenc_plane, reqs[i].ref1_plane, reqs[i].pu_w, reqs[i].pu_h, "bidir_req", i)))
-            return r;
-        const x265_hip_bidir_req &q = reqs[i];
-        if ((q.metric & ~(X265_HIP_LOWRES_REF | X265_HIP_MC_AVG)) > X265_HIP_SSE ||
-            (q.metric & (X265_HIP_LOWRES_REF | X265_HIP_MC_AVG)) == (X265_HIP_LOWRES_REF | X265_HIP_MC_AVG))
-            return fail(X265_HIP_EINVAL, "bidir_req[%d]: unknown metric %d", i, q.metric);
-        if (q.metric & X265_HIP_LOWRES_REF)
-        {
-            // Lowres references: the lookahead's 8x8 CU, four planes of one stride per reference
-            if (q.pu_w != 8 || q.pu_h != 8)
-                return fail(X265_HIP_EINVAL, "bidir_req[%d]: lowres references take 8x8 blocks only (lowres.h:64)", i);
-            for (int rp : { q.ref0_plane, q.ref1_plane })
-            {
-                if (rp + 3 >= X265_HIP_MAX_PLANES)
-                    return fail(X265_HIP_EINVAL, "bidir_req[%d]: lowres planes %d..%d out of range", i, rp, rp + 3);
-                for (int k = 1; k < 4; k++)
-                    if (!c->host_tabs.planes[rp + k].origin || c->host_tabs.planes[rp + k].stride != c->host_tabs.planes[rp].stride ||
-                        c->plane_bytes[rp + k] != c->plane_bytes[rp] || c->plane_origin[rp + k] != c->plane_origin[rp])
-                        return fail(X265_HIP_EINVAL, "bidir_req[%d]: lowres plane %d missing or of another layout", i, rp + k);
-            }
-        }
-        if ((r = check_inside(c, q.fenc_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, "bidir_req", i)) ||
-            (r = check_displaced(c, q.ref0_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv0_x, q.qmv0_y, "bidir_req", i)) ||
-            (r = check_displaced(c, q.ref1_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv1_x, q.qmv1_y, "bidir_req", i)))
-            return r;
+        int vr = validate_bidir(c, reqs, n);
+        if (vr)
+            return vr;
     }
     int r;
     if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))) ||
@@ -1121,6 +1283,11 @@ int x265_hip_fullsearch_device(x265_hip_ctx *c, const void *d_jobs, int n, void 
         return fail(X265_HIP_EINVAL, "fullsearch_device: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = checked_records<x265_hip_ctu_job>(c, d_jobs, n, [&](const x265_hip_ctu_job *h) { return validate_ctu(c, h, n); });
+        if (vr)
+            return vr;
+    }
     int r = push_tabs(c);
     if (r)
         return r;
@@ -1136,22 +1303,10 @@ int x265_hip_fullsearch(x265_hip_ctx *c, const x265_hip_ctu_job *jobs, int n, x2
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    for (int i = 0; i < n; i++)
     {
-        const x265_hip_ctu_job &j = jobs[i];
-        int r = check_block(c, j.fenc_plane, j.ref_plane, 64, 64, "ctu_job", i);
-        if (r)
-            return r;
-        if (j.qp >= X265_HIP_MAX_QP || !c->host_tabs.costtab[j.qp])
-            return fail(X265_HIP_EINVAL, "ctu_job[%d]: no cost table uploaded for qp %d", i, j.qp);
-        if (j.mvmin_x > j.mvmax_x || j.mvmin_y > j.mvmax_y)
-            return fail(X265_HIP_EINVAL, "ctu_job[%d]: empty search range", i);
-        if (j.mvmax_x - j.mvmin_x > 131 || j.mvmax_y - j.mvmin_y > 131)
-            return fail(X265_HIP_ERANGE, "ctu_job[%d]: window wider than 132 positions", i);
-        if ((r = check_inside(c, j.fenc_plane, j.ctu_x, j.ctu_y, 64, 64, "ctu_job", i)) ||
-            (r = check_reach(c, j.ref_plane, j.ctu_x + j.mvmin_x, j.ctu_y + j.mvmin_y, j.ctu_x + j.mvmax_x + 64,
-                             j.ctu_y + j.mvmax_y + 64, "ctu_job", i)))
-            return r;
+        int vr = validate_ctu(c, jobs, n);
+        if (vr)
+            return vr;
     }
     const size_t ob = (size_t)n * X265_HIP_PUS_PER_CTU * sizeof(*results);
     int r;

@@ -37,7 +37,7 @@ EXPORTS = [
     "x265_hip_dist_batch", "x265_hip_dist_batch_device", "x265_hip_predict_batch", "x265_hip_predict_batch_device",
     "x265_hip_cost_batch_device_noalloc", "x265_hip_refine_batch", "x265_hip_refine_batch_device",
     "x265_hip_inter_search_batch", "x265_hip_inter_search_batch_device",
-    "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device",
+    "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device", "x265_hip_ctx_check_records",
 ]
 
 
@@ -201,6 +201,10 @@ class Context:
         out = np.zeros(len(jobs), INTER_RESULT)
         _check(load().x265_hip_inter_search_batch(self._h, _p(jobs), C.c_int(len(jobs)), C.c_int(pic_width), C.c_int(pic_height), _p(out)))
         return out
+
+    def check_records(self, on=True):
+        """record-check mode of the *_device entry points (debugging aid)"""
+        _check(load().x265_hip_ctx_check_records(self._h, C.c_int(1 if on else 0)))
 
     def lookahead_batch(self, jobs, width_in_cu, height_in_cu):
         """(n, height_in_cu, width_in_cu) results: the whole-frame searches of the lookahead"""
