@@ -59,16 +59,16 @@ __device__ __forceinline__ uint32_t ld4g(gptr_t p)
     return v;
 }
 
-// 12 bytes from any byte address as three dwords, fetched as one dword-aligned 16-byte load and shifted
-// into place (the texture-address unit splits unaligned multi-dword loads; the aligned form is one pass)
+// 12 bytes from any byte address as three dwords, as one unaligned global_load_dwordx3.  (Round 1 fetched the
+// enclosing aligned 16 bytes and shifted them into place with three v_alignbyte: one pass through the texture-address
+// unit instead of two, but these kernels are short of VALU issue slots, not of load bandwidth: me_kernel 3 % faster
+// with the plain load, cost_kernel unchanged.)
 __device__ __forceinline__ void ld12g(gptr_t p, uint32_t &d0, uint32_t &d1, uint32_t &d2)
 {
-    const unsigned s = (unsigned)(uintptr_t)p & 3u;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 w = *(const __attribute__((address_space(1))) u32x4 *)(p - s);
-    d0 = __builtin_amdgcn_alignbyte(w.y, w.x, s);
-    d1 = __builtin_amdgcn_alignbyte(w.z, w.y, s);
-    d2 = __builtin_amdgcn_alignbyte(w.w, w.z, s);
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    u32x3 w;
+    __builtin_memcpy(&w, (const void *)p, 12);
+    d0 = w.x, d1 = w.y, d2 = w.z;
 }
 
 __device__ __forceinline__ int byte_of(uint32_t v, int i)
