@@ -311,11 +311,110 @@ int device_low_ref(pixel *const planes[4], int stride, int lines)
 #ifdef WITH_HIP
 /* X265_USE_HIP_LOOKAHEAD: whole-frame lookahead searches (see the head of this file) */
 namespace {
-int g_hip_look = 0;
-long g_look_frames = 0, g_look_mismatch = 0;
+int g_hip_look = 0; /* 1 / 2: one launch per (picture, reference) pair, with / without the reference's own search beside it;
+                     * 3 / 4: the same with the pairs of a picture batched ahead of their use (see look_trigger) */
+long g_look_frames = 0, g_look_launches = 0, g_look_mismatch = 0, g_look_hits = 0, g_look_unused = 0;
 std::atomic<long> g_look_calls(0);
 double g_look_seconds = 0;
-std::map<std::pair<const void *, const void *>, std::vector<x265_hip_me_result> > g_look;
+struct LookEntry
+{
+    uint32_t fsum, rsum; /* content of the source plane and of the four reference planes the results were made from */
+    bool valid, used;
+    std::vector<x265_hip_me_result> res;
+};
+typedef std::pair<const void *, const void *> LookKey; /* (source lowresPlane[0], reference lowresPlane[0]) */
+std::map<LookKey, LookEntry> g_look;
+std::map<const pixel *, Lowres *> g_live; /* every Lowres that went through Lowres::init, by its lowresPlane[0] */
+
+uint32_t low_sum(const pixel *origin, int stride, int lines)
+{
+    return sparse_sum(origin - (intptr_t)MY * stride - MX, (size_t)stride * (lines + 2 * MY));
+}
+
+uint32_t low_sum4(pixel *const planes[4], int stride, int lines)
+{
+    uint32_t sum = 0;
+    for (int k = 0; k < 4; k++)
+        sum = sum * 31 + low_sum(planes[k], stride, lines);
+    return sum;
+}
+
+/* The first lowres motionEstimate call of a frame cost estimate's list (CU (W - 1, H - 1)).  Modes 1 / 2 search the
+ * pair.  Modes 3 / 4 first look for results made ahead of time from the same plane contents; failing that they
+ * search the pair together with every other pair (this picture, picture within bframes + 1 of it) the lookahead may
+ * ask for next -- the search of a pair depends on nothing but the two pictures (lowresMvs[list][dist] is keyed by
+ * the pair) -- in one launch, which takes about as long as the launch for one pair. */
+LookEntry *look_trigger(MotionEstimate *self, ReferencePlanes *ref, int merange, int W, int H, int lines)
+{
+    const int stride = (int)self->fencLumaStride;
+    const LookKey key((const void *)self->fencplane, (const void *)ref->lowresPlane[0]);
+    const bool batched = g_hip_look >= 3;
+    const uint32_t fsum = low_sum(self->fencplane, stride, lines), rsum = low_sum4(ref->lowresPlane, ref->lumaStride, lines);
+    LookEntry &e = g_look[key];
+    g_look_frames++;
+    if (batched && e.valid && e.fsum == fsum && e.rsum == rsum)
+    {
+        g_look_hits++;
+        e.used = true;
+        return &e;
+    }
+    std::vector<x265_hip_lookahead_job> jobs;
+    std::vector<LookEntry *> dst;
+    x265_hip_lookahead_job j;
+    memset(&j, 0, sizeof(j));
+    j.merange = (int16_t)merange;
+    j.method = (uint8_t)self->searchMethod;
+    j.subme = (uint8_t)self->subpelRefine;
+    j.qp = (uint8_t)qp_of(self->m_cost);
+    if (!g_qp_set[1][j.qp])
+    {
+        x265_hip_costtab_set_qp(g_ctx_low, j.qp);
+        g_qp_set[1][j.qp] = true;
+    }
+    j.fenc_plane = device_low_src(self->fencplane, stride, lines);
+    j.ref_plane = device_low_ref(ref->lowresPlane, ref->lumaStride, lines);
+    jobs.push_back(j);
+    e.fsum = fsum, e.rsum = rsum, e.valid = true, e.used = true;
+    dst.push_back(&e);
+    std::map<const pixel *, Lowres *>::iterator me = g_live.find(self->fencplane);
+    if (batched && me != g_live.end())
+    {
+        const int num = me->second->frameNum, reach = me->second->bframes + 1;
+        for (std::map<const pixel *, Lowres *>::iterator it = g_live.begin(); it != g_live.end() && jobs.size() < 11; ++it)
+        {
+            Lowres *l = it->second;
+            if (l == me->second || l->lowresPlane[0] == ref->lowresPlane[0] || l->frameNum < 0 || abs(l->frameNum - num) > reach)
+                continue;
+            LookEntry &o = g_look[LookKey((const void *)self->fencplane, (const void *)l->lowresPlane[0])];
+            const uint32_t osum = low_sum4(l->lowresPlane, l->lumaStride, lines);
+            if (o.valid && o.fsum == fsum && o.rsum == osum)
+                continue;
+            if (o.valid && !o.used)
+                g_look_unused++;
+            j.ref_plane = device_low_ref(l->lowresPlane, l->lumaStride, lines);
+            jobs.push_back(j);
+            o.fsum = fsum, o.rsum = osum, o.valid = true, o.used = false;
+            dst.push_back(&o);
+        }
+    }
+    std::vector<x265_hip_me_result> out((size_t)W * H * jobs.size());
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    if (x265_hip_lookahead_batch(g_ctx_low, jobs.data(), (int)jobs.size(), W, H, out.data()) != X265_HIP_OK)
+    {
+        fprintf(stderr, "lookahead_batch: %s\n", x265_hip_last_error());
+        abort();
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    g_look_seconds += (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+    g_look_launches++;
+    for (size_t k = 0; k < jobs.size(); k++)
+    {
+        dst[k]->res.resize((size_t)W * H); /* sized once: readers keep pointers into it */
+        memcpy(dst[k]->res.data(), out.data() + k * (size_t)W * H, (size_t)W * H * sizeof(x265_hip_me_result));
+    }
+    return &e;
+}
 
 int look_answer(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const MV &mvmax, const MV &qmvp, int numc, const MV *mvc,
                 int merange, MV &out)
@@ -324,58 +423,33 @@ int look_answer(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, con
     /* Lookahead::Lookahead, slicetype.cpp:62-63; Lowres::create, lowres.cpp:33-48 */
     const int W = ((g_width / 2) + 7) >> 3, H = ((g_height / 2) + 7) >> 3, lines = ((g_height / 2) + 7) / 8 * 8;
     const int cux = (int)(self->blockOffset % stride) / 8, cuy = (int)(self->blockOffset / stride) / 8;
-    const std::pair<const void *, const void *> key((const void *)self->fencplane, (const void *)ref);
+    const LookKey key((const void *)self->fencplane, (const void *)ref->lowresPlane[0]);
     /* A pair's results are looked up under the lock once per thread and search: the vector a pair's results live in
      * is never reallocated (its size is the picture's), and a pair is searched again only after the encoder has
      * finished the estimate that used the previous results. */
-    static thread_local std::pair<const void *, const void *> t_key;
+    static thread_local LookKey t_key;
     static thread_local const x265_hip_me_result *t_res = nullptr;
     if (cux == W - 1 && cuy == H - 1)
     {
         std::lock_guard<std::mutex> g(g_mu);
-        x265_hip_lookahead_job j;
-        memset(&j, 0, sizeof(j));
-        j.fenc_plane = device_low_src(self->fencplane, stride, lines);
-        j.ref_plane = device_low_ref(ref->lowresPlane, ref->lumaStride, lines);
-        j.merange = (int16_t)merange;
-        j.method = (uint8_t)self->searchMethod;
-        j.subme = (uint8_t)self->subpelRefine;
-        j.qp = (uint8_t)qp_of(self->m_cost);
-        if (!g_qp_set[1][j.qp])
-        {
-            x265_hip_costtab_set_qp(g_ctx_low, j.qp);
-            g_qp_set[1][j.qp] = true;
-        }
-        std::vector<x265_hip_me_result> &v = g_look[key];
-        v.resize((size_t)W * H);
-        struct timespec t0, t1;
-        clock_gettime(CLOCK_MONOTONIC, &t0);
-        if (x265_hip_lookahead_batch(g_ctx_low, &j, 1, W, H, v.data()) != X265_HIP_OK)
-        {
-            fprintf(stderr, "lookahead_batch: %s\n", x265_hip_last_error());
-            abort();
-        }
-        clock_gettime(CLOCK_MONOTONIC, &t1);
-        g_look_seconds += (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
-        g_look_frames++;
+        t_res = look_trigger(self, ref, merange, W, H, lines)->res.data();
         t_key = key;
-        t_res = v.data();
     }
     else if (!t_res || t_key != key)
     {
         std::lock_guard<std::mutex> g(g_mu);
-        std::map<std::pair<const void *, const void *>, std::vector<x265_hip_me_result> >::iterator it = g_look.find(key);
-        if (it == g_look.end())
+        std::map<LookKey, LookEntry>::iterator it = g_look.find(key);
+        if (it == g_look.end() || !it->second.valid)
         {
             fprintf(stderr, "enc_capture: lowres call for CU (%d, %d) before the frame's first CU\n", cux, cuy);
             abort();
         }
         t_key = key;
-        t_res = it->second.data();
+        t_res = it->second.res.data();
     }
     const x265_hip_me_result r = t_res[(size_t)cuy * W + cux];
     g_look_calls++;
-    if (g_hip_look == 1)
+    if (g_hip_look & 1)
     {
         MV own;
         const int cost = real_me(self, ref, mvmin, mvmax, qmvp, numc, mvc, merange, own);
@@ -425,6 +499,11 @@ void planes_fail(const char *what)
 void wrap_li(Lowres *self, TComPicYuv *orig, int poc, int type)
 {
     real_li(self, orig, poc, type);
+    if (g_hip_look >= 3)
+    {
+        std::lock_guard<std::mutex> g(g_mu);
+        g_live[self->lowresPlane[0]] = self;
+    }
     if (!g_hip_planes)
         return;
     std::lock_guard<std::mutex> g(g_mu);
@@ -822,10 +901,13 @@ int main(int argc, char **argv)
             fprintf(stderr, "x265_hip_ctx_create: %s\n", x265_hip_last_error());
             return 1;
         }
-        g_hip_look = atoi(getenv("X265_USE_HIP_LOOKAHEAD")) == 2 ? 2 : 1;
+        g_hip_look = atoi(getenv("X265_USE_HIP_LOOKAHEAD"));
+        if (g_hip_look < 1 || g_hip_look > 4)
+            g_hip_look = 1;
         g_hip_sparse = true;
-        fprintf(stderr, "enc_capture: the lookahead's motion searches answered a frame at a time by x265_hip_lookahead_batch%s\n",
-                g_hip_look == 2 ? " (the reference's own search does not run)" : "");
+        fprintf(stderr, "enc_capture: the lookahead's motion searches answered a frame at a time by x265_hip_lookahead_batch%s%s\n",
+                g_hip_look >= 3 ? ", the pairs of a picture batched ahead of their use" : "",
+                (g_hip_look & 1) ? "" : " (the reference's own search does not run)");
     }
     if (getenv("X265_USE_HIP_ME") && !g_hip_look)
     {
@@ -909,9 +991,14 @@ int main(int argc, char **argv)
         fprintf(stderr, "enc_capture: %ld motionCompensation luma blocks predicted on the GPU (%ld weighted, %ld bi-directional), %ld differed from the reference's own pixels, %ld left alone\n",
                 g_mc_calls, g_mc_weighted, g_mc_bi, g_mc_mismatch, g_mc_skipped);
     if (g_hip_look)
-        fprintf(stderr, "enc_capture: %ld lookahead frame searches on the GPU in %.3f s (%.3f ms each, upload and download included), %ld lowres motionEstimate calls answered from them, %ld differed from the reference's own answer%s\n",
-                g_look_frames, g_look_seconds, g_look_frames ? 1e3 * g_look_seconds / g_look_frames : 0.0, g_look_calls.load(), g_look_mismatch,
-                g_hip_look == 2 ? " (not compared in this mode)" : "");
+    {
+        fprintf(stderr, "enc_capture: %ld lookahead frame searches asked for, %ld launches of x265_hip_lookahead_batch in %.3f s (%.3f ms each, upload and download included), %ld lowres motionEstimate calls answered from them, %ld differed from the reference's own answer%s\n",
+                g_look_frames, g_look_launches, g_look_seconds, g_look_launches ? 1e3 * g_look_seconds / g_look_launches : 0.0,
+                g_look_calls.load(), g_look_mismatch, (g_hip_look & 1) ? "" : " (not compared in this mode)");
+        if (g_hip_look >= 3)
+            fprintf(stderr, "enc_capture: %ld of the searches asked for had been made ahead of time; %ld searches made ahead were replaced unused\n",
+                    g_look_hits, g_look_unused);
+    }
     if (g_hip_me)
     {
         fprintf(stderr, "enc_capture: %ld motionEstimate calls answered on the GPU, %ld differed from the reference's own answer\n",

@@ -95,12 +95,13 @@ ENC_HIP = os.path.join(ROOT, "oracle", "_ref", "enc_hip")
 
 
 @pytest.mark.skipif(not os.path.exists(ENC_HIP), reason="oracle/_ref/enc_hip not built (needs the reference sources)")
-@pytest.mark.parametrize("fade", [False, True])
-def test_whole_frame_lookahead_inside_the_reference_encoder(tmp_path, fade):
-    """the reference encoder with every lookahead frame cost search done by one x265_hip_lookahead_batch launch
-    (X265_USE_HIP_LOOKAHEAD=1: each of its lowres motionEstimate calls is answered from the launch's results and also
-    run by the reference itself and compared): no call may differ and the bitstream must be the one the unmodified
-    encoder writes; with `fade` the clip fades to black so that the lookahead searches weighted references"""
+@pytest.mark.parametrize("fade,mode", [(False, 1), (True, 1), (False, 3), (True, 3)])
+def test_whole_frame_lookahead_inside_the_reference_encoder(tmp_path, fade, mode):
+    """the reference encoder with every lookahead frame cost search done by x265_hip_lookahead_batch
+    (X265_USE_HIP_LOOKAHEAD=1: one launch per (picture, reference) pair; 3: the pairs of a picture batched ahead of their
+    use; in both every lowres motionEstimate call is answered from the launches' results and also run by the reference
+    itself and compared): no call may differ and the bitstream must be the one the unmodified encoder writes; with
+    `fade` the clip fades to black so that the lookahead searches weighted references"""
     import re
     from x265_amd import synth
     W, H, N = 640, 360, 12
@@ -117,11 +118,12 @@ def test_whole_frame_lookahead_inside_the_reference_encoder(tmp_path, fade):
     env = {k: v for k, v in os.environ.items() if not k.startswith("X265_USE_HIP")}
     plain = subprocess.run(args, capture_output=True, text=True, timeout=100, env=env)
     assert plain.returncode == 0, plain.stderr[-2000:]
-    hip = subprocess.run(args, capture_output=True, text=True, timeout=100, env=dict(env, X265_USE_HIP_LOOKAHEAD="1"))
+    hip = subprocess.run(args, capture_output=True, text=True, timeout=100, env=dict(env, X265_USE_HIP_LOOKAHEAD=str(mode)))
     assert hip.returncode == 0, hip.stderr[-2000:]
     h0, h1 = re.search(r"hash ([0-9a-f]+)", plain.stderr), re.search(r"hash ([0-9a-f]+)", hip.stderr)
     assert h0 and h1 and h0.group(1) == h1.group(1), (plain.stderr[-500:], hip.stderr[-500:])
-    m = re.search(r"(\d+) lookahead frame searches on the GPU.* (\d+) lowres motionEstimate calls answered from them, (\d+) differed", hip.stderr)
+    m = re.search(r"(\d+) lookahead frame searches asked for, (\d+) launches.* (\d+) lowres motionEstimate calls answered from them, (\d+) differed", hip.stderr)
     assert m, hip.stderr[-1000:]
-    frames, calls, differed = (int(v) for v in m.groups())
+    frames, launches, calls, differed = (int(v) for v in m.groups())
     assert frames >= 10 and calls == frames * ((W // 2 + 7) // 8) * ((H // 2 + 7) // 8) and differed == 0, hip.stderr[-1000:]
+    assert launches == frames if mode == 1 else launches < frames, hip.stderr[-1000:]

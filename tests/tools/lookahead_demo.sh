@@ -2,7 +2,8 @@
 # Whole-frame lookahead inside the reference encoder: oracle/_ref/enc_hip (the reference's own sources
 # + libx265_hip.so) encodes the same clip with its own lookahead search, with every frame cost estimate's search done
 # by one x265_hip_lookahead_batch launch and compared call by call with the reference's own (X265_USE_HIP_LOOKAHEAD=1),
-# and with the reference's search not run at all (=2, the timing run).  The bitstreams must be identical.
+# with the reference's search not run at all (=2, the timing run), and again (=3, =4) with the pairs of a picture searched
+# in one launch ahead of their use.  The bitstreams must be identical.
 #   tests/tools/lookahead_demo.sh [width height frames [pool_threads]]      DROPIN_FADE=1: weighted references
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
@@ -31,9 +32,15 @@ echo "== frame searches by x265_hip_lookahead_batch, compared with the reference
 X265_USE_HIP_LOOKAHEAD=1 run | tee /tmp/look_v.txt || exit 1
 echo "== frame searches by x265_hip_lookahead_batch alone"
 X265_USE_HIP_LOOKAHEAD=2 run | tee /tmp/look_t.txt || exit 1
+echo "== the pairs of a picture batched ahead of their use, compared with the reference's own"
+X265_USE_HIP_LOOKAHEAD=3 run | tee /tmp/look_bv.txt || exit 1
+echo "== batched ahead, x265_hip_lookahead_batch alone"
+X265_USE_HIP_LOOKAHEAD=4 run | tee /tmp/look_bt.txt || exit 1
 a=$(grep -o "hash [0-9a-f]*" /tmp/look_c.txt); b=$(grep -o "hash [0-9a-f]*" /tmp/look_v.txt); c=$(grep -o "hash [0-9a-f]*" /tmp/look_t.txt)
-if [ -n "$a" ] && [ "$a" == "$b" ] && [ "$a" == "$c" ] && grep -q "answered from them, 0 differed" /tmp/look_v.txt; then
+d=$(grep -o "hash [0-9a-f]*" /tmp/look_bv.txt); e=$(grep -o "hash [0-9a-f]*" /tmp/look_bt.txt)
+if [ -n "$a" ] && [ "$a" == "$b" ] && [ "$a" == "$c" ] && [ "$a" == "$d" ] && [ "$a" == "$e" ] && grep -q "answered from them, 0 differed" /tmp/look_v.txt &&
+   grep -q "answered from them, 0 differed" /tmp/look_bv.txt; then
   echo "LOOKAHEAD DROP-IN OK: identical bitstreams ($a)"
 else
-  echo "LOOKAHEAD DROP-IN MISMATCH: '$a' vs '$b' vs '$c'"; exit 1
+  echo "LOOKAHEAD DROP-IN MISMATCH: '$a' vs '$b' vs '$c' vs '$d' vs '$e'"; exit 1
 fi
