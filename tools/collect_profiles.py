@@ -62,9 +62,6 @@ with open(os.path.join(DST, f"{tag}_pmc_sq.csv"), "w") as f:
     for (k, c) in sorted(sq):
         v = sq[(k, c)]
         f.write(f"{k},{c},{mean(v):.0f},{len(v)}\n")
-        if k == "refine_kernel":
-            for i, s in enumerate((64, 32, 16, 8)):
-                f.write(f"{k}[pu {s}],{c},{mean(v[i::4]):.0f},{len(v[i::4])}\n")
 # 3. HBM traffic (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE in separate passes, KiB units; on gfx950 FETCH_SIZE counts
 # half of what 16-byte-per-lane streaming reads move: raw and 2 x raw are both given, the corrected figure is the one
 # quoted for kernels that stage with 16-byte loads)
@@ -73,30 +70,27 @@ wr = pmc("pmc_write/**/*counter_collection.csv")
 import ast
 run = next(ast.literal_eval(l) for l in open(os.path.join(SRC, "pmc_fetch.log")) if l.startswith("{"))
 traffic = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/prof_4k.py (one 4K P picture against "
-                   "3 references: rings of 8 per PU size through refine_kernel, the same candidates as single requests through "
+                   "3 references: rings of 8 through refine_kernel (the four PU sizes as four runs of one launch), the same candidates as single requests through "
                    "cost_kernel, 516 k motionEstimate calls through me_kernel, 2040 CTU full searches, 12 lookahead frame searches of "
                    "240 x 135 CUs), mean per launch, bytes = KiB x 1024.  *_4k keys: bytes per bench step, as bench.py's `traffic` "
-                   "(refine_kernel: the four launches of a step added up); fetch is given raw and x 2 (gfx950: FETCH_SIZE reports half "
+                   "fetch is given raw and x 2 (gfx950: FETCH_SIZE reports half "
                    "the bytes of 16-byte-per-lane reads; refine_kernel and fullsearch2_kernel read 16 bytes per lane, cost_kernel "
                    "and me_kernel mostly 4), hbm_bytes = corrected fetch + write for the 16-byte kernels, raw fetch + write otherwise",
            "workload": run}
 wide = {"refine_kernel", "fullsearch2_kernel"}
 for k in sorted({k for (k, _) in fe}):
     f_, w_ = fe[(k, "FETCH_SIZE")], wr.get((k, "WRITE_SIZE"), [0.0])
-    per_step = 4 if k == "refine_kernel" else 1
+    per_step = 1
     fb, wb = mean(f_) * 1024 * per_step, mean(w_) * 1024 * per_step
     d = {"launches_per_step": per_step, "fetch_bytes_raw": fb, "fetch_bytes_x2": 2 * fb, "write_bytes": wb,
          "hbm_bytes": (2 * fb if k in wide else fb) + wb, "kernel_us_mean": mean(dur[k]) * per_step if k in dur else None}
-    if k == "refine_kernel":
-        d["per_pu_size"] = {str(s): {"fetch_bytes_raw": mean(f_[i::4]) * 1024, "write_bytes": mean(w_[i::4]) * 1024,
-                                     "kernel_us": mean(dur[k][i::4])} for i, s in enumerate((64, 32, 16, 8))}
     traffic[k + "_4k_detail"] = d
     traffic[k + "_4k"] = d["hbm_bytes"]
 json.dump(traffic, open(os.path.join(DST, f"{tag}_traffic.json"), "w"), indent=1)
 print("wrote", sorted(p for p in os.listdir(DST) if p.startswith(tag)))
 
 # 4. the bench run's timed launches, leg by leg, from the kernel trace of the same run: the legs run one after the other
-# (rings, single requests, motionEstimate, full search at 4K; then 1080p), so the last `steps` launches (x 4 for the
+# (rings, single requests, motionEstimate, full search at 4K; then 1080p), so the last `steps` launches of a kernel in
 # rings) of a kernel in front of the next leg's first launch are the timed ones.  Compared with the HIP-event times
 # bench.py printed in that run.
 bt = list(csv.DictReader(open(find("stats/**/*kernel_trace.csv"))))
@@ -112,7 +106,7 @@ for i, k in enumerate(order):
     while pos < len(seqk) and seqk[pos][0] == k:
         pos += 1
     block = [d for _, d in seqk[start:pos]]
-    per = 4 if k == "refine_kernel" else 1
+    per = 1
     timed = block[-K * per:]
     legs[k] = {"launches_in_leg": len(block), "timed_launches": len(timed), "trace_ms_per_step": sum(timed) / K,
                "trace_mean_launch_us": 1e3 * sum(timed) / len(timed)}

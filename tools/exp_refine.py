@@ -58,6 +58,23 @@ rrq = synth.refine_requests(W, H, 3, refs, mot)
 run("all sizes", crq, rrq)
 o = np.argsort(-rrq["pu_w"].astype(int), kind="stable")
 run("sorted", crq, rrq[o], check=False)
+per_size = 0.0
 for s in (64, 32, 16, 8):
-    run(f"{s}x{s}", crq[crq["pu_w"] == s], rrq[rrq["pu_w"] == s])
+    sel = rrq[rrq["pu_w"] == s]
+    run(f"{s}x{s}", crq[crq["pu_w"] == s], sel)
+    d_r, o_r = DeviceBuffer.from_array(sel), DeviceBuffer(36 * len(sel))
+    per_size += timed(lambda: ctx.refine_batch_device(d_r.ptr, len(sel), o_r.ptr))
+# the four sizes as one list of four runs, one launch (x265_hip_refine_sections_device)
+srt = rrq[o]
+d_r, o_r = DeviceBuffer.from_array(srt), DeviceBuffer(36 * len(srt))
+secs = [(int((srt["pu_w"] == s).sum()), s, s) for s in (64, 32, 16, 8)]
+ms = timed(lambda: ctx.refine_sections_device(d_r.ptr, secs, o_r.ptr))
+ops = synth.satd_lane_ops(crq)
+print(f"one launch per size: {per_size:.3f} ms   four runs in one launch: {ms:.3f} ms  {8 * len(srt) / ms * 1e3:9.3e}/s  "
+      f"({ops / ms * 1e3 / 7.86e13:.3f} of 7.86e13)")
+# same numbers as the single-run launches
+one = DeviceBuffer(36 * len(srt))
+ctx.refine_batch_device(d_r.ptr, len(srt), one.ptr)
+ctx.sync()
+assert np.array_equal(o_r.download(np.int32), one.download(np.int32)), "sections differ from the plain launch"
 ctx.close()

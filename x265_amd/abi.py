@@ -107,6 +107,10 @@ INTER_RESULT = np.dtype([
 ])
 assert INTER_RESULT.itemsize == 32
 
+REFINE_SECTION = np.dtype([("count", "<i4"), ("pu_w", "u1"), ("pu_h", "u1"), ("pad", "u1", (2,))])
+assert REFINE_SECTION.itemsize == 8
+MAX_SECTIONS = 4
+
 # x265_hip_lookahead_job: the motion search of one (picture, reference) pair of a lookahead frame cost estimate
 LOOKAHEAD_JOB = np.dtype([
     ("fenc_plane", "<i4"), ("ref_plane", "<i4"), ("merange", "<i2"),

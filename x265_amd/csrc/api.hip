@@ -1126,6 +1126,45 @@ int x265_hip_refine_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, voi
     return X265_HIP_OK;
 }
 
+int x265_hip_refine_sections_device(x265_hip_ctx *c, const void *d_reqs, const x265_hip_refine_section *sections, int nsections, void *d_costs9)
+{
+    if (!c || !sections || nsections < 1 || nsections > X265_HIP_MAX_SECTIONS || !d_reqs || !d_costs9)
+        return fail(X265_HIP_EINVAL, "refine_sections_device: bad argument");
+    long n = 0;
+    for (int s = 0; s < nsections; s++)
+    {
+        if (sections[s].count < 0 || x265_hip_partition_from_sizes(sections[s].pu_w, sections[s].pu_h) < 0)
+            return fail(X265_HIP_EINVAL, "refine_sections_device: section %d: %d requests of %dx%d", s, sections[s].count, sections[s].pu_w,
+                        sections[s].pu_h);
+        n += sections[s].count;
+    }
+    if (n > 0x7fffffff)
+        return fail(X265_HIP_EINVAL, "refine_sections_device: too many requests");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = checked_records<x265_hip_refine_req>(c, d_reqs, (int)n, [&](const x265_hip_refine_req *h) {
+            int r = validate_refine(c, h, (int)n);
+            long i = 0;
+            for (int s = 0; s < nsections && !r; s++)
+                for (int k = 0; k < sections[s].count && !r; k++, i++)
+                    if (h[i].pu_w != sections[s].pu_w || h[i].pu_h != sections[s].pu_h)
+                        r = fail(X265_HIP_EINVAL, "refine_req[%ld]: %dx%d in a section of %dx%d", i, h[i].pu_w, h[i].pu_h, sections[s].pu_w, sections[s].pu_h);
+            return r;
+        });
+        if (vr)
+            return vr;
+    }
+    int r = push_tabs(c);
+    if (r)
+        return r;
+    LAUNCH(launch_refine_sections(c->dev_tabs, (const x265_hip_refine_req *)d_reqs, sections, nsections, (int32_t *)d_costs9, c->batch_counter,
+                                  c->batch_parity ^= 1, c->stream));
+    return X265_HIP_OK;
+}
+
 int x265_hip_refine_batch(x265_hip_ctx *c, const x265_hip_refine_req *reqs, int n, int32_t *costs9)
 {
     if (!c || n < 0 || (n && (!reqs || !costs9)))
@@ -1144,7 +1183,21 @@ int x265_hip_refine_batch(x265_hip_ctx *c, const x265_hip_refine_req *reqs, int 
     if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))) || (r = ensure(c, c->out, ob)))
         return r;
     HIP_TRY(hipMemcpyAsync(c->in.d, reqs, (size_t)n * sizeof(*reqs), hipMemcpyHostToDevice, c->stream));
-    LAUNCH(launch_refine(c->dev_tabs, (const x265_hip_refine_req *)c->in.d, n, (int32_t *)c->out.d, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    // a list made of a few runs of one PU size each goes out with its batches cut per run
+    x265_hip_refine_section runs[X265_HIP_MAX_SECTIONS];
+    int nruns = 0;
+    for (int i = 0; i < n && nruns <= X265_HIP_MAX_SECTIONS; i++)
+    {
+        if (nruns && reqs[i].pu_w == runs[nruns - 1].pu_w && reqs[i].pu_h == runs[nruns - 1].pu_h)
+            runs[nruns - 1].count++;
+        else if (nruns++ < X265_HIP_MAX_SECTIONS)
+            runs[nruns - 1] = x265_hip_refine_section{ 1, reqs[i].pu_w, reqs[i].pu_h, { 0, 0 } };
+    }
+    if (nruns <= X265_HIP_MAX_SECTIONS)
+        LAUNCH(launch_refine_sections(c->dev_tabs, (const x265_hip_refine_req *)c->in.d, runs, nruns, (int32_t *)c->out.d, c->batch_counter,
+                                      c->batch_parity ^= 1, c->stream));
+    else
+        LAUNCH(launch_refine(c->dev_tabs, (const x265_hip_refine_req *)c->in.d, n, (int32_t *)c->out.d, c->batch_counter, c->batch_parity ^= 1, c->stream));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(costs9, c->out.h, ob);

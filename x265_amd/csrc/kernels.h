@@ -84,6 +84,8 @@ void launch_refine(const DeviceTables *tabs, const x265_hip_refine_req *reqs, in
 // `tickets`: 16 zeroed words per search; `status`: one zeroed word; `results` filled with 0xff bytes (all on `st`, before)
 void launch_lookahead(const DeviceTables *tabs, const x265_hip_lookahead_job *jobs, int njobs, int w_cu, int h_cu, uint32_t *tickets,
                       x265_hip_me_result *results, int *status, hipStream_t st);
+void launch_refine_sections(const DeviceTables *tabs, const x265_hip_refine_req *reqs, const x265_hip_refine_section *sections, int nsec,
+                            int32_t *out, uint32_t *counters, int parity, hipStream_t st);
 void launch_prim_cmp(const PrimCmpArgs &a, int32_t *out, hipStream_t st);
 void launch_prim_filter(const PrimFilterArgs &a, hipStream_t st);
 void launch_fullsearch2(const DeviceTables *tabs, const x265_hip_ctu_job *jobs, int n, x265_hip_me_result *out,

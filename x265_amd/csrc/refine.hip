@@ -59,6 +59,16 @@ __device__ __constant__ __attribute__((aligned(16))) const uint32_t k_ring_taps[
 // index into square1 (motion.cpp:71-73) of grid position (k, j) = (dx + 1, dy + 1)
 __device__ __constant__ const uint8_t k_sq_of[3][3] = { { 5, 3, 6 }, { 1, 0, 2 }, { 7, 4, 8 } };
 
+// A list made of up to four runs of requests of one PU size each (the sizes an encoder works through: 64, 32, 16, 8):
+// run s holds requests req0[s] .. req0[s + 1] - 1 in batches of rb[s], its first batch is number bat0[s] of the launch.
+// One launch for the four runs instead of four launches: the short batches of the small sizes fill the end of the
+// launch, where a launch of large blocks alone leaves waves idle for up to one long batch.
+struct RingSections
+{
+    int nsec; // 0: no runs given, the kernel sizes its batches from a sample of the list
+    int req0[5], bat0[5], rb[4];
+};
+
 struct RingLds
 {
     int pre[RF_BATCH + 1]; // exclusive prefix of the requests' strip counts
@@ -220,7 +230,7 @@ __device__ __forceinline__ void ring_strip(gptr_t src, int stride, int fx, int j
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RF_WAVES))) void refine_kernel(const DeviceTables *tabs, const x265_hip_refine_req *reqs,
-                                                                                           int n, int32_t *out, uint32_t *counters, int parity, int rb, int max_items, int max_items_one)
+                                                                                           int n, int32_t *out, uint32_t *counters, int parity, int rb, int max_items, int max_items_one, RingSections secs)
 {
     __shared__ RingLds lds[4];
     __shared__ __attribute__((aligned(16))) uint32_t taps_lds[8 * 12];
@@ -239,7 +249,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RF_WAVES)))
     // size, defeats a size taken from a sample of the whole list: callers submit such lists one size at a time.
     // Deciding the length of a run where it is taken, from the request it starts with, was tried with a
     // compare-and-swap hand-out and serialised the waves of a part: 3 us per run.)
-    if (rb > 1)
+    const bool sectioned = secs.nsec > 0;
+    if (!sectioned && rb > 1)
     {
         const int si = n >= 64 ? (int)(((unsigned long long)((unsigned)lane * 0x9E3779B1u) * (unsigned long long)n) >> 32) : lane;
         const int cnt = n < 64 ? n : 64;
@@ -254,7 +265,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RF_WAVES)))
             rb >>= 1;
         rb = uniform(rb);
     }
-    const int nbatch = (n + rb - 1) / rb;
+    const int nbatch = sectioned ? secs.bat0[secs.nsec] : (n + rb - 1) / rb;
+    // batch g of the launch: its first request, the end of its run and the run's batch size (all wave-uniform)
+    auto locate = [&](int g, int &first, int &limit, int &size) {
+        first = g * rb, limit = n, size = rb;
+        if (sectioned)
+        {
+            first = secs.req0[0] + g * secs.rb[0], limit = secs.req0[1], size = secs.rb[0];
+#pragma unroll
+            for (int q = 1; q < 4; q++)
+                if (q < secs.nsec && g >= secs.bat0[q])
+                    first = secs.req0[q] + (g - secs.bat0[q]) * secs.rb[q], limit = secs.req0[q + 1], size = secs.rb[q];
+        }
+    };
     const int parts = min((int)gridDim.x, RF_PARTS), part = blockIdx.x % parts;
     const int nwaves = 4 * (((int)gridDim.x - part + parts - 1) / parts);
     auto batch_of = [&](int j) { return ((j / RF_CHUNK) * parts + part) * RF_CHUNK + j % RF_CHUNK; };
@@ -265,8 +288,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RF_WAVES)))
         counters[((parity ^ 1) * RF_PARTS + threadIdx.x) * 16] = 0;
     int b = (blockIdx.x / parts) * 4 + (threadIdx.x >> 6);
     x265_hip_refine_req cur = {};
-    if (lane < rb && b < hi && (long)batch_of(b) * rb + lane < n)
-        cur = reqs[batch_of(b) * rb + lane];
+    if (b < hi && batch_of(b) < nbatch)
+    {
+        int first, limit, size;
+        locate(batch_of(b), first, limit, size);
+        if (lane < size && first + lane < limit)
+            cur = reqs[first + lane];
+    }
 
     while (b < hi)
     {
@@ -274,8 +302,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RF_WAVES)))
         if (lane == 0)
             nb = (int)atomicAdd(counter, 1u);
         nb = nwaves + uniform(nb);
-        const int base = batch_of(b) * rb;
-        const bool have = lane < rb && base + lane < n;
+        int base = 0, limit = 0, bsize = 0;
+        if (batch_of(b) < nbatch)
+            locate(batch_of(b), base, limit, bsize);
+        const bool have = lane < bsize && base + lane < limit;
         int ns = 0; // strips of this lane's request
         if (have)
         {
@@ -308,10 +338,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RF_WAVES)))
         for (int i = lane; i < RF_BATCH * X265_HIP_RING_COSTS; i += 64)
             L.cost[i] = 0;
         // next batch's records: in flight during this batch's arithmetic
+        if (nb < hi && batch_of(nb) < nbatch)
         {
-            const int nid = batch_of(nb) * rb + lane;
-            if (lane < rb && nb < hi && nid < n)
-                cur = reqs[nid];
+            int first, nlimit, size;
+            locate(batch_of(nb), first, nlimit, size);
+            if (lane < size && first + lane < nlimit)
+                cur = reqs[first + lane];
         }
         wave_sync();
         const int S = L.pre[RF_BATCH]; // strips of the batch; items are (k, strip), k-major
@@ -351,10 +383,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RF_WAVES)))
         }
         wave_sync();
         // ---- results: nine per request, INT_MAX where the pattern has no candidate ---------------------------------
-        for (int i = lane; i < rb * X265_HIP_RING_COSTS; i += 64)
+        for (int i = lane; i < bsize * X265_HIP_RING_COSTS; i += 64)
         {
             const int r = i / X265_HIP_RING_COSTS, k = i - r * X265_HIP_RING_COSTS;
-            if (base + r < n)
+            if (base + r < limit)
             {
                 const int info = L.info[r], ndirs = ((info >> 9) & 1) ? 8 : 4;
                 const bool used = k == 0 ? ((info >> 10) & 1) != 0 : k <= ndirs;
@@ -366,6 +398,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RF_WAVES)))
     }
 }
 
+// batch bounds (items per batch by the list's mean), see the kernel; the environment overrides are for experiments
+static int rf_max_items() { static const int v = getenv("X265_RF_ITEMS") ? atoi(getenv("X265_RF_ITEMS")) : 1024; return v; }
+static int rf_max_items_one() { static const int v = getenv("X265_RF_ITEMS1") ? atoi(getenv("X265_RF_ITEMS1")) : 256; return v; }
+
 void launch_refine(const DeviceTables *tabs, const x265_hip_refine_req *reqs, int n, int32_t *out, uint32_t *counters, int parity, hipStream_t st)
 {
     if (n <= 0)
@@ -376,10 +412,37 @@ void launch_refine(const DeviceTables *tabs, const x265_hip_refine_req *reqs, in
     int blocks = (n + 3) / 4;
     if (blocks > RF_MAX_BLOCKS)
         blocks = RF_MAX_BLOCKS;
-    // batch bounds (items per batch by the list's mean), see the kernel; the environment overrides are for experiments
-    static const int max_items = getenv("X265_RF_ITEMS") ? atoi(getenv("X265_RF_ITEMS")) : 1024;
-    static const int max_items_one = getenv("X265_RF_ITEMS1") ? atoi(getenv("X265_RF_ITEMS1")) : 256;
-    hipLaunchKernelGGL(refine_kernel, dim3(blocks), dim3(256), 0, st, tabs, reqs, n, out, counters, parity, rb, max_items, max_items_one);
+    RingSections secs = {};
+    hipLaunchKernelGGL(refine_kernel, dim3(blocks), dim3(256), 0, st, tabs, reqs, n, out, counters, parity, rb, rf_max_items(), rf_max_items_one(), secs);
+}
+
+// the list as runs of one PU size each (at most four, largest blocks first for the best packing; any order works)
+void launch_refine_sections(const DeviceTables *tabs, const x265_hip_refine_req *reqs, const x265_hip_refine_section *sections, int nsec, int32_t *out,
+                            uint32_t *counters, int parity, hipStream_t st)
+{
+    RingSections secs = {};
+    int n = 0, nbatch = 0;
+    for (int s = 0; s < nsec; s++)
+    {
+        if (sections[s].count <= 0)
+            continue;
+        const int q = secs.nsec++;
+        const int items = 3 * (sections[s].pu_w >> 2) * ((sections[s].pu_h + 7) >> 3);
+        int rb = RF_BATCH;
+        while (rb > 1 && items * rb > rf_max_items_one())
+            rb >>= 1;
+        secs.req0[q] = n, secs.bat0[q] = nbatch, secs.rb[q] = rb;
+        n += sections[s].count;
+        nbatch += (sections[s].count + rb - 1) / rb;
+    }
+    if (!secs.nsec)
+        return;
+    for (int q = secs.nsec; q < 5; q++)
+        secs.req0[q] = n, secs.bat0[q] = nbatch;
+    int blocks = (nbatch + 3) / 4;
+    if (blocks > RF_MAX_BLOCKS)
+        blocks = RF_MAX_BLOCKS;
+    hipLaunchKernelGGL(refine_kernel, dim3(blocks), dim3(256), 0, st, tabs, reqs, n, out, counters, parity, 1, rf_max_items(), rf_max_items_one(), secs);
 }
 
 } // namespace x265hip

@@ -37,7 +37,7 @@ EXPORTS = [
     "x265_hip_dist_batch", "x265_hip_dist_batch_device", "x265_hip_predict_batch", "x265_hip_predict_batch_device",
     "x265_hip_cost_batch_device_noalloc", "x265_hip_refine_batch", "x265_hip_refine_batch_device",
     "x265_hip_inter_search_batch", "x265_hip_inter_search_batch_device",
-    "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device", "x265_hip_ctx_check_records",
+    "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device", "x265_hip_ctx_check_records", "x265_hip_refine_sections_device",
 ]
 
 
@@ -201,6 +201,14 @@ class Context:
         out = np.zeros(len(jobs), INTER_RESULT)
         _check(load().x265_hip_inter_search_batch(self._h, _p(jobs), C.c_int(len(jobs)), C.c_int(pic_width), C.c_int(pic_height), _p(out)))
         return out
+
+    def refine_sections_device(self, d_reqs, sections, d_costs9):
+        """sections: [(count, pu_w, pu_h), ...] (at most abi.MAX_SECTIONS runs of one PU size each, in list order)"""
+        from .abi import REFINE_SECTION
+        sec = np.zeros(len(sections), REFINE_SECTION)
+        for i, (cnt, w, h) in enumerate(sections):
+            sec[i]["count"], sec[i]["pu_w"], sec[i]["pu_h"] = cnt, w, h
+        _check(load().x265_hip_refine_sections_device(self._h, C.c_void_p(d_reqs), _p(sec), C.c_int(len(sec)), C.c_void_p(d_costs9)))
 
     def check_records(self, on=True):
         """record-check mode of the *_device entry points (debugging aid)"""
