@@ -91,7 +91,7 @@ print("wrote", sorted(p for p in os.listdir(DST) if p.startswith(tag)))
 
 # 4. the bench run's timed launches, leg by leg, from the kernel trace of the same run: the legs run one after the other
 # (rings, single requests, motionEstimate, full search at 4K; then 1080p), so the last `steps` launches of a kernel in
-# rings) of a kernel in front of the next leg's first launch are the timed ones.  Compared with the HIP-event times
+# front of the next leg's first launch are the timed ones.  Compared with the HIP-event times
 # bench.py printed in that run.
 bt = list(csv.DictReader(open(find("stats/**/*kernel_trace.csv"))))
 bt.sort(key=lambda r: int(r["Dispatch_Id"]))
