@@ -133,6 +133,90 @@ def one(k):
 with ThreadPoolExecutor(16) as ex:
     want = np.stack(list(ex.map(one, range(nctu))))
 report("fullsearch (CTUs x 85 PUs)", got.reshape(-1), want.reshape(-1).view(got.dtype), np.repeat(cj, 85))
+# ---- round 2 entry points -----------------------------------------------------------------------------------------
+# sub-pel rings: every partition, both rings, 4 / 8 points, with / without centre, sad / satd, any centre fraction;
+# as a mixed list (sampled batches) and as runs of one size (batches cut per run; x265_hip_refine_sections_device)
+def ring_reqs(n, parts):
+    r = np.zeros(n, abi.REFINE_REQ)
+    pi = rng.integers(0, len(parts), n)
+    wh = np.array(parts)[pi]
+    r["pu_w"], r["pu_h"] = wh[:, 0], wh[:, 1]
+    r["fenc_plane"], r["ref_plane"] = rng.choice([1, 4], n), rng.choice([0, 2, 3, 4], n)
+    r["pu_x"], r["pu_y"] = rng.integers(0, W - wh[:, 0] + 1), rng.integers(0, H - wh[:, 1] + 1)
+    r["metric"] = rng.integers(0, 2, n)
+    r["pattern"] = rng.choice([abi.RING_QPEL, abi.RING_HPEL], n) | (abi.RING_8 * rng.integers(0, 2, n)) | (abi.RING_CENTRE * rng.integers(0, 2, n))
+    frac = rng.integers(0, 4, n) > 0
+    r["qmv_x"] = np.where(frac, rng.integers(-200, 200, n), 4 * rng.integers(-50, 50, n))
+    r["qmv_y"] = np.where(rng.integers(0, 4, n) > 0, rng.integers(-200, 200, n), 4 * rng.integers(-50, 50, n))
+    return r
+
+
+def ring_want(r):
+    creqs, used = abi.refine_as_cost_reqs(r)
+    w = O.cost_batch(pl, creqs.reshape(-1), nthreads=16).reshape(-1, abi.RING_COSTS)
+    return np.where(used, w, 0x7fffffff)
+
+
+rr = ring_reqs(N, abi.PARTS[1:])
+got, want = ctx.refine_batch(rr), ring_want(rr)
+report("refine_batch mixed sizes (rings)", (got != want).any(axis=1), np.zeros(len(rr), bool), rr)
+from x265_amd.hipmem import DeviceBuffer
+runs = [(64, 64, N // 40), (32, 32, N // 10), (16, 16, N // 3), (8, 8, N)]
+rs = np.concatenate([ring_reqs(n, [(w, h)]) for w, h, n in runs])
+d, o = DeviceBuffer.from_array(rs), DeviceBuffer(36 * len(rs))
+ctx.refine_sections_device(d.ptr, [(n, w, h) for w, h, n in runs], o.ptr)
+ctx.sync()
+got, want = o.download(np.int32).reshape(-1, 9), ring_want(rs)
+report("refine_sections_device (rings)", (got != want).any(axis=1), np.zeros(len(rs), bool), rs)
+
+# predInterSearch's (list, reference) iteration: AMVP pick + search window + motionEstimate, all methods but FULL
+ij = np.zeros(N, abi.INTER_JOB)
+for j in ij:
+    w, h = abi.PARTS[int(rng.integers(1, 25))]
+    cu = max(8, 1 << int(np.ceil(np.log2(max(w, h)))))
+    cx, cy = int(rng.integers(0, (W - cu) // 8 + 1)) * 8, int(rng.integers(0, (H - cu) // 8 + 1)) * 8
+    j["fenc_plane"], j["ref_plane"] = int(rng.choice([1, 4])), int(rng.choice([0, 2, 3, 4]))
+    j["pred_plane"] = j["ref_plane"] if rng.integers(3) else int(rng.choice([0, 2]))
+    j["cu_x"], j["cu_y"] = cx, cy
+    j["pu_x"], j["pu_y"] = cx + int(rng.integers(0, (cu - w) // 4 + 1)) * 4, cy + int(rng.integers(0, (cu - h) // 4 + 1)) * 4
+    j["pu_w"], j["pu_h"] = w, h
+    j["method"], j["subme"] = int(rng.integers(0, 4)), int(rng.integers(0, 8))
+    j["merange"] = int(rng.choice([4, 8, 16, 57]))
+    j["ref_lag"] = H if rng.integers(3) else int(rng.choice([8, 16, 57]))
+    j["qp"] = int(rng.integers(0, 52))
+    j["num_amvp"] = 1 + int(rng.integers(0, 4) > 0)
+    kind = int(rng.integers(4))
+    base = (0, 0) if kind == 0 else (int(rng.integers(-40, 40)), int(rng.integers(-40, 40))) if kind == 1 else \
+        (int(rng.integers(-4000, 4000)), int(rng.integers(-2500, 2500)))
+    j["amvp"][0], j["amvp"][1] = base
+    j["amvp"][2], j["amvp"][3] = (base[0] + int(rng.integers(-12, 13)), base[1] + int(rng.integers(-12, 13))) if rng.integers(3) else base
+    nm = int(rng.integers(0, 6))
+    j["num_mvc"] = nm
+    for c in range(nm):
+        j["mvc"][2 * c] = base[0] + int(rng.integers(-30, 30)) if rng.integers(3) else 0
+        j["mvc"][2 * c + 1] = base[1] + int(rng.integers(-30, 30)) if rng.integers(3) else 0
+got = ctx.inter_search_batch(ij, W, H)
+want = O.inter_search_batch(pl, tabs, ij, W, H)
+report("inter_search_batch", got, want.view(got.dtype), ij)
+
+# whole-frame lookahead searches: every ordered pair of the three natural pictures' lowres planes, a few settings
+lj = []
+for a in range(3):
+    for b in range(3):
+        if a != b:
+            for (mer, method, subme, qp) in ((16, abi.HEX, 1, 12), (8, abi.DIA, 2, 30), (32, abi.UMH, 1, 12), (16, abi.STAR, 3, 40)):
+                lj.append((4 * a, 4 * b, mer, method, subme, qp))
+lk = np.zeros(len(lj), abi.LOOKAHEAD_JOB)
+for k, (f, r, mer, method, subme, qp) in enumerate(lj):
+    lk[k]["fenc_plane"], lk[k]["ref_plane"], lk[k]["merange"] = f, r, mer
+    lk[k]["method"], lk[k]["subme"], lk[k]["qp"] = method, subme, qp
+LW, LH = size[0] // 8, size[1] // 8
+want = O.lookahead_batch(low, tabs, lk, LW, LH, nthreads=16)
+gk = lk.copy()
+gk["fenc_plane"] += 8
+gk["ref_plane"] += 8
+got = ctx.lookahead_batch(gk, LW, LH)
+report(f"lookahead_batch ({len(lk)} x {LW * LH} CUs)", got.reshape(-1), want.reshape(-1).view(got.dtype), np.repeat(lk, LW * LH))
 ctx.close()
 print("TOTAL MISMATCHES", bad_total)
 sys.exit(1 if bad_total else 0)
