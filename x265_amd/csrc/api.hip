@@ -1381,8 +1381,26 @@ int x265_hip_fullsearch(x265_hip_ctx *c, const x265_hip_ctu_job *jobs, int n, x2
 
 namespace {
 
-x265_hip_ctx *g_prim_ctx = nullptr;
+x265_hip_ctx *g_prim_ctx = nullptr; // made by x265_hip_setup_primitives; owns the host-plane registry's copies
+int g_prim_device = 0;
 std::mutex g_prim_init_mu;
+
+// The table's entries are called concurrently by every pool thread of the encoder (one MotionEstimate per CTU row,
+// SURVEY.md 8(b) "Threading").  Each calling thread gets a context of its own (stream, staging buffers) the first time
+// it calls an entry, so calls from different threads neither wait for each other's mutex nor share a stream; the
+// contexts live until the process ends.
+x265_hip_ctx *prim_ctx()
+{
+    static thread_local x265_hip_ctx *t_ctx = nullptr;
+    if (t_ctx)
+        return t_ctx;
+    if (!g_prim_ctx)
+        return nullptr;
+    x265_hip_ctx *c = nullptr;
+    if (x265_hip_ctx_create(g_prim_device, &c) != X265_HIP_OK)
+        return nullptr;
+    return t_ctx = c;
+}
 
 struct HostPlane
 {
@@ -1423,7 +1441,7 @@ int pack_region(uint8_t *dst, const uint8_t *p, long stride, int es, int w, int 
 int prim_cmp(int part, int metric, const uint8_t *fenc, intptr_t fstride, const uint8_t *const *fref, int nref,
              intptr_t rstride, int32_t *res)
 {
-    x265_hip_ctx *c = g_prim_ctx;
+    x265_hip_ctx *c = prim_ctx();
     if (!c)
         return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
     const int w = k_part_w[part], h = k_part_h[part];
@@ -1479,7 +1497,7 @@ int prim_cmp(int part, int metric, const uint8_t *fenc, intptr_t fstride, const 
 // kind: PRIM_HPP / PRIM_VPP / PRIM_HPS / PRIM_VSP.  Writes exactly w x rows elements of dst.
 int prim_filter_wh(int w, int rows, int kind, const void *src, intptr_t sstride, void *dst, intptr_t dstride, int coeff, int row_ext)
 {
-    x265_hip_ctx *c = g_prim_ctx;
+    x265_hip_ctx *c = prim_ctx();
     if (!c)
         return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
     if (coeff < 0 || coeff > 3)
@@ -1663,7 +1681,7 @@ int stage_rows(x265_hip_ctx *c, Buf &b, size_t off, const uint8_t *src, long sst
 
 int prim_avg(int part, uint8_t *dst, intptr_t ds, const uint8_t *s0, intptr_t ss0, const uint8_t *s1, intptr_t ss1)
 {
-    x265_hip_ctx *c = g_prim_ctx;
+    x265_hip_ctx *c = prim_ctx();
     if (!c)
         return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
     const int w = k_part_w[part], h = k_part_h[part];
@@ -1685,7 +1703,7 @@ int prim_avg(int part, uint8_t *dst, intptr_t ds, const uint8_t *s0, intptr_t ss
 
 int prim_addavg(int part, const int16_t *s0, const int16_t *s1, uint8_t *dst, intptr_t ss0, intptr_t ss1, intptr_t ds)
 {
-    x265_hip_ctx *c = g_prim_ctx;
+    x265_hip_ctx *c = prim_ctx();
     if (!c)
         return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
     const int w = k_part_w[part], h = k_part_h[part];
@@ -1716,7 +1734,7 @@ void t_addavg(int16_t *s0, int16_t *s1, uint8_t *dst, intptr_t ss0, intptr_t ss1
 int prim_weight(const uint8_t *src, uint8_t *dst, intptr_t ss, intptr_t ds, int width, int height, int w0, int round, int shift,
                 int offset)
 {
-    x265_hip_ctx *c = g_prim_ctx;
+    x265_hip_ctx *c = prim_ctx();
     if (!c)
         return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
     if (width <= 0 || height <= 0)
@@ -1751,7 +1769,7 @@ int prim_weight(const uint8_t *src, uint8_t *dst, intptr_t ss, intptr_t ds, int 
 
 int prim_lowres(const uint8_t *src0, uint8_t *const dst[4], intptr_t ss, intptr_t ds, int width, int height)
 {
-    x265_hip_ctx *c = g_prim_ctx;
+    x265_hip_ctx *c = prim_ctx();
     if (!c)
         return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
     if (width <= 0 || height <= 0)
@@ -1846,6 +1864,7 @@ int x265_hip_setup_primitives(x265_hip_primitives *table, int device)
         if (r)
             return r;
         g_prim_ctx = c;
+        g_prim_device = device;
     }
     fill<0>(table);
     table->luma_p2s = t_p2s;
