@@ -338,6 +338,9 @@ enum State
 };
 
 // (cost, vector) come back wave-uniform in rcost / rmx / rmy
+// SMALL: the diamond and hexagon searches only (the state of the other methods, and their code, drop out of the
+// instantiation: the hexagon search of the medium preset then keeps more of its scalar state in registers)
+template <bool SMALL>
 __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_job &j, int &rcost, int &rmx, int &rmy)
 {
     // integer-stage state, all wave-uniform
@@ -450,172 +453,13 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
         if (st == ST_DONE)
             break;
 
-        switch (st)
+        // the states of UMH, STAR and the raster scans: a switch of their own, absent from the SMALL instantiation
+        bool other = true;
+        if constexpr (!SMALL)
         {
-        case ST_PRE:
-        {
-            int k = 0;
-            bprecost = q_cost(wv, k++);
-            bx = fpx;
-            by = fpy;
-            bcost = bprecost;
-            if (sub)
-                bcost = q_cost(wv, k++); // full-pel start re-measured with its mv rate (:562-567)
-            if (nz)
+            other = false;
+            switch (st)
             {
-                const int cost = q_cost(wv, k++); // zero vector (:570-578)
-                if (cost < bcost)
-                {
-                    bcost = cost;
-                    bx = by = 0;
-                }
-            }
-            for (k = first_mvc; k < wv.nq; k++)
-            {
-                const int mx = q_x(wv, k), my = q_y(wv, k);
-                if (mx == bpx && my == bpy)
-                    continue;
-                const int cost = q_cost(wv, k);
-                if (cost < bprecost) // candidates compete with bprecost only (:592)
-                {
-                    bprecost = cost;
-                    bpx = mx;
-                    bpy = my;
-                }
-            }
-            wv.nq = 0;
-            st = ST_INT_BEGIN;
-            break;
-        }
-
-        case ST_INT_BEGIN:
-            if (method == X265_HIP_DIA)
-            {
-                cnt = merange;
-                push_pat(wv, bx, by, PAT_SQ + 1, 4, 1, 2, MV_COST); // (0,-1) (0,1) (-1,0) (1,0)
-                st = ST_DIA;
-            }
-            else if (method == X265_HIP_HEX)
-                st = ST_HEX_BEGIN;
-            else if (method == X265_HIP_UMH)
-            {
-                // refine predictors: DIA1_ITER(pmv), DIA1_ITER(0) (motion.cpp:707-712)
-                ucost1 = bcost;
-                push_f(wv, fpx, fpy - 1);
-                push_f(wv, fpx, fpy + 1);
-                push_f(wv, fpx - 1, fpy);
-                push_f(wv, fpx + 1, fpy);
-                if (fpx | fpy)
-                {
-                    push_f(wv, 0, -1);
-                    push_f(wv, 0, 1);
-                    push_f(wv, -1, 0);
-                    push_f(wv, 1, 0);
-                }
-                flush = FL_BEST;
-                st = ST_U0;
-            }
-            else if (method == X265_HIP_STAR)
-            {
-                point = dist = 0;
-                star_phase = 0;
-                early = 3;
-                st = ST_STAR_BEGIN;
-            }
-            else
-            {
-                ras_step = 1;
-                ras_quirk = false;
-                ras_next = ST_POST;
-                st = ST_RASTER;
-            }
-            break;
-
-        // ---- DIA: radius-1 diamond, packed (cost << 4) + code, centre wins ties (motion.cpp:605-626)
-        case ST_DIA:
-        {
-            // the reference packs (cost << 4) + code with codes 1, 3, 4, 12 in visiting order and takes the
-            // minimum against bcost << 4: the first minimum, if strictly better than the centre
-            wv.nq = 0;
-            if (!take_ring(0, 4, 1))
-            {
-                st = ST_POST;
-                break;
-            }
-            if (--cnt && IN_RANGE(bx, by))
-                push_pat(wv, bx, by, PAT_SQ + 1, 4, 1, 2, MV_COST);
-            else
-                st = ST_POST;
-            break;
-        }
-
-        // ---- HEX: radius-2 hexagon then square refine (motion.cpp:628-700)
-        case ST_HEX_BEGIN:
-            push_pat(wv, bx, by, PAT_HEX + 1, 6, 1, 2, MV_COST); // hex2[1..6]: directions 0..5
-            if (spec_sq)
-                push_square();
-            st = ST_HEX1;
-            break;
-
-        case ST_HEX1:
-        case ST_HEXN:
-        {
-            bool go_on = false, moved = false;
-            const int nstep = st == ST_HEX1 ? 6 : 3; // the speculated square sits behind the step's points
-            // the reference's packed minimum ((cost << 3) + code against bcost << 3): first minimum of the
-            // step if strictly better than the centre
-            const int key = q_argmin(wv, 0, nstep);
-            wv.nq = 0;
-            if ((key >> 4) < bcost)
-            {
-                moved = true;
-                bcost = key >> 4;
-                if (st == ST_HEX1)
-                {
-                    dir = key & 15;
-                    cnt = (merange >> 1) - 1;
-                }
-                else
-                {
-                    dir += (key & 15) - 1;
-                    dir = dir < 0 ? dir + 6 : (dir >= 6 ? dir - 6 : dir); // mod6m1
-                    cnt--;
-                }
-                const int p = pat_at(wv, PAT_HEX + dir + 1);
-                bx = s16(bx + pat_dx(p));
-                by = s16(by + pat_dy(p));
-                go_on = cnt > 0 && IN_RANGE(bx, by);
-            }
-            if (go_on)
-            {
-                // half hexagon, not overlapping the previous one
-                push_pat(wv, bx, by, PAT_HEX + dir, 3, 1, 2, MV_COST);
-                if (spec_sq)
-                    push_square();
-                st = ST_HEXN;
-            }
-            else
-            {
-                if (spec_sq && !moved)
-                {
-                    take_square(nstep); // the centre stayed: the square was evaluated with this step
-                    st = ST_POST;
-                }
-                else
-                {
-                    push_square();
-                    st = ST_SQ;
-                }
-            }
-            break;
-        }
-
-        case ST_SQ:
-            take_square(0);
-            wv.nq = 0;
-            st = ST_POST;
-            break;
-
         // ---- UMH (motion.cpp:702-885)
 #define THRESH(v) (bcost < (((v) >> 4) * ((wv.h * wv.h) >> 4))) /* SAD_THRESH, size_scale (motion.cpp:60-66) */
         case ST_U0:
@@ -995,6 +839,178 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
             break;
         }
 
+            default:
+                other = true;
+                break;
+            }
+        }
+        if (other)
+        switch (st)
+        {
+        case ST_PRE:
+        {
+            int k = 0;
+            bprecost = q_cost(wv, k++);
+            bx = fpx;
+            by = fpy;
+            bcost = bprecost;
+            if (sub)
+                bcost = q_cost(wv, k++); // full-pel start re-measured with its mv rate (:562-567)
+            if (nz)
+            {
+                const int cost = q_cost(wv, k++); // zero vector (:570-578)
+                if (cost < bcost)
+                {
+                    bcost = cost;
+                    bx = by = 0;
+                }
+            }
+            for (k = first_mvc; k < wv.nq; k++)
+            {
+                const int mx = q_x(wv, k), my = q_y(wv, k);
+                if (mx == bpx && my == bpy)
+                    continue;
+                const int cost = q_cost(wv, k);
+                if (cost < bprecost) // candidates compete with bprecost only (:592)
+                {
+                    bprecost = cost;
+                    bpx = mx;
+                    bpy = my;
+                }
+            }
+            wv.nq = 0;
+            st = ST_INT_BEGIN;
+            break;
+        }
+
+        case ST_INT_BEGIN:
+            if (method == X265_HIP_DIA)
+            {
+                cnt = merange;
+                push_pat(wv, bx, by, PAT_SQ + 1, 4, 1, 2, MV_COST); // (0,-1) (0,1) (-1,0) (1,0)
+                st = ST_DIA;
+            }
+            else if (SMALL || method == X265_HIP_HEX)
+                st = ST_HEX_BEGIN;
+            else if (method == X265_HIP_UMH)
+            {
+                // refine predictors: DIA1_ITER(pmv), DIA1_ITER(0) (motion.cpp:707-712)
+                ucost1 = bcost;
+                push_f(wv, fpx, fpy - 1);
+                push_f(wv, fpx, fpy + 1);
+                push_f(wv, fpx - 1, fpy);
+                push_f(wv, fpx + 1, fpy);
+                if (fpx | fpy)
+                {
+                    push_f(wv, 0, -1);
+                    push_f(wv, 0, 1);
+                    push_f(wv, -1, 0);
+                    push_f(wv, 1, 0);
+                }
+                flush = FL_BEST;
+                st = ST_U0;
+            }
+            else if (method == X265_HIP_STAR)
+            {
+                point = dist = 0;
+                star_phase = 0;
+                early = 3;
+                st = ST_STAR_BEGIN;
+            }
+            else
+            {
+                ras_step = 1;
+                ras_quirk = false;
+                ras_next = ST_POST;
+                st = ST_RASTER;
+            }
+            break;
+
+        // ---- DIA: radius-1 diamond, packed (cost << 4) + code, centre wins ties (motion.cpp:605-626)
+        case ST_DIA:
+        {
+            // the reference packs (cost << 4) + code with codes 1, 3, 4, 12 in visiting order and takes the
+            // minimum against bcost << 4: the first minimum, if strictly better than the centre
+            wv.nq = 0;
+            if (!take_ring(0, 4, 1))
+            {
+                st = ST_POST;
+                break;
+            }
+            if (--cnt && IN_RANGE(bx, by))
+                push_pat(wv, bx, by, PAT_SQ + 1, 4, 1, 2, MV_COST);
+            else
+                st = ST_POST;
+            break;
+        }
+
+        // ---- HEX: radius-2 hexagon then square refine (motion.cpp:628-700)
+        case ST_HEX_BEGIN:
+            push_pat(wv, bx, by, PAT_HEX + 1, 6, 1, 2, MV_COST); // hex2[1..6]: directions 0..5
+            if (spec_sq)
+                push_square();
+            st = ST_HEX1;
+            break;
+
+        case ST_HEX1:
+        case ST_HEXN:
+        {
+            bool go_on = false, moved = false;
+            const int nstep = st == ST_HEX1 ? 6 : 3; // the speculated square sits behind the step's points
+            // the reference's packed minimum ((cost << 3) + code against bcost << 3): first minimum of the
+            // step if strictly better than the centre
+            const int key = q_argmin(wv, 0, nstep);
+            wv.nq = 0;
+            if ((key >> 4) < bcost)
+            {
+                moved = true;
+                bcost = key >> 4;
+                if (st == ST_HEX1)
+                {
+                    dir = key & 15;
+                    cnt = (merange >> 1) - 1;
+                }
+                else
+                {
+                    dir += (key & 15) - 1;
+                    dir = dir < 0 ? dir + 6 : (dir >= 6 ? dir - 6 : dir); // mod6m1
+                    cnt--;
+                }
+                const int p = pat_at(wv, PAT_HEX + dir + 1);
+                bx = s16(bx + pat_dx(p));
+                by = s16(by + pat_dy(p));
+                go_on = cnt > 0 && IN_RANGE(bx, by);
+            }
+            if (go_on)
+            {
+                // half hexagon, not overlapping the previous one
+                push_pat(wv, bx, by, PAT_HEX + dir, 3, 1, 2, MV_COST);
+                if (spec_sq)
+                    push_square();
+                st = ST_HEXN;
+            }
+            else
+            {
+                if (spec_sq && !moved)
+                {
+                    take_square(nstep); // the centre stayed: the square was evaluated with this step
+                    st = ST_POST;
+                }
+                else
+                {
+                    push_square();
+                    st = ST_SQ;
+                }
+            }
+            break;
+        }
+
+        case ST_SQ:
+            take_square(0);
+            wv.nq = 0;
+            st = ST_POST;
+            break;
+
         // ---- after the integer stage (motion.cpp:1039-1119)
         case ST_POST:
             if (bprecost < bcost) // pre-test winner bypasses the integer result
@@ -1125,7 +1141,10 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
 __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_result *out)
 {
     int bcost, bx, by;
-    motion_estimate_uv(wv, j, bcost, bx, by);
+    if ((j.method & ~X265_HIP_LOWRES_REF) <= X265_HIP_HEX)
+        motion_estimate_uv<true>(wv, j, bcost, bx, by);
+    else
+        motion_estimate_uv<false>(wv, j, bcost, bx, by);
     if (wv.lane == 0)
     {
         out->cost = bcost;
@@ -1395,7 +1414,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lo
         wv.mvpy = mvpy;
         wave_sync();
         int cost, mx, my;
-        motion_estimate_uv(wv, jl, cost, mx, my);
+        if (lj.method <= X265_HIP_HEX)
+            motion_estimate_uv<true>(wv, jl, cost, mx, my);
+        else
+            motion_estimate_uv<false>(wv, jl, cost, mx, my);
         right = (int)((uint32_t)(mx & 0xffff) | ((uint32_t)my << 16));
         if (lane == 0)
             __hip_atomic_store(&mine[cux], (look_word)(uint32_t)cost | ((look_word)(uint32_t)right << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
