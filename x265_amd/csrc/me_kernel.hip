@@ -174,8 +174,11 @@ __device__ __forceinline__ void lowres_tile(const uint8_t *p0, const uint8_t *p1
 
 // cost[c] = mv rate (per its mode) + SAD or SATD of the PU against the reference at candidate c's
 // quarter-pel position (subpelCompare + cmp, motion.cpp:1126-1164)
+// LOW: 1 the reference is a Lowres, 0 it is not, -1 as wv.lowres says
+template <int LOW = -1>
 __device__ __forceinline__ void q_eval(Wave &wv, int metric)
 {
+    const bool is_low = LOW < 0 ? wv.lowres : LOW != 0;
     WaveLds *s = wv.s;
     const int lane = wv.lane, nq = wv.nq;
     int seed = 0, px = 0, py = 0, pa = 0;
@@ -217,7 +220,7 @@ __device__ __forceinline__ void q_eval(Wave &wv, int metric)
         else
         {
             uint32_t pix[4][2];
-            if (wv.lowres)
+            if (is_low)
                 lowres_tile(wv.ref, wv.lref1, wv.lref2, wv.lref3, wv.stride, qx, qy, 4 * ty * wv.stride + 4 * tx, pix);
             else
             {
@@ -340,7 +343,8 @@ enum State
 // (cost, vector) come back wave-uniform in rcost / rmx / rmy
 // SMALL: the diamond and hexagon searches only (the state of the other methods, and their code, drop out of the
 // instantiation: the hexagon search of the medium preset then keeps more of its scalar state in registers)
-template <bool SMALL>
+// LOWRES: the reference is a Lowres (the lookahead's searches): the other sub-pel stage drops out, and vice versa
+template <bool SMALL, bool LOWRES>
 __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_job &j, int &rcost, int &rmx, int &rmy)
 {
     // integer-stage state, all wave-uniform
@@ -427,7 +431,7 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
     for (;;)
     {
         if (wv.nq)
-            q_eval(wv, metric);
+            q_eval<LOWRES ? 1 : 0>(wv, metric);
         if (flush != FL_NONE)
         {
             if (wv.nq)
@@ -1030,7 +1034,7 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
                 st = ST_DONE;
                 break;
             }
-            if (wv.lowres)
+            if (LOWRES)
             {
                 // motion.cpp:1055-1080: one half-pel ring with SAD, then the SATD re-measure of the winner
                 // together with its quarter-pel ring; the iteration counts of workload[] are not used
@@ -1052,6 +1056,11 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
 
         case ST_HPEL:
         {
+            if (LOWRES) // not a state of this instantiation
+            {
+                st = ST_DONE;
+                break;
+            }
             int k = 0;
             if (hsatd && sub_it == 0)
                 bcost = q_cost(wv, k++);
@@ -1085,6 +1094,11 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
         }
 
         case ST_LOWRES_HPEL:
+            if (!LOWRES) // not a state of this instantiation
+            {
+                st = ST_DONE;
+                break;
+            }
             take_ring(0, hpel_dirs, 2);
             wv.nq = 0;
             metric = X265_HIP_SATD;
@@ -1094,6 +1108,11 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
             break;
 
         case ST_LOWRES_QPEL:
+            if (!LOWRES) // not a state of this instantiation
+            {
+                st = ST_DONE;
+                break;
+            }
             bcost = q_cost(wv, 0);
             take_ring(1, qpel_dirs, 1);
             wv.nq = 0;
@@ -1101,12 +1120,22 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
             break;
 
         case ST_REM:
+            if (LOWRES) // not a state of this instantiation
+            {
+                st = ST_DONE;
+                break;
+            }
             bcost = q_cost(wv, 0);
             wv.nq = 0;
             st = ST_QPEL_BEGIN;
             break;
 
         case ST_QPEL_BEGIN:
+            if (LOWRES) // not a state of this instantiation
+            {
+                st = ST_DONE;
+                break;
+            }
             sub_it = 0;
             metric = X265_HIP_SATD;
             if (qpel_iters > 0)
@@ -1119,6 +1148,11 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
             break;
 
         case ST_QPEL:
+            if (LOWRES) // not a state of this instantiation
+            {
+                st = ST_DONE;
+                break;
+            }
             take_ring(0, qpel_dirs, 1);
             wv.nq = 0;
             if (++sub_it < qpel_iters)
@@ -1141,10 +1175,18 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
 __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_result *out)
 {
     int bcost, bx, by;
-    if ((j.method & ~X265_HIP_LOWRES_REF) <= X265_HIP_HEX)
-        motion_estimate_uv<true>(wv, j, bcost, bx, by);
+    const bool small = (j.method & ~X265_HIP_LOWRES_REF) <= X265_HIP_HEX;
+    if (wv.lowres)
+    {
+        if (small)
+            motion_estimate_uv<true, true>(wv, j, bcost, bx, by);
+        else
+            motion_estimate_uv<false, true>(wv, j, bcost, bx, by);
+    }
+    else if (small)
+        motion_estimate_uv<true, false>(wv, j, bcost, bx, by);
     else
-        motion_estimate_uv<false>(wv, j, bcost, bx, by);
+        motion_estimate_uv<false, false>(wv, j, bcost, bx, by);
     if (wv.lane == 0)
     {
         out->cost = bcost;
@@ -1415,9 +1457,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lo
         wave_sync();
         int cost, mx, my;
         if (lj.method <= X265_HIP_HEX)
-            motion_estimate_uv<true>(wv, jl, cost, mx, my);
+            motion_estimate_uv<true, true>(wv, jl, cost, mx, my);
         else
-            motion_estimate_uv<false>(wv, jl, cost, mx, my);
+            motion_estimate_uv<false, true>(wv, jl, cost, mx, my);
         right = (int)((uint32_t)(mx & 0xffff) | ((uint32_t)my << 16));
         if (lane == 0)
             __hip_atomic_store(&mine[cux], (look_word)(uint32_t)cost | ((look_word)(uint32_t)right << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
