@@ -1198,7 +1198,7 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
 #ifndef ME_XCD_CHUNK
 #define ME_XCD_CHUNK 1024 // about what one XCD holds at a time (768 waves): measured 16 .. 1024, larger is better
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
                                                 x265_hip_me_result *out, int out_stride)
 {
     __shared__ WaveLds lds;
