@@ -46,6 +46,8 @@ def mean(v):
 # 1. kernel stats of the bench run (rocprofv3 --kernel-trace --stats) and of the 4K driver
 shutil.copy(find("stats/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats.csv"))
 shutil.copy(find("stats4k/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats_prof4k.csv"))
+shutil.copy(find("stats_4k/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats_4k_only.csv"))
+shutil.copy(os.path.join(SRC, "bench_4k_under_rocprof.json"), os.path.join(DST, f"{tag}_bench_4k_under_rocprof.json"))
 shutil.copy(os.path.join(SRC, "bench_under_rocprof.json"), os.path.join(DST, f"{tag}_bench_under_rocprof.json"))
 shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{tag}_bench.json"))
 # per-launch durations of the 4K driver by kernel; refine_kernel per PU size (dispatch order: 64, 32, 16, 8)
