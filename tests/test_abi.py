@@ -83,7 +83,9 @@ def test_synth_search_range_matches_reference_rule():
 def test_hot_kernels_use_no_scratch(tmp_path):
     """the ME and full-search kernels must keep their state in registers: a struct that slips into scratch memory
     costs several KB of HBM writes per motionEstimate call (seen once: 120 bytes per lane, caught by WRITE_SIZE).
-    me_kernel is built for six waves per SIMD (80 VGPRs) and may spill a handful of dwords, nothing more; the cost
+    me_kernel is built for seven waves per SIMD (72 VGPRs) and may spill a handful of dwords, nothing more (a loop that
+    cleared 2048 counters at its start once cost it 13 spilled registers and 5 % of every small call); me_big_kernel,
+    at four waves per SIMD, spills nothing; the cost
     kernels spill nothing (cost_kernel at six waves spilled 14 dwords, 100 MB of scratch writes per 1080p launch,
     and was 8 % slower than at five waves without spills); refine_kernel at five waves keeps its 32 registers of filtered
     rows and four rows in flight and spills nine dwords once per strip."""
@@ -93,7 +95,7 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     src = os.path.join(ROOT, "x265_amd", "csrc")
-    allowed = {"me_kernel": 48, "refine_kernel": 48}
+    allowed = {"me_kernel": 32, "refine_kernel": 48}
     seen = set()
     for name in ("me_kernel.hip", "fullsearch.hip", "refine.hip"):
         out = tmp_path / (name + ".s")
@@ -101,11 +103,11 @@ def test_hot_kernels_use_no_scratch(tmp_path):
                                os.path.join(src, name)], stderr=subprocess.DEVNULL)
         text = out.read_text()
         for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s*(\d+)", text):
-            kernel = next((k for k in ("me_kernel", "cost_kernel", "dist_kernel", "predict_kernel", "fullsearch2_kernel", "refine_kernel") if k in m.group(1)), None)
+            kernel = next((k for k in ("me_kernel", "me_big_kernel", "cost_kernel", "dist_kernel", "predict_kernel", "fullsearch2_kernel", "refine_kernel") if k in m.group(1)), None)
             if kernel:
                 seen.add(kernel)
                 assert int(m.group(2)) <= allowed.get(kernel, 0), (kernel, m.group(2))
-    assert seen == {"me_kernel", "cost_kernel", "dist_kernel", "predict_kernel", "fullsearch2_kernel", "refine_kernel"}
+    assert seen == {"me_kernel", "me_big_kernel", "cost_kernel", "dist_kernel", "predict_kernel", "fullsearch2_kernel", "refine_kernel"}
 
 
 def test_python_struct_layouts_match_the_header(tmp_path):

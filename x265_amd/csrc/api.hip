@@ -70,12 +70,15 @@ struct x265_hip_ctx
 {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;            // me_big_kernel runs here, beside me_kernel on `stream`
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::mutex mu;
     DeviceTables host_tabs;
     DeviceTables *dev_tabs = nullptr;
     bool tabs_dirty = true;
     uint32_t *batch_counter = nullptr; // batch counters of the cost kernels (two sets, see launch_cost)
     int batch_parity = 0;
+    int route_parity = 0; // counter set of the next motionEstimate launch (me_kernel.hip)
     bool check_records = false; // record-check mode of the device-array entry points
     void *owned_plane[X265_HIP_MAX_PLANES] = {};
     size_t plane_bytes[X265_HIP_MAX_PLANES] = {};
@@ -83,6 +86,7 @@ struct x265_hip_ctx
     uint16_t *owned_tab[X265_HIP_MAX_QP] = {};
     Buf in, out;       // staging of the host-array batch calls
     Buf mejobs;        // motionEstimate jobs made on the device by x265_hip_inter_search_batch (device side only is used)
+    Buf route;         // motionEstimate launches: the list of large-block jobs me_route_kernel makes for me_big_kernel (device side only)
     Buf look;          // x265_hip_lookahead_batch: row counters (64 bytes per search) behind one status word
     Buf prim_a, prim_b; // staging of the primitive thunks
 };
@@ -132,6 +136,37 @@ int ensure(x265_hip_ctx *c, Buf &b, size_t bytes)
     HIP_TRY(hipHostMalloc(&b.h, cap, hipHostMallocDefault));
     b.cap = cap;
     (void)c;
+    return 0;
+}
+
+MeRoute me_route(x265_hip_ctx *c, bool any_big = true)
+{
+    if (!any_big)
+        return MeRoute{ nullptr, 0, c->stream, nullptr, nullptr, nullptr };
+    return MeRoute{ (uint32_t *)c->route.d, c->route_parity++, c->stream, c->side, c->ev_fork, c->ev_join };
+}
+
+template <typename Job>
+bool any_big_job(const Job *jobs, int n)
+{
+    for (int i = 0; i < n; i++)
+        if (me_block_is_big(jobs[i].pu_w, jobs[i].pu_h, jobs[i].method))
+            return true;
+    return false;
+}
+
+// room for the routing list of an n-job motionEstimate launch
+int ensure_route(x265_hip_ctx *c, int n)
+{
+    const size_t bytes = me_route_words(n) * sizeof(uint32_t);
+    if (c->route.cap >= bytes)
+        return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream)); // an earlier launch may still read the buffer that is about to be replaced
+    int r = ensure(c, c->route, bytes);
+    if (r)
+        return r;
+    HIP_TRY(hipMemsetAsync(c->route.d, 0, me_route_counter_words() * sizeof(uint32_t), c->stream)); // both counter sets
+    c->route_parity = 0;
     return 0;
 }
 
@@ -196,6 +231,12 @@ int x265_hip_ctx_create(int device, x265_hip_ctx **out)
     c->device = device;
     memset(&c->host_tabs, 0, sizeof(c->host_tabs));
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess && !(getenv("X265_HIP_ME_ONE_STREAM") && atoi(getenv("X265_HIP_ME_ONE_STREAM"))))
+        e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipMalloc((void **)&c->dev_tabs, sizeof(DeviceTables));
     if (e == hipSuccess)
@@ -224,13 +265,15 @@ void x265_hip_ctx_destroy(x265_hip_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
+    if (c->side)
+        (void)hipStreamSynchronize(c->side);
     for (int i = 0; i < X265_HIP_MAX_PLANES; i++)
         if (c->owned_plane[i])
             (void)hipFree(c->owned_plane[i]);
     for (int i = 0; i < X265_HIP_MAX_QP; i++)
         if (c->owned_tab[i])
             (void)hipFree(c->owned_tab[i]);
-    Buf *bufs[6] = { &c->in, &c->out, &c->prim_a, &c->prim_b, &c->mejobs, &c->look };
+    Buf *bufs[7] = { &c->in, &c->out, &c->prim_a, &c->prim_b, &c->mejobs, &c->look, &c->route };
     for (Buf *b : bufs)
     {
         if (b->d)
@@ -242,6 +285,12 @@ void x265_hip_ctx_destroy(x265_hip_ctx *c)
         (void)hipFree(c->dev_tabs);
     if (c->batch_counter)
         (void)hipFree(c->batch_counter);
+    if (c->ev_fork)
+        (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join)
+        (void)hipEventDestroy(c->ev_join);
+    if (c->side)
+        (void)hipStreamDestroy(c->side);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
@@ -887,9 +936,9 @@ int x265_hip_me_batch_device(x265_hip_ctx *c, const void *d_jobs, int n, void *d
             return vr;
     }
     int r = push_tabs(c);
-    if (r)
+    if (r || (r = ensure_route(c, n)))
         return r;
-    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)d_jobs, n, (x265_hip_me_result *)d_results, c->stream));
+    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)d_jobs, n, (x265_hip_me_result *)d_results, me_route(c)));
     return X265_HIP_OK;
 }
 
@@ -903,12 +952,12 @@ int x265_hip_me_batch(x265_hip_ctx *c, const x265_hip_me_job *jobs, int n, x265_
     HIP_TRY(hipSetDevice(c->device));
     int r = check_jobs(c, jobs, n);
     if (r || (r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*jobs))) ||
-        (r = ensure(c, c->out, (size_t)n * sizeof(*results))))
+        (r = ensure(c, c->out, (size_t)n * sizeof(*results))) || (r = ensure_route(c, n)))
         return r;
     // straight from the caller's memory: the runtime pipelines its own staging, which beats a copy into the
     // pinned mirror followed by one DMA
     HIP_TRY(hipMemcpyAsync(c->in.d, jobs, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
-    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, c->stream));
+    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, me_route(c, any_big_job(jobs, n))));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(*results), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(results, c->out.h, (size_t)n * sizeof(*results));
@@ -933,10 +982,10 @@ int x265_hip_inter_search_batch_device(x265_hip_ctx *c, const void *d_jobs, int 
     int r;
     if (c->mejobs.cap < (size_t)n * sizeof(x265_hip_me_job))
         HIP_TRY(hipStreamSynchronize(c->stream)); // an earlier launch may still read the buffer that is about to be replaced
-    if ((r = push_tabs(c)) || (r = ensure(c, c->mejobs, (size_t)n * sizeof(x265_hip_me_job))))
+    if ((r = push_tabs(c)) || (r = ensure(c, c->mejobs, (size_t)n * sizeof(x265_hip_me_job))) || (r = ensure_route(c, n)))
         return r;
     LAUNCH(launch_inter_search(c->dev_tabs, (const x265_hip_inter_job *)d_jobs, n, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d,
-                               (x265_hip_inter_result *)d_results, c->stream));
+                               (x265_hip_inter_result *)d_results, me_route(c)));
     return X265_HIP_OK;
 }
 
@@ -956,11 +1005,11 @@ int x265_hip_inter_search_batch(x265_hip_ctx *c, const x265_hip_inter_job *jobs,
     int r;
     const size_t ob = (size_t)n * sizeof(*results);
     if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*jobs))) || (r = ensure(c, c->out, ob)) ||
-        (r = ensure(c, c->mejobs, (size_t)n * sizeof(x265_hip_me_job))))
+        (r = ensure(c, c->mejobs, (size_t)n * sizeof(x265_hip_me_job))) || (r = ensure_route(c, n)))
         return r;
     HIP_TRY(hipMemcpyAsync(c->in.d, jobs, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
     LAUNCH(launch_inter_search(c->dev_tabs, (const x265_hip_inter_job *)c->in.d, n, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d,
-                               (x265_hip_inter_result *)c->out.d, c->stream));
+                               (x265_hip_inter_result *)c->out.d, me_route(c, any_big_job(jobs, n))));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(results, c->out.h, ob);

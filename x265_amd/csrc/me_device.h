@@ -71,6 +71,15 @@ __device__ __forceinline__ void ld12g(gptr_t p, uint32_t &d0, uint32_t &d1, uint
     d0 = w.x, d1 = w.y, d2 = w.z;
 }
 
+// 16 bytes from any byte address, one unaligned global_load_dwordx4
+__device__ __forceinline__ uint4 ld16g(gptr_t p)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w;
+    __builtin_memcpy(&w, (const void *)p, 16);
+    return make_uint4(w.x, w.y, w.z, w.w);
+}
+
 __device__ __forceinline__ int byte_of(uint32_t v, int i)
 {
     return (int)((v >> (8 * i)) & 0xffu);

@@ -39,7 +39,7 @@ __device__ __forceinline__ int s16(int v) { return (int)(int16_t)v; }
 #define SPEC_SQ_TILES 4    // speculate the square refine for PUs of at most this many 4x4 tiles
 #define SPEC_QPEL_TILES 16 // same for the quarter-pel ring
 
-struct WaveLds
+struct __attribute__((aligned(16))) WaveLds
 {
     uint8_t fenc[64 * 64]; // PU source pixels at stride 64 (setSourcePU, motion.cpp:110-126)
     int qx[QMAX];          // candidate position, quarter-pel
@@ -47,6 +47,7 @@ struct WaveLds
     int cost[QMAX];
     int aux[QMAX];         // (tag << 2) | mv-rate mode
     int pat[PAT_N];        // search patterns, (dy << 16) | (dx & 0xffff): hex2[0..7], square1[0..8], star rings, hex4
+    int sel[2][QMAX];      // q_eval_big: the queue split into full-pel SAD candidates and the others
 };
 
 // how the evaluation seeds a candidate's cost with its motion-vector rate
@@ -172,10 +173,50 @@ __device__ __forceinline__ void lowres_tile(const uint8_t *p0, const uint8_t *p1
     }
 }
 
+// Full-pel SAD of the candidates 0 .. nq-1 (all full-pel) of a block whose width is a multiple of 16, added into
+// cost[]: a work item is a strip of 16 x 4 pixels (per row one 16-byte load from the plane, one from LDS, four
+// v_sad_u8: a quarter of the instructions per pixel of the 4x4 tile form)
+__device__ __forceinline__ void wide_sad(Wave &wv, int nq)
+{
+    WaveLds *s = wv.s;
+    const int ns = wv.nt >> 2, total = nq * ns, wx = wv.w >> 4;
+    // exact: i < 1024, ns <= 64
+    const float inv_ns = __builtin_amdgcn_rcpf((float)ns), inv_wx = __builtin_amdgcn_rcpf((float)wx);
+    for (int i = wv.lane; i < total; i += 64)
+    {
+        const int c = (int)(((float)i + 0.5f) * inv_ns), t = i - c * ns;
+        const int sy = (int)(((float)t + 0.5f) * inv_wx), sx = t - sy * wx;
+        gptr_t r = as_global(wv.ref) + ((s->qy[c] >> 2) + 4 * sy) * wv.stride + (s->qx[c] >> 2) + 16 * sx;
+        const uint8_t *f = s->fenc + sy * 4 * 64 + sx * 16;
+        uint32_t a = 0;
+        // two rows in flight at a time: the kernel has 72 registers per lane
+#pragma unroll
+        for (int y = 0; y < 4; y += 2)
+        {
+            const uint4 r0 = ld16g(r), r1 = ld16g(r + wv.stride);
+            r += 2 * wv.stride;
+            const uint4 f0 = *(const uint4 *)(f + y * 64);
+            a = __builtin_amdgcn_sad_u8(f0.x, r0.x, a);
+            a = __builtin_amdgcn_sad_u8(f0.y, r0.y, a);
+            a = __builtin_amdgcn_sad_u8(f0.z, r0.z, a);
+            a = __builtin_amdgcn_sad_u8(f0.w, r0.w, a);
+            const uint4 f1 = *(const uint4 *)(f + y * 64 + 64);
+            a = __builtin_amdgcn_sad_u8(f1.x, r1.x, a);
+            a = __builtin_amdgcn_sad_u8(f1.y, r1.y, a);
+            a = __builtin_amdgcn_sad_u8(f1.z, r1.z, a);
+            a = __builtin_amdgcn_sad_u8(f1.w, r1.w, a);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        atomicAdd(&s->cost[c], (int)a);
+    }
+}
+
 // cost[c] = mv rate (per its mode) + SAD or SATD of the PU against the reference at candidate c's
 // quarter-pel position (subpelCompare + cmp, motion.cpp:1126-1164)
 // LOW: 1 the reference is a Lowres, 0 it is not, -1 as wv.lowres says
-template <int LOW = -1>
+// WIDE (the caller vouches for a full-resolution reference, at least 64 tiles and a width that is a multiple of 16:
+// 32x32, 64x16, 16x64): groups of full-pel SAD candidates go through wide_sad
+template <int LOW = -1, bool WIDE = false>
 __device__ __forceinline__ void q_eval(Wave &wv, int metric)
 {
     const bool is_low = LOW < 0 ? wv.lowres : LOW != 0;
@@ -197,6 +238,12 @@ __device__ __forceinline__ void q_eval(Wave &wv, int metric)
     if (lane < QMAX)
         s->cost[lane] = 0;
     wave_sync();
+    // a group of full-pel SAD candidates (every round of the integer stage) of a block of at least 64 tiles whose width
+    // is a multiple of 16 (32x32, 64x16, 16x64; 16x16 was 4 % slower this way): strips of 16 x 4 pixels instead of tiles
+    if (WIDE && metric == X265_HIP_SAD && __ballot(lane < nq && ((px | py) & 3)) == 0)
+        wide_sad(wv, nq);
+    else
+    {
     const int total = nq * wv.nt;
     // i / nt and t / ntx by reciprocal: exact for i < 4096, nt <= 256 (error 4e-4 << 0.5 / nt)
     const float inv_nt = __builtin_amdgcn_rcpf((float)wv.nt), inv_ntx = __builtin_amdgcn_rcpf((float)wv.ntx);
@@ -231,6 +278,128 @@ __device__ __forceinline__ void q_eval(Wave &wv, int metric)
             v = tile_metric(f, 64, pix, metric);
         }
         atomicAdd(&s->cost[c], v);
+    }
+    }
+    wave_sync();
+    wv.vc = lane < nq ? s->cost[lane & (QMAX - 1)] + seed : 0x7fffffff;
+    wv.vx = px;
+    wv.vy = py;
+    wv.va = pa;
+}
+
+// The same for blocks of at least 64 tiles whose width is a multiple of 16 (32x32 and up, 64x16, 16x64): the 4x4 tile
+// is the wrong unit for them.  A full-pel SAD candidate is dealt out as strips of 16 x 4 pixels (per row one 16-byte
+// load from the plane, one from LDS, four v_sad_u8: a quarter of the instructions per pixel); every other candidate
+// as strips of NT stacked tiles, NT = 4 for 64x64 (ref_strip<4>: 23 filtered rows for four tiles instead of 4 x 11),
+// 2 for 128 or 192 tiles, 1 for 64 tiles, so that a candidate still fills a pass of the wave.  Either way a candidate
+// is a multiple of 16 items and a DPP row of lanes belongs to one candidate: the partial sums meet inside the row
+// first and one lane of it adds them to the candidate's cost.
+#ifndef ME_WIDE
+#define ME_WIDE 1
+#endif
+#ifndef ME_BIG_TILES
+#define ME_BIG_TILES 128
+#endif
+__device__ __forceinline__ bool big_block(int w, int h) { return (w & 15) == 0 && (w >> 2) * (h >> 2) >= ME_BIG_TILES; }
+
+__device__ __forceinline__ int row_sum16(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);  // quad_perm 1,0,3,2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);  // quad_perm 2,3,0,1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false); // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); // row_mirror
+    return v;
+}
+
+// candidates sel[0 .. count) as strips of NT tiles
+template <int NT>
+__device__ __forceinline__ void big_strips(Wave &wv, const int *sel, int count, int metric)
+{
+    WaveLds *s = wv.s;
+    const int ns = wv.nt / NT, total = count * ns;
+    const float inv_ns = __builtin_amdgcn_rcpf((float)ns), inv_ntx = __builtin_amdgcn_rcpf((float)wv.ntx);
+    for (int i = wv.lane; i < total; i += 64)
+    {
+        const int k = (int)(((float)i + 0.5f) * inv_ns), t = i - k * ns, c = sel[k];
+        const int ty = (int)(((float)t + 0.5f) * inv_ntx), tx = t - ty * wv.ntx;
+        const int qx = s->qx[c], qy = s->qy[c];
+        const uint8_t *r = wv.ref + ((qy >> 2) + 4 * NT * ty) * wv.stride + (qx >> 2) + 4 * tx;
+        const uint8_t *f = s->fenc + ty * 4 * NT * 64 + tx * 4;
+        const bool any_diag = __ballot((qx & 3) && (qy & 3)) != 0;
+        uint32_t pix[4 * NT][2];
+        ref_strip<NT>(r, wv.stride, qx & 3, qy & 3, pix, any_diag);
+        int v = 0;
+#pragma unroll
+        for (int u = 0; u < NT; u++)
+            v += tile_metric(f + u * 4 * 64, 64, &pix[4 * u], metric);
+        v = row_sum16(v);
+        if ((wv.lane & 15) == 0)
+            atomicAdd(&s->cost[c], v);
+    }
+}
+
+__device__ __forceinline__ void q_eval_big(Wave &wv, int metric)
+{
+    WaveLds *s = wv.s;
+    const int lane = wv.lane, nq = wv.nq;
+    int seed = 0, px = 0, py = 0, pa = 0;
+    bool wide = false;
+    if (lane < nq)
+    {
+        px = s->qx[lane];
+        py = s->qy[lane];
+        pa = s->aux[lane];
+        const int mode = pa & 3;
+        if (mode != MV_NONE)
+        {
+            const int a = tab_at(wv.tab, wv.mvpx, px), b = tab_at(wv.tab, wv.mvpy, py);
+            seed = mode == MV_COST ? (int)(uint16_t)(a + b) : a + b;
+        }
+        wide = metric == X265_HIP_SAD && ((px | py) & 3) == 0;
+    }
+    // the two kinds of candidate, each list in queue order
+    const uint32_t mw = (uint32_t)__ballot(wide), mt = (uint32_t)__ballot(lane < nq && !wide);
+    if (lane < nq)
+        s->sel[wide ? 0 : 1][__builtin_amdgcn_mbcnt_lo(wide ? mw : mt, 0u)] = lane;
+    if (lane < QMAX)
+        s->cost[lane] = 0;
+    wave_sync();
+    const int nwide = __popc(mw), ntall = __popc(mt);
+    if (nwide)
+    {
+        const int ns = wv.nt >> 2, total = nwide * ns, wx = wv.w >> 4;
+        // exact as in q_eval: i < 1024, ns <= 64
+        const float inv_ns = __builtin_amdgcn_rcpf((float)ns), inv_wx = __builtin_amdgcn_rcpf((float)wx);
+        for (int i = lane; i < total; i += 64)
+        {
+            const int k = (int)(((float)i + 0.5f) * inv_ns), t = i - k * ns, c = s->sel[0][k];
+            const int sy = (int)(((float)t + 0.5f) * inv_wx), sx = t - sy * wx;
+            gptr_t r = as_global(wv.ref) + ((s->qy[c] >> 2) + 4 * sy) * wv.stride + (s->qx[c] >> 2) + 16 * sx;
+            const uint8_t *f = s->fenc + sy * 4 * 64 + sx * 16;
+            uint32_t a = 0;
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+            {
+                const uint4 fv = *(const uint4 *)(f + y * 64), rv = ld16g(r);
+                r += wv.stride;
+                a = __builtin_amdgcn_sad_u8(fv.x, rv.x, a);
+                a = __builtin_amdgcn_sad_u8(fv.y, rv.y, a);
+                a = __builtin_amdgcn_sad_u8(fv.z, rv.z, a);
+                a = __builtin_amdgcn_sad_u8(fv.w, rv.w, a);
+            }
+            const int v = row_sum16((int)a);
+            if ((lane & 15) == 0)
+                atomicAdd(&s->cost[c], v);
+        }
+    }
+    if (ntall)
+    {
+        if (wv.nt == 256)
+            big_strips<4>(wv, s->sel[1], ntall, metric);
+        else if (wv.nt >= 128)
+            big_strips<2>(wv, s->sel[1], ntall, metric);
+        else
+            big_strips<1>(wv, s->sel[1], ntall, metric);
     }
     wave_sync();
     wv.vc = lane < nq ? s->cost[lane & (QMAX - 1)] + seed : 0x7fffffff;
@@ -344,7 +513,9 @@ enum State
 // SMALL: the diamond and hexagon searches only (the state of the other methods, and their code, drop out of the
 // instantiation: the hexagon search of the medium preset then keeps more of its scalar state in registers)
 // LOWRES: the reference is a Lowres (the lookahead's searches): the other sub-pel stage drops out, and vice versa
-template <bool SMALL, bool LOWRES>
+// BIG: big_block() sizes, evaluated by q_eval_big (never against a Lowres: the lookahead's blocks are 8x8)
+// WIDE: the block has at least 64 tiles and a width that is a multiple of 16 (q_eval's wide_sad path)
+template <bool SMALL, bool LOWRES, bool BIG = false, bool WIDE = false>
 __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_job &j, int &rcost, int &rmx, int &rmy)
 {
     // integer-stage state, all wave-uniform
@@ -431,7 +602,12 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
     for (;;)
     {
         if (wv.nq)
-            q_eval<LOWRES ? 1 : 0>(wv, metric);
+        {
+            if constexpr (BIG)
+                q_eval_big(wv, metric);
+            else
+                q_eval<LOWRES ? 1 : 0, WIDE>(wv, metric);
+        }
         if (flush != FL_NONE)
         {
             if (wv.nq)
@@ -1172,11 +1348,19 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
     rmy = by;
 }
 
+template <bool BIG>
 __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job &j, x265_hip_me_result *out)
 {
     int bcost, bx, by;
     const bool small = (j.method & ~X265_HIP_LOWRES_REF) <= X265_HIP_HEX;
-    if (wv.lowres)
+    if constexpr (BIG)
+    {
+        if (small)
+            motion_estimate_uv<true, false, true>(wv, j, bcost, bx, by);
+        else
+            motion_estimate_uv<false, false, true>(wv, j, bcost, bx, by);
+    }
+    else if (wv.lowres)
     {
         if (small)
             motion_estimate_uv<true, true>(wv, j, bcost, bx, by);
@@ -1184,7 +1368,12 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
             motion_estimate_uv<false, true>(wv, j, bcost, bx, by);
     }
     else if (small)
-        motion_estimate_uv<true, false>(wv, j, bcost, bx, by);
+    {
+        if (ME_WIDE && (wv.w & 15) == 0 && wv.nt >= 64)
+            motion_estimate_uv<true, false, false, true>(wv, j, bcost, bx, by);
+        else
+            motion_estimate_uv<true, false>(wv, j, bcost, bx, by);
+    }
     else
         motion_estimate_uv<false, false>(wv, j, bcost, bx, by);
     if (wv.lane == 0)
@@ -1198,14 +1387,33 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
 #ifndef ME_XCD_CHUNK
 #define ME_XCD_CHUNK 1024 // about what one XCD holds at a time (768 waves): measured 16 .. 1024, larger is better
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
-                                                x265_hip_me_result *out, int out_stride)
+#ifndef ME_BIG_WAVES
+#define ME_BIG_WAVES 4
+#endif
+// One motionEstimate call per wave.  me_kernel, one workgroup per job, takes the jobs q_eval suits; a job of big_block()
+// size against a full-resolution reference it only notes in a list (`route`), and me_big_kernel (more registers per
+// lane, fewer waves per SIMD), launched behind it, has its waves take jobs from that list until it is empty.
+// The list of big jobs.  One counter for the whole grid would serialise (an atomic on one address takes ~12 ns), so
+// the list is kept in ME_PARTS parts: job i belongs to part i mod ME_PARTS (at most `cap` = ceil(n / ME_PARTS) entries)
+// and part p is served by the waves p, p + ME_PARTS, ... of me_big_kernel.  Per part one append counter (me_kernel) and
+// one hand-out counter (me_big_kernel), 64 bytes apart.  Two sets of counters alternate between launches (`parity`):
+// a launch's me_big_kernel clears the set of the next one, so nothing is memset per call.
+#define ME_PARTS 64
+#define ME_ROUTE_SET (2 * ME_PARTS * 16)  // words per counter set: append counters, then hand-out counters
+#define ME_ROUTE_HEAD (2 * ME_ROUTE_SET) // the lists start behind the two sets
+
+__device__ __forceinline__ bool job_is_big(const x265_hip_me_job &j)
 {
-    __shared__ WaveLds lds;
-    if ((int)blockIdx.x >= n)
-        return;
-    const int id = xcd_chunked(blockIdx.x, n, ME_XCD_CHUNK);
-    const x265_hip_me_job &j = jobs[id];
+    return big_block(j.pu_w, j.pu_h) && !(j.method & X265_HIP_LOWRES_REF);
+}
+
+// BIG: me_big_kernel's side.  Otherwise `skip_big` makes the wave leave a big job to that kernel; it does so after
+// the set-up, where the choice between the instantiations of the search is made anyway: a test in front of it puts
+// one more round of memory latency at the start of every small call (the loads of the set-up wait behind the
+// branch), 4 % of an 8x8 call.
+template <bool BIG>
+__device__ __forceinline__ void me_job(WaveLds &lds, const DeviceTables *tabs, const x265_hip_me_job &j, x265_hip_me_result *out, bool skip_big = false)
+{
     Wave wv;
     wave_init(wv, &lds, j.pu_w, j.pu_h);
     const PlaneDesc fp = tabs->planes[j.fenc_plane], rp = tabs->planes[j.ref_plane];
@@ -1214,7 +1422,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void me
     wv.tab = tabs->costtab[j.qp];
     wv.mvpx = j.qmvp_x;
     wv.mvpy = j.qmvp_y;
-    if (j.method & X265_HIP_LOWRES_REF)
+    if (!BIG && (j.method & X265_HIP_LOWRES_REF))
     {
         wv.lowres = true;
         const long off = (long)j.pu_y * rp.stride + j.pu_x;
@@ -1223,8 +1431,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void me
         wv.lref3 = tabs->planes[j.ref_plane + 3].origin + off;
     }
     load_fenc(wv, fp.origin + (long)j.pu_y * fp.stride + j.pu_x, fp.stride);
-    // results are out_stride bytes apart: 8 for x265_hip_me_result arrays, more when they head a larger record
-    motion_estimate(wv, j, (x265_hip_me_result *)((char *)out + (size_t)id * out_stride));
+    if (!BIG && skip_big && job_is_big(j))
+        return;
+    motion_estimate<BIG>(wv, j, out);
+}
+
+// results are out_stride bytes apart: 8 for x265_hip_me_result arrays, more when they head a larger record
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
+                                                x265_hip_me_result *out, int out_stride, int skip_big)
+{
+    __shared__ WaveLds lds;
+    if ((int)blockIdx.x >= n)
+        return;
+    const int id = xcd_chunked(blockIdx.x, n, ME_XCD_CHUNK);
+    me_job<false>(lds, tabs, jobs[id], (x265_hip_me_result *)((char *)out + (size_t)id * out_stride), skip_big != 0);
+}
+
+// the list of big jobs for me_big_kernel: a wave's big jobs go to their parts in one atomic per part and wave at most
+// (consecutive jobs go to consecutive parts)
+__global__ __launch_bounds__(256) void me_route_kernel(const x265_hip_me_job *jobs, int n, uint32_t *route, int parity, int cap)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && job_is_big(jobs[i]))
+    {
+        const int p = i & (ME_PARTS - 1);
+        route[ME_ROUTE_HEAD + p * cap + atomicAdd(&route[parity * ME_ROUTE_SET + p * 16], 1u)] = (uint32_t)i;
+    }
+}
+
+// gridDim.x is a multiple of ME_PARTS.  A wave starts with the list entry of its own rank within the part and takes
+// further ones from the part's counter; it leaves when that has passed the end of the part's list (it only grows).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_BIG_WAVES))) void me_big_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs,
+                                                uint32_t *route, int parity, int cap, x265_hip_me_result *out, int out_stride)
+{
+    __shared__ WaveLds lds;
+    const int p = blockIdx.x & (ME_PARTS - 1), waves = gridDim.x / ME_PARTS;
+    // the next launch's counters (in me_kernel this loop cost a dozen spilled registers)
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < ME_ROUTE_SET; i += 64)
+            route[(parity ^ 1) * ME_ROUTE_SET + i] = 0u;
+    uint32_t *const counters = route + parity * ME_ROUTE_SET;
+    const uint32_t count = counters[p * 16];
+    uint32_t k = blockIdx.x / ME_PARTS;
+    while (k < count)
+    {
+        const uint32_t id = route[ME_ROUTE_HEAD + p * cap + k];
+        me_job<true>(lds, tabs, jobs[id], (x265_hip_me_result *)((char *)out + (size_t)id * out_stride));
+        wave_sync();
+        k = 0;
+        if ((threadIdx.x & 63) == 0)
+            k = (uint32_t)waves + atomicAdd(&counters[ME_PARTS * 16 + p * 16], 1u);
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    }
 }
 
 // The steps of predInterSearch in front of motionEstimate (reference Lib/TLibEncoder/TEncSearch.cpp:2315-2339), one wave
@@ -1984,21 +2242,55 @@ static int cost_blocks(int n, int)
     return (n + 3) / 4;
 }
 
-void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, hipStream_t st)
+static int me_route_cap(int n) { return (n + ME_PARTS - 1) / ME_PARTS; }
+size_t me_route_words(int n) { return (size_t)ME_ROUTE_HEAD + (size_t)ME_PARTS * me_route_cap(n > 0 ? n : 0); }
+size_t me_route_counter_words() { return ME_ROUTE_HEAD; }
+bool me_block_is_big(int w, int h, int method) { return (w & 15) == 0 && (w >> 2) * (h >> 2) >= ME_BIG_TILES && !(method & X265_HIP_LOWRES_REF); }
+
+static void me_launch_both(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, int out_stride, const MeRoute &r)
 {
-    if (n > 0)
-        hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, st, tabs, jobs, n, out, (int)sizeof(x265_hip_me_result));
+    if (n <= 0)
+        return;
+    if (!r.route) // the caller knows that the list holds no big job
+    {
+        hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, r.stream, tabs, jobs, n, out, out_stride, 0);
+        return;
+    }
+    const int cap = me_route_cap(n), parity = r.parity & 1;
+    // The list and the big jobs on the side stream, the other jobs on the main one, side by side: me_kernel does not
+    // wait for the list (it only skips the big jobs), and the small jobs fill what the big ones leave idle (their last
+    // round, or most of the chip when there are few of them).
+    hipStream_t sb = r.side ? r.side : r.stream;
+    if (r.side)
+    {
+        (void)hipEventRecord(r.fork, r.stream);
+        (void)hipStreamWaitEvent(r.side, r.fork, 0);
+    }
+    hipLaunchKernelGGL(me_route_kernel, dim3((n + 255) / 256), dim3(256), 0, sb, jobs, n, r.route, parity, cap);
+    hipLaunchKernelGGL(me_big_kernel, dim3(256 * 4 * ME_BIG_WAVES), dim3(64), 0, sb, tabs, jobs, r.route, parity, cap, out, out_stride);
+    hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, r.stream, tabs, jobs, n, out, out_stride, 1);
+    if (r.side)
+    {
+        (void)hipEventRecord(r.join, r.side);
+        (void)hipStreamWaitEvent(r.stream, r.join, 0);
+    }
+}
+
+void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, const MeRoute &r)
+{
+    me_launch_both(tabs, jobs, n, out, (int)sizeof(x265_hip_me_result), r);
 }
 
 void launch_inter_search(const DeviceTables *tabs, const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h, x265_hip_me_job *mejobs,
-                         x265_hip_inter_result *out, hipStream_t st)
+                         x265_hip_inter_result *out, const MeRoute &r)
 {
+    hipStream_t st = r.stream;
     if (n <= 0)
         return;
     hipLaunchKernelGGL(inter_prepare_kernel, dim3(n), dim3(64), 0, st, tabs, jobs, n, pic_w, pic_h, mejobs, out);
     // (cost, mv) head the result record
     static_assert(offsetof(x265_hip_inter_result, cost) == 0 && offsetof(x265_hip_inter_result, mvx) == 4, "x265_hip_me_result heads the record");
-    hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, st, tabs, mejobs, n, (x265_hip_me_result *)out, (int)sizeof(x265_hip_inter_result));
+    me_launch_both(tabs, mejobs, n, (x265_hip_me_result *)out, (int)sizeof(x265_hip_inter_result), r);
 }
 
 void launch_lookahead(const DeviceTables *tabs, const x265_hip_lookahead_job *jobs, int njobs, int w_cu, int h_cu, uint32_t *tickets,
