@@ -319,7 +319,12 @@ typedef struct x265_hip_me_result
 
 /* host arrays in, host arrays out (H2D + kernel + D2H, synchronous) */
 int x265_hip_me_batch(x265_hip_ctx *ctx, const x265_hip_me_job *jobs, int n, x265_hip_me_result *results);
-/* same kernel on device-resident job / result arrays, asynchronous on the context stream */
+/* the same on device-resident job / result arrays, asynchronous on the context stream.  Jobs on blocks of 128 4x4
+ * tiles and more (64x64, 64x32, 32x64, 64x48, 48x64) against a full-resolution reference are listed on the device and
+ * searched by a kernel of their own beside the other jobs' kernel, on a second stream of the context that is forked
+ * from and joined to the context stream inside the call (X265_HIP_ME_ONE_STREAM=1 in the environment at context
+ * creation keeps both on the one stream); results are the same either way.  The list lives in a buffer of the
+ * context that grows (one synchronisation + allocation) when a call has more jobs than any before it. */
 int x265_hip_me_batch_device(x265_hip_ctx *ctx, const void *d_jobs, int n, void *d_results);
 int x265_hip_cost_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs);
 

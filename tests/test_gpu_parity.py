@@ -840,3 +840,47 @@ def test_record_check_mode_refuses_bad_device_records(gpu_ctx, small_seq):
             gpu_ctx.refine_batch_device(d_rr.ptr, 2, d_c9.ptr)
     finally:
         gpu_ctx.check_records(False)
+
+
+@pytest.mark.parametrize("one_stream", [False, True])
+def test_large_block_jobs_and_their_routing(oracle, small_seq, costtabs, one_stream, monkeypatch):
+    """blocks of 128 tiles and more are listed on the device and searched by me_big_kernel beside me_kernel (on a second
+    stream, or on the one stream with X265_HIP_ME_ONE_STREAM=1): lists of big blocks only (every such size, every
+    method but FULL, every sub-pel level), of none, and mixed ones, with growing and shrinking job counts back to back
+    on one context (the two counter sets of the list alternate; the list buffer grows), through the device-array and
+    the host-array entry point"""
+    from x265_amd import abi, lib, synth
+    from x265_amd.hipmem import DeviceBuffer
+    if one_stream:
+        monkeypatch.setenv("X265_HIP_ME_ONE_STREAM", "1")
+    ctx = lib.Context(0)
+    for i, p in enumerate(small_seq):
+        ctx.plane_upload(i, p.buf, p.stride, p.origin)
+    for q, t in costtabs.items():
+        ctx.costtab_upload(q, t)
+    rng = np.random.default_rng(128 + one_stream)
+    W, H = small_seq[0].w, small_seq[0].h
+    planes = _planes(small_seq)
+    big_parts = [i for i in range(1, 25) if abi.PARTS[i][0] % 16 == 0 and abi.PARTS[i][0] * abi.PARTS[i][1] >= 128 * 16]
+    assert sorted(abi.PARTS[i] for i in big_parts) == [(32, 64), (48, 64), (64, 32), (64, 48), (64, 64)]
+    small_parts = [i for i in range(1, 25) if i not in big_parts]
+
+    def jobs_of(n, which, method, subme):
+        # random_me_jobs draws partition indices 1..24: hand it a table that maps every index into the wanted set
+        table = [abi.PARTS[0]] + [abi.PARTS[which[int(rng.integers(len(which)))]] for _ in range(24)]
+        return random_me_jobs(rng, n, method, subme, W, H, abi.ME_JOB, synth.search_range, table)
+
+    both = big_parts + small_parts
+    lists = [jobs_of(40, big_parts, m, s) for m in (0, 1, 2, 3) for s in (0, 2, 3, 5, 7)]
+    lists += [jobs_of(n, which, int(rng.integers(0, 4)), int(rng.integers(0, 8)))
+              for n, which in ((700, both), (3, big_parts), (5000, both), (900, small_parts), (130, big_parts), (1, big_parts), (64, both), (2000, both))]
+    for k, jobs in enumerate(lists):
+        want = oracle.me_batch(planes, costtabs, jobs)
+        d = DeviceBuffer.from_array(jobs)
+        o = DeviceBuffer(len(jobs) * abi.ME_RESULT.itemsize)
+        ctx.me_batch_device(d.ptr, len(jobs), o.ptr)
+        ctx.sync()
+        got = o.download(abi.ME_RESULT, len(jobs))
+        assert np.array_equal(got, want), (k, "device", np.nonzero(got != want)[0][:5])
+        assert np.array_equal(ctx.me_batch(jobs), want), (k, "host")
+    ctx.close()
