@@ -357,12 +357,12 @@ def main():
         if me_model:
             ms = me_model["kernel_ms"]  # that picture's list timed on its own
             line["me_stage"]["roofline"] = {
-                "bound": "valu", "kernel": "me_kernel", "kernel_ms": ms, "algorithmic_lane_ops": me_model["lane_ops"],
+                "bound": "valu", "kernel": "me_kernel + me_big_kernel", "kernel_ms": ms, "algorithmic_lane_ops": me_model["lane_ops"],
                 "achieved": me_model["lane_ops"] / (ms * 1e-3) / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-op/s",
                 "frac": me_model["lane_ops"] / (ms * 1e-3) / VALU_PEAK,
                 "issue_ceiling": {"peak": VALU_ISSUE_4CYC / 1e12, "frac": me_model["lane_ops"] / (ms * 1e-3) / VALU_ISSUE_4CYC},
                 "model": {k: me_model[k] for k in ("sad_ops", "satd_ops", "interp_ops", "sad_candidates", "subpel_candidates", "calls")},
-                "traffic": traffic.get("me_kernel_4k")}
+                "traffic": (sum(traffic.get(k + "_4k", 0) for k in ("me_kernel", "me_big_kernel", "me_route_kernel")) or None)}
         if hd:
             line["hd"] = hd
         if cpu:

@@ -97,7 +97,25 @@ print("wrote", sorted(p for p in os.listdir(DST) if p.startswith(tag)))
 # bench.py printed in that run.
 bt = list(csv.DictReader(open(find("stats/**/*kernel_trace.csv"))))
 bt.sort(key=lambda r: int(r["Dispatch_Id"]))
-seqk = [(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6) for r in bt if ours(r["Kernel_Name"])]
+# a motionEstimate launch is three kernels (me_route_kernel and me_big_kernel on the side stream beside me_kernel): one leg,
+# timed by the union of their intervals
+ME_FAMILY = {"me_route_kernel": "me_kernel", "me_big_kernel": "me_kernel"}
+seqk = [(ME_FAMILY.get(short(r["Kernel_Name"]), short(r["Kernel_Name"])), int(r["Start_Timestamp"]) * 1e-6, int(r["End_Timestamp"]) * 1e-6)
+        for r in bt if ours(r["Kernel_Name"])]
+
+
+def busy_ms(intervals):
+    total, cur_s, cur_e = 0.0, None, None
+    for s_, e_ in sorted(intervals):
+        if cur_e is None or s_ > cur_e:
+            if cur_e is not None:
+                total += cur_e - cur_s
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    return total + (cur_e - cur_s if cur_e is not None else 0.0)
+
+
 line = json.loads(open(os.path.join(SRC, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
 K = line["steps"]
 order = ["refine_kernel", "cost_kernel", "me_kernel", "fullsearch2_kernel"]
@@ -107,11 +125,10 @@ for i, k in enumerate(order):
     start = pos
     while pos < len(seqk) and seqk[pos][0] == k:
         pos += 1
-    block = [d for _, d in seqk[start:pos]]
-    per = 1
+    block = [(s_, e_) for _, s_, e_ in seqk[start:pos]]
+    per = 3 if k == "me_kernel" else 1
     timed = block[-K * per:]
-    legs[k] = {"launches_in_leg": len(block), "timed_launches": len(timed), "trace_ms_per_step": sum(timed) / K,
-               "trace_mean_launch_us": 1e3 * sum(timed) / len(timed)}
+    legs[k] = {"kernels_in_leg": len(block), "timed_kernels": len(timed), "kernels_per_step": per, "trace_ms_per_step": busy_ms(timed) / K}
     assert seqk[pos][0] == nxt, (k, seqk[pos][0])
 legs["refine_kernel"]["bench_kernel_ms"] = line["roofline"]["kernel_ms"]
 legs["cost_kernel"]["bench_kernel_ms"] = line["satd_single_requests"]["roofline"]["kernel_ms"]

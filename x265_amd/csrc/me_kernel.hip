@@ -2257,17 +2257,23 @@ static void me_launch_both(const DeviceTables *tabs, const x265_hip_me_job *jobs
         return;
     }
     const int cap = me_route_cap(n), parity = r.parity & 1;
-    // The list and the big jobs on the side stream, the other jobs on the main one, side by side: me_kernel does not
-    // wait for the list (it only skips the big jobs), and the small jobs fill what the big ones leave idle (their last
-    // round, or most of the chip when there are few of them).
+    // The list first (made beside me_kernel on the side stream it had to find room among that kernel's half a million
+    // workgroups and sometimes ended with it: nothing ran side by side), then the big jobs on the side stream and the
+    // other jobs on the main one: the small jobs fill what the big ones leave idle (their last round, or most of the
+    // chip when there are few of them).
+    hipLaunchKernelGGL(me_route_kernel, dim3((n + 255) / 256), dim3(256), 0, r.stream, jobs, n, r.route, parity, cap);
     hipStream_t sb = r.side ? r.side : r.stream;
     if (r.side)
     {
         (void)hipEventRecord(r.fork, r.stream);
         (void)hipStreamWaitEvent(r.side, r.fork, 0);
     }
-    hipLaunchKernelGGL(me_route_kernel, dim3((n + 255) / 256), dim3(256), 0, sb, jobs, n, r.route, parity, cap);
-    hipLaunchKernelGGL(me_big_kernel, dim3(256 * 4 * ME_BIG_WAVES), dim3(64), 0, sb, tabs, jobs, r.route, parity, cap, out, out_stride);
+    static const int big_grid = [] {
+        const char *e = getenv("X265_HIP_ME_BIG_GRID"); // experiments; a multiple of ME_PARTS
+        const int g = e ? atoi(e) : 0;
+        return g >= ME_PARTS ? g / ME_PARTS * ME_PARTS : 256 * 4 * ME_BIG_WAVES;
+    }();
+    hipLaunchKernelGGL(me_big_kernel, dim3(big_grid), dim3(64), 0, sb, tabs, jobs, r.route, parity, cap, out, out_stride);
     hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, r.stream, tabs, jobs, n, out, out_stride, 1);
     if (r.side)
     {
