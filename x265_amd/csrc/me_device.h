@@ -385,6 +385,80 @@ __device__ __forceinline__ void ref_tile(const uint8_t *ref, int stride, int xf,
     ref_strip<1>(ref, stride, xf, yf, P, diag);
 }
 
+// 4x4 bytes held as one dword per row -> one dword per column
+__device__ __forceinline__ void transpose4x4_u8(uint32_t d[4])
+{
+    const uint32_t t0 = __builtin_amdgcn_perm(d[1], d[0], 0x05010400), t1 = __builtin_amdgcn_perm(d[1], d[0], 0x07030602);
+    const uint32_t t2 = __builtin_amdgcn_perm(d[3], d[2], 0x05010400), t3 = __builtin_amdgcn_perm(d[3], d[2], 0x07030602);
+    d[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100);
+    d[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302);
+    d[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100);
+    d[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302);
+}
+
+// One 4x4 tile at a position with exactly one fractional component, luma_hpp and luma_vpp through ONE filter
+// routine: lanes of a wave that hold horizontal and vertical half-/quarter-pel candidates (every sub-pel diamond has
+// both) then run it once instead of one path after the other.  A vertical position is filtered as a horizontal one
+// on the transposed rows and comes back transposed (P[x] = column x of the prediction); SAD and the 4x4 Hadamard
+// SATD are invariant under transposing both operands, so the caller transposes its source tile for those lanes
+// (xf == 0) and compares as usual.
+__device__ __forceinline__ void ref_tile_1d(const uint8_t *ref, int stride, int xf, int yf, uint32_t P[4][2])
+{
+    const uint32_t bias = 0x80808080u;
+    const bool vert = xf == 0;
+    const int fr = vert ? yf : xf;
+    const uint32_t tlo = k_taps_s8[fr][0], thi = k_taps_s8[fr][1];
+    const gptr_t r_ = as_global(ref);
+    uint32_t c[4][3];
+    if (vert)
+    {
+        gptr_t p = r_ - 3 * stride;
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+        {
+            uint32_t d[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                d[i] = 0u;
+                if (4 * b + i < 11)
+                {
+                    d[i] = ld4g(p) ^ bias;
+                    p += stride;
+                }
+            }
+            transpose4x4_u8(d);
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                c[x][b] = d[x];
+        }
+    }
+    else
+    {
+        gptr_t p = r_ - 3;
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            ld12g(p, c[y][0], c[y][1], c[y][2]);
+            p += stride;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                c[y][k] ^= bias;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++)
+    {
+        int o[4];
+        tap8x4<8192 + 32>(c[v][0], c[v][1], c[v][2], tlo, thi, o);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            o[k] = clip_pixel(o[k] >> 6);
+        P[v][0] = pack2(o[0], o[1]);
+        P[v][1] = pack2(o[2], o[3]);
+    }
+}
+
 // SAD or SATD of one 4x4 tile.  `f` walks the source block with `fstride`.
 // SATD: sum |H4 * D * H4| / 2 per tile; the per-tile sum is always even, so halving per tile is
 // exactly what the reference's 4x4 / 8x4 grouping yields (pixel.cpp:201-252).  All of it runs on packed

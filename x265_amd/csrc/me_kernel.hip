@@ -30,6 +30,9 @@ namespace x265hip {
 __device__ __forceinline__ int s16(int v) { return (int)(int16_t)v; }
 
 #define QMAX 16
+#ifndef ME_ONE_D
+#define ME_ONE_D 1 // hpp and vpp tiles of q_eval through one routine (ref_tile_1d); 2: only in the diamond / hexagon instantiations
+#endif
 #define PAT_HEX 0
 #define PAT_SQ 8
 #define PAT_STAR8 17  // small star ring in visiting order, units of dist / 2
@@ -216,7 +219,7 @@ __device__ __forceinline__ void wide_sad(Wave &wv, int nq)
 // LOW: 1 the reference is a Lowres, 0 it is not, -1 as wv.lowres says
 // WIDE (the caller vouches for a full-resolution reference, at least 64 tiles and a width that is a multiple of 16:
 // 32x32, 64x16, 16x64): groups of full-pel SAD candidates go through wide_sad
-template <int LOW = -1, bool WIDE = false>
+template <int LOW = -1, bool WIDE = false, bool ONE_D = false>
 __device__ __forceinline__ void q_eval(Wave &wv, int metric)
 {
     const bool is_low = LOW < 0 ? wv.lowres : LOW != 0;
@@ -266,16 +269,28 @@ __device__ __forceinline__ void q_eval(Wave &wv, int metric)
         }
         else
         {
-            uint32_t pix[4][2];
+            uint32_t pix[4][2], frow[4];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+                frow[y] = *(const uint32_t *)(f + y * 64);
             if (is_low)
                 lowres_tile(wv.ref, wv.lref1, wv.lref2, wv.lref3, wv.stride, qx, qy, 4 * ty * wv.stride + 4 * tx, pix);
             else
             {
-                // lanes of this pass that need the diagonal filter pull the half-fractional ones along
-                const bool any_diag = __ballot((qx & 3) && (qy & 3)) != 0;
-                ref_tile(r, wv.stride, qx & 3, qy & 3, pix, any_diag);
+                // lanes of this pass that need the diagonal filter pull the half-fractional ones along; without any,
+                // the horizontal and the vertical ones share one routine (ref_tile_1d)
+                const int xf = qx & 3, yf = qy & 3;
+                const bool any_diag = __ballot(xf && yf) != 0;
+                if (ONE_D && !any_diag && (xf | yf))
+                {
+                    ref_tile_1d(r, wv.stride, xf, yf, pix);
+                    if (xf == 0)
+                        transpose4x4_u8(frow);
+                }
+                else
+                    ref_tile(r, wv.stride, xf, yf, pix, any_diag);
             }
-            v = tile_metric(f, 64, pix, metric);
+            v = tile_metric_rows(frow, pix, metric);
         }
         atomicAdd(&s->cost[c], v);
     }
@@ -606,7 +621,7 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
             if constexpr (BIG)
                 q_eval_big(wv, metric);
             else
-                q_eval<LOWRES ? 1 : 0, WIDE>(wv, metric);
+                q_eval<LOWRES ? 1 : 0, WIDE, ME_ONE_D == 1 || (ME_ONE_D == 2 && SMALL)>(wv, metric);
         }
         if (flush != FL_NONE)
         {
@@ -1437,7 +1452,10 @@ __device__ __forceinline__ void me_job(WaveLds &lds, const DeviceTables *tabs, c
 }
 
 // results are out_stride bytes apart: 8 for x265_hip_me_result arrays, more when they head a larger record
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
+#ifndef ME_WAVES
+#define ME_WAVES 7
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_WAVES))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
                                                 x265_hip_me_result *out, int out_stride, int skip_big)
 {
     __shared__ WaveLds lds;
