@@ -41,6 +41,9 @@ __device__ __forceinline__ int s16(int v) { return (int)(int16_t)v; }
 #define PAT_N 57
 #define SPEC_SQ_TILES 4    // speculate the square refine for PUs of at most this many 4x4 tiles
 #define SPEC_QPEL_TILES 16 // same for the quarter-pel ring
+#ifndef ME_SPEC_LOW
+#define ME_SPEC_LOW 1 // Lowres references: SATD re-measure + quarter-pel ring together with the half-pel ring
+#endif
 
 struct __attribute__((aligned(16))) WaveLds
 {
@@ -57,6 +60,10 @@ struct __attribute__((aligned(16))) WaveLds
 enum { MV_NONE = 0,  // distortion only
        MV_COST = 1,  // BitCost::mvcost(): sum of the two entries truncated to uint16 (bitcost.h:45)
        MV_RAW = 2 }; // plain int sum of the two entries (UMH hexagon grid, motion.cpp:832)
+
+// aux bit 30: this candidate is measured with SATD whatever the group's metric (Lowres references: the SATD re-measure
+// and the quarter-pel ring evaluated together with the SAD half-pel ring)
+#define AUX_SATD (1 << 30)
 
 // how a group's results are applied before the state code runs
 enum { FL_NONE = 0,  // the state reads the costs itself
@@ -220,8 +227,9 @@ __device__ __forceinline__ void wide_sad(Wave &wv, int nq)
 // WIDE (the caller vouches for a full-resolution reference, at least 64 tiles and a width that is a multiple of 16:
 // 32x32, 64x16, 16x64): groups of full-pel SAD candidates go through wide_sad
 template <int LOW = -1, bool WIDE = false, bool ONE_D = false>
-__device__ __forceinline__ void q_eval(Wave &wv, int metric)
+__device__ __forceinline__ void q_eval(Wave &wv, int group_metric)
 {
+    static_assert(X265_HIP_SAD == 0 && X265_HIP_SATD == 1, "AUX_SATD turns SAD into SATD by or-ing a bit");
     const bool is_low = LOW < 0 ? wv.lowres : LOW != 0;
     WaveLds *s = wv.s;
     const int lane = wv.lane, nq = wv.nq;
@@ -243,7 +251,7 @@ __device__ __forceinline__ void q_eval(Wave &wv, int metric)
     wave_sync();
     // a group of full-pel SAD candidates (every round of the integer stage) of a block of at least 64 tiles whose width
     // is a multiple of 16 (32x32, 64x16, 16x64; 16x16 was 4 % slower this way): strips of 16 x 4 pixels instead of tiles
-    if (WIDE && metric == X265_HIP_SAD && __ballot(lane < nq && ((px | py) & 3)) == 0)
+    if (WIDE && group_metric == X265_HIP_SAD && __ballot(lane < nq && ((px | py) & 3)) == 0)
         wide_sad(wv, nq);
     else
     {
@@ -258,6 +266,7 @@ __device__ __forceinline__ void q_eval(Wave &wv, int metric)
         const uint8_t *r = wv.ref + ((qy >> 2) + 4 * ty) * wv.stride + (qx >> 2) + 4 * tx;
         const uint8_t *f = s->fenc + ty * 4 * 64 + tx * 4;
         int v;
+        const int metric = LOW == 1 ? (group_metric | ((s->aux[c] >> 30) & 1)) : group_metric;
         if (metric == X265_HIP_SAD && ((qx | qy) & 3) == 0)
         {
             // full-pel SAD, the bulk of the integer stage: four v_sad_u8 on the packed rows
@@ -592,6 +601,7 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
     // ring).  They are evaluated in the same pass when that costs no or little extra time, consumed in
     // the reference's order if the centre stayed, and dropped otherwise, so results are unchanged.
     const bool spec_sq = wv.nt <= SPEC_SQ_TILES;
+    const bool spec_low = LOWRES && ME_SPEC_LOW && (1 + hpel_dirs + qpel_dirs) * wv.nt <= 64 && 1 + hpel_dirs + qpel_dirs <= QMAX;
     const bool spec_qp = hsatd && hpel_iters == 1 && qpel_iters > 0 && wv.nt <= SPEC_QPEL_TILES &&
                          1 + hpel_dirs + qpel_dirs <= QMAX;
 
@@ -1231,6 +1241,12 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
                 // together with its quarter-pel ring; the iteration counts of workload[] are not used
                 metric = X265_HIP_SAD;
                 push_pat(wv, bx, by, PAT_SQ + 1, hpel_dirs, 2, 0, MV_COST);
+                if (spec_low)
+                {
+                    // what follows if the half-pel ring does not move the centre, in the same pass (idle lanes)
+                    q_push(wv, bx, by, MV_COST, AUX_SATD >> 2);
+                    push_pat(wv, bx, by, PAT_SQ + 1, qpel_dirs, 1, 0, MV_COST | AUX_SATD);
+                }
                 st = ST_LOWRES_HPEL;
                 break;
             }
@@ -1290,7 +1306,14 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
                 st = ST_DONE;
                 break;
             }
-            take_ring(0, hpel_dirs, 2);
+            if (!take_ring(0, hpel_dirs, 2) && spec_low)
+            {
+                bcost = q_cost(wv, hpel_dirs);
+                take_ring(hpel_dirs + 1, qpel_dirs, 1);
+                wv.nq = 0;
+                st = ST_DONE;
+                break;
+            }
             wv.nq = 0;
             metric = X265_HIP_SATD;
             q_push(wv, bx, by, MV_COST);
