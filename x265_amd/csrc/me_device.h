@@ -674,7 +674,8 @@ __host__ __device__ inline void search_window(int mvpx, int mvpy, int merange, i
 // there, which is undefined; in-range motion vectors never wrap)
 __device__ __forceinline__ int tab_at(const uint16_t *tab, int mvp, int v)
 {
-    return tab[(uint16_t)(v - mvp + 32768)];
+    // the table is device memory: a global load (a generic pointer makes it a flat load, which also queues on the LDS path)
+    return ((const __attribute__((address_space(1))) uint16_t *)tab)[(uint16_t)(v - mvp + 32768)];
 }
 
 // BitCost::mvcost: the sum of the two entries truncated to uint16 (bitcost.h:45)
