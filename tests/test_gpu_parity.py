@@ -884,3 +884,40 @@ def test_large_block_jobs_and_their_routing(oracle, small_seq, costtabs, one_str
         assert np.array_equal(got, want), (k, "device", np.nonzero(got != want)[0][:5])
         assert np.array_equal(ctx.me_batch(jobs), want), (k, "host")
     ctx.close()
+
+
+def test_empty_and_single_record_lists(gpu_ctx, oracle, small_seq, costtabs):
+    """every batched entry point with no record at all (host arrays and the device forms with n = 0: nothing is
+    launched, nothing is read) and with exactly one record (against the oracle): the ragged ends of the batch
+    hand-out, the routing list of the motionEstimate launch and the staging buffers"""
+    from conftest import random_bidir_reqs, random_cost_reqs
+    from x265_amd import abi, lib, synth
+    rng = np.random.default_rng(1)
+    W, H = small_seq[0].w, small_seq[0].h
+    planes = _planes(small_seq)
+    assert len(gpu_ctx.me_batch(np.zeros(0, abi.ME_JOB))) == 0
+    assert len(gpu_ctx.cost_batch(np.zeros(0, abi.COST_REQ))) == 0
+    assert len(gpu_ctx.dist_batch(np.zeros(0, abi.COST_REQ))) == 0
+    assert len(gpu_ctx.bidir_cost_batch(np.zeros(0, abi.BIDIR_REQ))) == 0
+    assert len(gpu_ctx.refine_batch(np.zeros(0, abi.REFINE_REQ))) == 0
+    assert len(gpu_ctx.inter_search_batch(np.zeros(0, abi.INTER_JOB), W, H)) == 0
+    assert len(gpu_ctx.fullsearch(np.zeros(0, lib.CTU_JOB))) == 0
+    gpu_ctx.predict_batch(np.zeros(0, abi.PRED_REQ))
+    for call in (gpu_ctx.me_batch_device, gpu_ctx.cost_batch_device, gpu_ctx.cost_batch_device_noalloc, gpu_ctx.dist_batch_device,
+                 gpu_ctx.bidir_cost_batch_device, gpu_ctx.refine_batch_device, gpu_ctx.fullsearch_device):
+        call(0, 0, 0)
+    gpu_ctx.predict_batch_device(0, 0)
+    gpu_ctx.inter_search_batch_device(0, 0, W, H, 0)
+    gpu_ctx.sync()
+    for size in ((8, 8), (64, 64)):  # one job for me_kernel, one for me_big_kernel
+        table = [abi.PARTS[0]] + [size] * 24
+        jobs = random_me_jobs(rng, 1, abi.HEX, 2, W, H, abi.ME_JOB, synth.search_range, table)
+        assert np.array_equal(gpu_ctx.me_batch(jobs), oracle.me_batch(planes, costtabs, jobs)), size
+    reqs = random_cost_reqs(rng, 1, W, H, abi.COST_REQ, abi.PARTS)
+    assert np.array_equal(gpu_ctx.cost_batch(reqs), oracle.cost_batch(planes, reqs))
+    reqs = random_cost_reqs(rng, 1, W, H, abi.COST_REQ, abi.PARTS, metrics=(2,))
+    assert np.array_equal(gpu_ctx.dist_batch(reqs), oracle.cost_batch(planes, reqs))
+    br = random_bidir_reqs(rng, 1, W, H, abi.BIDIR_REQ, abi.PARTS)
+    assert np.array_equal(gpu_ctx.bidir_cost_batch(br), oracle.bidir_cost_batch(planes, br))
+    rr = _random_refine_reqs(rng, 1, W, H, abi.PARTS)
+    _check_refine(gpu_ctx, oracle, small_seq, rr)
