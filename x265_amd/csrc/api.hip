@@ -139,9 +139,11 @@ int ensure(x265_hip_ctx *c, Buf &b, size_t bytes)
     return 0;
 }
 
-MeRoute me_route(x265_hip_ctx *c, bool any_big = true)
+// `launches`: whether kernels will run (a call without jobs must not take a counter set: the set is cleared for the
+// launch after next by the launch that uses it)
+MeRoute me_route(x265_hip_ctx *c, bool launches, bool any_big = true)
 {
-    if (!any_big)
+    if (!launches || !any_big)
         return MeRoute{ nullptr, 0, c->stream, nullptr, nullptr, nullptr };
     return MeRoute{ (uint32_t *)c->route.d, c->route_parity++, c->stream, c->side, c->ev_fork, c->ev_join };
 }
@@ -928,6 +930,8 @@ int x265_hip_me_batch_device(x265_hip_ctx *c, const void *d_jobs, int n, void *d
 {
     if (!c || n < 0 || (n && (!d_jobs || !d_results)))
         return fail(X265_HIP_EINVAL, "me_batch_device: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     {
@@ -938,7 +942,7 @@ int x265_hip_me_batch_device(x265_hip_ctx *c, const void *d_jobs, int n, void *d
     int r = push_tabs(c);
     if (r || (r = ensure_route(c, n)))
         return r;
-    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)d_jobs, n, (x265_hip_me_result *)d_results, me_route(c)));
+    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)d_jobs, n, (x265_hip_me_result *)d_results, me_route(c, n > 0)));
     return X265_HIP_OK;
 }
 
@@ -957,7 +961,7 @@ int x265_hip_me_batch(x265_hip_ctx *c, const x265_hip_me_job *jobs, int n, x265_
     // straight from the caller's memory: the runtime pipelines its own staging, which beats a copy into the
     // pinned mirror followed by one DMA
     HIP_TRY(hipMemcpyAsync(c->in.d, jobs, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
-    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, me_route(c, any_big_job(jobs, n))));
+    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, me_route(c, n > 0, any_big_job(jobs, n))));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(*results), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(results, c->out.h, (size_t)n * sizeof(*results));
@@ -985,7 +989,7 @@ int x265_hip_inter_search_batch_device(x265_hip_ctx *c, const void *d_jobs, int 
     if ((r = push_tabs(c)) || (r = ensure(c, c->mejobs, (size_t)n * sizeof(x265_hip_me_job))) || (r = ensure_route(c, n)))
         return r;
     LAUNCH(launch_inter_search(c->dev_tabs, (const x265_hip_inter_job *)d_jobs, n, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d,
-                               (x265_hip_inter_result *)d_results, me_route(c)));
+                               (x265_hip_inter_result *)d_results, me_route(c, n > 0)));
     return X265_HIP_OK;
 }
 
@@ -1009,7 +1013,7 @@ int x265_hip_inter_search_batch(x265_hip_ctx *c, const x265_hip_inter_job *jobs,
         return r;
     HIP_TRY(hipMemcpyAsync(c->in.d, jobs, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
     LAUNCH(launch_inter_search(c->dev_tabs, (const x265_hip_inter_job *)c->in.d, n, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d,
-                               (x265_hip_inter_result *)c->out.d, me_route(c, any_big_job(jobs, n))));
+                               (x265_hip_inter_result *)c->out.d, me_route(c, n > 0, any_big_job(jobs, n))));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(results, c->out.h, ob);

@@ -81,7 +81,6 @@ struct Wave
     int lane;
     int nq;
     int vc, vx, vy, va; // after an evaluation: lane k holds candidate k's cost / position / aux word
-    int patv;           // lane k holds pattern entry k (same words as WaveLds::pat), for scalar reads
     // reference is a Lowres (ReferencePlanes::isLowres): ref is lowresPlane[0], these are [1..3], all at the
     // PU origin and of one stride
     bool lowres;
@@ -120,9 +119,8 @@ __device__ __forceinline__ void wave_init(Wave &wv, WaveLds *s, int w, int h)
     wv.vc = wv.vx = wv.vy = wv.va = 0;
     wv.lowres = false;
     wv.lref1 = wv.lref2 = wv.lref3 = nullptr;
-    wv.patv = wv.lane < PAT_N ? k_pat[wv.lane] : 0;
     if (wv.lane < PAT_N)
-        s->pat[wv.lane] = wv.patv; // made visible by load_fenc's wave_sync
+        s->pat[wv.lane] = k_pat[wv.lane]; // made visible by load_fenc's wave_sync
 }
 
 __device__ __forceinline__ void load_fenc(Wave &wv, const uint8_t *src, int sstride)
@@ -232,7 +230,11 @@ __device__ __forceinline__ void q_eval(Wave &wv, int group_metric)
     static_assert(X265_HIP_SAD == 0 && X265_HIP_SATD == 1, "AUX_SATD turns SAD into SATD by or-ing a bit");
     const bool is_low = LOW < 0 ? wv.lowres : LOW != 0;
     WaveLds *s = wv.s;
-    const int lane = wv.lane, nq = wv.nq;
+    // opaque: otherwise the LDS address of this lane's queue slot is computed once per kernel, spilled to scratch for
+    // want of registers and reloaded at the start of every evaluation (a memory round trip for one v_add)
+    int lane = wv.lane;
+    asm volatile("" : "+v"(lane));
+    const int nq = wv.nq;
     int seed = 0, px = 0, py = 0, pa = 0;
     if (lane < nq)
     {
@@ -478,7 +480,16 @@ __device__ __forceinline__ void push_lanes(Wave &wv, int count, int qx, int qy, 
 }
 
 // pattern entry k as a wave-uniform value (k uniform)
-__device__ __forceinline__ int pat_at(const Wave &wv, int k) { return __builtin_amdgcn_readlane(wv.patv, k); }
+// Pattern entry k as a wave-uniform value (k uniform).  IN_REG: from `patv`, a register copy of the table with one lane
+// per entry (pat_vector()).  The searches against Lowres references use that: they are latency-bound chains and the
+// lookahead kernel has room for it.  In me_kernel the register was the allocator's first choice for a spill and every
+// hexagon step waited for a scratch reload, so the other searches read the LDS copy.
+__device__ __forceinline__ int pat_vector() { return (int)(threadIdx.x & 63) < PAT_N ? k_pat[threadIdx.x & 63] : 0; }
+template <bool IN_REG>
+__device__ __forceinline__ int pat_at(const Wave &wv, int patv, int k)
+{
+    return IN_REG ? __builtin_amdgcn_readlane(patv, k) : uniform(wv.s->pat[k]);
+}
 
 // First minimum among the evaluated candidates [off, off + count) (count >= 1, all inside lanes 0..15):
 // returns (cost << 4) | (k - off).  Sequential strict-less updates in push order pick exactly this one.
@@ -540,7 +551,7 @@ enum State
 // BIG: big_block() sizes, evaluated by q_eval_big (never against a Lowres: the lookahead's blocks are 8x8)
 // WIDE: the block has at least 64 tiles and a width that is a multiple of 16 (q_eval's wide_sad path)
 template <bool SMALL, bool LOWRES, bool BIG = false, bool WIDE = false>
-__device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_job &j, int &rcost, int &rmx, int &rmy)
+__device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_job &j, int &rcost, int &rmx, int &rmy, int patv = 0)
 {
     // integer-stage state, all wave-uniform
     const int lox = j.mvmin_x, loy = j.mvmin_y, hix = j.mvmax_x, hiy = j.mvmax_y; // full-pel, inclusive
@@ -551,9 +562,10 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
     const int method = j.method & ~X265_HIP_LOWRES_REF;
     const int nmvc = j.num_mvc;
     const int subme = j.subme;
-    const int hpel_iters = k_workload[subme][0], hpel_dirs = k_workload[subme][1];
-    const int qpel_iters = k_workload[subme][2], qpel_dirs = k_workload[subme][3];
-    const int hsatd = k_workload[subme][4];
+    // wave-uniform, and said so: left in vector registers they were among the values spilled to scratch
+    const int hpel_iters = uniform(k_workload[subme][0]), hpel_dirs = uniform(k_workload[subme][1]);
+    const int qpel_iters = uniform(k_workload[subme][2]), qpel_dirs = uniform(k_workload[subme][3]);
+    const int hsatd = uniform(k_workload[subme][4]);
 
 #define IN_RANGE(x, y) ((x) >= lox && (x) <= hix && (y) >= loy && (y) <= hiy)
 
@@ -613,7 +625,7 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
         if ((key >> 4) < bcost)
         {
             bcost = key >> 4;
-            const int p = pat_at(wv, PAT_SQ + 1 + (key & 15));
+            const int p = pat_at<LOWRES>(wv, patv, PAT_SQ + 1 + (key & 15));
             bx = s16(bx + pat_dx(p) * mul);
             by = s16(by + pat_dy(p) * mul);
             return true;
@@ -626,6 +638,7 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
 
     for (;;)
     {
+        metric = uniform(metric); // keeps it in a scalar register across the states (it was a spilled vector register)
         if (wv.nq)
         {
             if constexpr (BIG)
@@ -867,7 +880,7 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
                     wv.nq = 0;
                     if ((key >> 4) < bcost)
                     {
-                        const int p = pat_at(wv, PAT_HEX4 + (key & 15));
+                        const int p = pat_at<LOWRES>(wv, patv, PAT_HEX4 + (key & 15));
                         bcost = key >> 4;
                         bx = s16(ox + ring * pat_dx(p));
                         by = s16(oy + ring * pat_dy(p));
@@ -1181,7 +1194,7 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
                     dir = dir < 0 ? dir + 6 : (dir >= 6 ? dir - 6 : dir); // mod6m1
                     cnt--;
                 }
-                const int p = pat_at(wv, PAT_HEX + dir + 1);
+                const int p = pat_at<LOWRES>(wv, patv, PAT_HEX + dir + 1);
                 bx = s16(bx + pat_dx(p));
                 by = s16(by + pat_dy(p));
                 go_on = cnt > 0 && IN_RANGE(bx, by);
@@ -1401,9 +1414,9 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
     else if (wv.lowres)
     {
         if (small)
-            motion_estimate_uv<true, true>(wv, j, bcost, bx, by);
+            motion_estimate_uv<true, true>(wv, j, bcost, bx, by, pat_vector());
         else
-            motion_estimate_uv<false, true>(wv, j, bcost, bx, by);
+            motion_estimate_uv<false, true>(wv, j, bcost, bx, by, pat_vector());
     }
     else if (small)
     {
@@ -1496,7 +1509,9 @@ __global__ __launch_bounds__(256) void me_route_kernel(const x265_hip_me_job *jo
     if (i < n && job_is_big(jobs[i]))
     {
         const int p = i & (ME_PARTS - 1);
-        route[ME_ROUTE_HEAD + p * cap + atomicAdd(&route[parity * ME_ROUTE_SET + p * 16], 1u)] = (uint32_t)i;
+        const uint32_t slot = atomicAdd(&route[parity * ME_ROUTE_SET + p * 16], 1u);
+        if (slot < (uint32_t)cap) // always, with counters that start at zero; never write outside the list
+            route[ME_ROUTE_HEAD + p * cap + slot] = (uint32_t)i;
     }
 }
 
@@ -1512,7 +1527,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_BIG_WAVES
         for (int i = threadIdx.x; i < ME_ROUTE_SET; i += 64)
             route[(parity ^ 1) * ME_ROUTE_SET + i] = 0u;
     uint32_t *const counters = route + parity * ME_ROUTE_SET;
-    const uint32_t count = counters[p * 16];
+    const uint32_t count = min(counters[p * 16], (uint32_t)cap);
     uint32_t k = blockIdx.x / ME_PARTS;
     while (k < count)
     {
@@ -1642,6 +1657,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lo
     const x265_hip_lookahead_job &lj = jobs[job];
     Wave wv;
     wave_init(wv, &lds, 8, 8);
+    const int patv = pat_vector();
     const PlaneDesc fp = tabs->planes[lj.fenc_plane], rp = tabs->planes[lj.ref_plane];
     const uint8_t *const r1 = tabs->planes[lj.ref_plane + 1].origin, *const r2 = tabs->planes[lj.ref_plane + 2].origin,
                   *const r3 = tabs->planes[lj.ref_plane + 3].origin;
@@ -1756,9 +1772,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lo
         wave_sync();
         int cost, mx, my;
         if (lj.method <= X265_HIP_HEX)
-            motion_estimate_uv<true, true>(wv, jl, cost, mx, my);
+            motion_estimate_uv<true, true>(wv, jl, cost, mx, my, patv);
         else
-            motion_estimate_uv<false, true>(wv, jl, cost, mx, my);
+            motion_estimate_uv<false, true>(wv, jl, cost, mx, my, patv);
         right = (int)((uint32_t)(mx & 0xffff) | ((uint32_t)my << 16));
         if (lane == 0)
             __hip_atomic_store(&mine[cux], (look_word)(uint32_t)cost | ((look_word)(uint32_t)right << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
