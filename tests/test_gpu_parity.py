@@ -909,6 +909,15 @@ def test_empty_and_single_record_lists(gpu_ctx, oracle, small_seq, costtabs):
     gpu_ctx.predict_batch_device(0, 0)
     gpu_ctx.inter_search_batch_device(0, 0, W, H, 0)
     gpu_ctx.sync()
+    # an empty call must not take one of the two alternating counter sets (the launch after it would start on counters
+    # nobody cleared): one empty call between two real launches, for the cost kernels and for the motionEstimate list
+    for _ in range(3):
+        reqs = random_cost_reqs(rng, 700, W, H, abi.COST_REQ, abi.PARTS)
+        assert np.array_equal(gpu_ctx.cost_batch(reqs), oracle.cost_batch(planes, reqs))
+        gpu_ctx.cost_batch_device(0, 0, 0)
+        jobs = random_me_jobs(rng, 300, abi.HEX, 2, W, H, abi.ME_JOB, synth.search_range, abi.PARTS)
+        assert np.array_equal(gpu_ctx.me_batch(jobs), oracle.me_batch(planes, costtabs, jobs))
+        gpu_ctx.me_batch_device(0, 0, 0)
     for size in ((8, 8), (64, 64)):  # one job for me_kernel, one for me_big_kernel
         table = [abi.PARTS[0]] + [size] * 24
         jobs = random_me_jobs(rng, 1, abi.HEX, 2, W, H, abi.ME_JOB, synth.search_range, table)

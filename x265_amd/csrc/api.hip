@@ -1090,6 +1090,8 @@ int x265_hip_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void 
 {
     if (!c || n < 0 || (n && (!d_reqs || !d_costs)))
         return fail(X265_HIP_EINVAL, "cost_batch_device: bad argument");
+    if (n == 0) // nothing to launch; a launch takes one of the two counter sets and clears the other
+        return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     {
@@ -1165,6 +1167,8 @@ int x265_hip_refine_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, voi
 {
     if (!c || n < 0 || (n && (!d_reqs || !d_costs9)))
         return fail(X265_HIP_EINVAL, "refine_batch_device: bad argument");
+    if (n == 0) // nothing to launch; a launch takes one of the two counter sets and clears the other
+        return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     {
@@ -1261,6 +1265,8 @@ int x265_hip_dist_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void 
 {
     if (!c || n < 0 || (n && (!d_reqs || !d_costs)))
         return fail(X265_HIP_EINVAL, "dist_batch_device: bad argument");
+    if (n == 0) // nothing to launch; a launch takes one of the two counter sets and clears the other
+        return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     {
@@ -1304,6 +1310,8 @@ int x265_hip_predict_batch_device(x265_hip_ctx *c, const void *d_reqs, int n)
 {
     if (!c || n < 0 || (n && !d_reqs))
         return fail(X265_HIP_EINVAL, "predict_batch_device: bad argument");
+    if (n == 0) // nothing to launch; a launch takes one of the two counter sets and clears the other
+        return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     {
@@ -1344,6 +1352,8 @@ int x265_hip_bidir_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n,
 {
     if (!c || n < 0 || (n && (!d_reqs || !d_costs)))
         return fail(X265_HIP_EINVAL, "bidir_cost_batch_device: bad argument");
+    if (n == 0) // nothing to launch; a launch takes one of the two counter sets and clears the other
+        return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     {
