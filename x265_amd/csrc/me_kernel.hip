@@ -235,17 +235,18 @@ __device__ __forceinline__ void q_eval(Wave &wv, int group_metric)
     int lane = wv.lane;
     asm volatile("" : "+v"(lane));
     const int nq = wv.nq;
-    int seed = 0, px = 0, py = 0, pa = 0;
+    // the two cost-table entries of this lane's candidate are asked for here and first used behind the item loop, so
+    // that their round trip runs beside the loop's pixel loads instead of in front of them
+    int ta = 0, tb = 0, px = 0, py = 0, pa = 0;
     if (lane < nq)
     {
         px = s->qx[lane];
         py = s->qy[lane];
         pa = s->aux[lane];
-        const int mode = pa & 3;
-        if (mode != MV_NONE)
+        if ((pa & 3) != MV_NONE)
         {
-            const int a = tab_at(wv.tab, wv.mvpx, px), b = tab_at(wv.tab, wv.mvpy, py);
-            seed = mode == MV_COST ? (int)(uint16_t)(a + b) : a + b;
+            ta = tab_at(wv.tab, wv.mvpx, px);
+            tb = tab_at(wv.tab, wv.mvpy, py);
         }
     }
     if (lane < QMAX)
@@ -307,6 +308,7 @@ __device__ __forceinline__ void q_eval(Wave &wv, int group_metric)
     }
     }
     wave_sync();
+    const int seed = (pa & 3) == MV_COST ? (int)(uint16_t)(ta + tb) : ta + tb; // MV_NONE: 0 + 0
     wv.vc = lane < nq ? s->cost[lane & (QMAX - 1)] + seed : 0x7fffffff;
     wv.vx = px;
     wv.vy = py;
@@ -368,18 +370,17 @@ __device__ __forceinline__ void q_eval_big(Wave &wv, int metric)
 {
     WaveLds *s = wv.s;
     const int lane = wv.lane, nq = wv.nq;
-    int seed = 0, px = 0, py = 0, pa = 0;
+    int ta = 0, tb = 0, px = 0, py = 0, pa = 0; // as in q_eval
     bool wide = false;
     if (lane < nq)
     {
         px = s->qx[lane];
         py = s->qy[lane];
         pa = s->aux[lane];
-        const int mode = pa & 3;
-        if (mode != MV_NONE)
+        if ((pa & 3) != MV_NONE)
         {
-            const int a = tab_at(wv.tab, wv.mvpx, px), b = tab_at(wv.tab, wv.mvpy, py);
-            seed = mode == MV_COST ? (int)(uint16_t)(a + b) : a + b;
+            ta = tab_at(wv.tab, wv.mvpx, px);
+            tb = tab_at(wv.tab, wv.mvpy, py);
         }
         wide = metric == X265_HIP_SAD && ((px | py) & 3) == 0;
     }
@@ -428,6 +429,7 @@ __device__ __forceinline__ void q_eval_big(Wave &wv, int metric)
             big_strips<1>(wv, s->sel[1], ntall, metric);
     }
     wave_sync();
+    const int seed = (pa & 3) == MV_COST ? (int)(uint16_t)(ta + tb) : ta + tb; // MV_NONE: 0 + 0
     wv.vc = lane < nq ? s->cost[lane & (QMAX - 1)] + seed : 0x7fffffff;
     wv.vx = px;
     wv.vy = py;
