@@ -261,10 +261,26 @@ __device__ __forceinline__ void q_eval(Wave &wv, int group_metric)
     const int total = nq * wv.nt;
     // i / nt and t / ntx by reciprocal: exact for i < 4096, nt <= 256 (error 4e-4 << 0.5 / nt)
     const float inv_nt = __builtin_amdgcn_rcpf((float)wv.nt), inv_ntx = __builtin_amdgcn_rcpf((float)wv.ntx);
+    // blocks whose sides are powers of two (all but the 12 / 24 / 48 ones): shifts and masks instead
+    const bool pow2 = ((wv.nt & (wv.nt - 1)) | (wv.ntx & (wv.ntx - 1))) == 0;
+    const int sh_nt = __builtin_ctz(wv.nt), sh_ntx = __builtin_ctz(wv.ntx);
     for (int i = lane; i < total; i += 64)
     {
-        const int c = (int)(((float)i + 0.5f) * inv_nt), t = i - c * wv.nt;
-        const int ty = (int)(((float)t + 0.5f) * inv_ntx), tx = t - ty * wv.ntx;
+        int c, ty, tx;
+        if (pow2)
+        {
+            c = i >> sh_nt;
+            const int t = i & (wv.nt - 1);
+            ty = t >> sh_ntx;
+            tx = t & (wv.ntx - 1);
+        }
+        else
+        {
+            c = (int)(((float)i + 0.5f) * inv_nt);
+            const int t = i - c * wv.nt;
+            ty = (int)(((float)t + 0.5f) * inv_ntx);
+            tx = t - ty * wv.ntx;
+        }
         const int qx = s->qx[c], qy = s->qy[c];
         const uint8_t *r = wv.ref + ((qy >> 2) + 4 * ty) * wv.stride + (qx >> 2) + 4 * tx;
         const uint8_t *f = s->fenc + ty * 4 * 64 + tx * 4;
