@@ -194,7 +194,7 @@ __device__ __forceinline__ void wide_sad(Wave &wv, int nq)
     {
         const int c = (int)(((float)i + 0.5f) * inv_ns), t = i - c * ns;
         const int sy = (int)(((float)t + 0.5f) * inv_wx), sx = t - sy * wx;
-        gptr_t r = as_global(wv.ref) + ((s->qy[c] >> 2) + 4 * sy) * wv.stride + (s->qx[c] >> 2) + 16 * sx;
+        gptr_t r = as_global(wv.ref) + (((s->qy[c] >> 2) + 4 * sy) * wv.stride + (s->qx[c] >> 2) + 16 * sx);
         const uint8_t *f = s->fenc + sy * 4 * 64 + sx * 16;
         uint32_t a = 0;
         // two rows in flight at a time: the kernel has 72 registers per lane
@@ -282,7 +282,7 @@ __device__ __forceinline__ void q_eval(Wave &wv, int group_metric)
             tx = t - ty * wv.ntx;
         }
         const int qx = s->qx[c], qy = s->qy[c];
-        const uint8_t *r = wv.ref + ((qy >> 2) + 4 * ty) * wv.stride + (qx >> 2) + 4 * tx;
+        const uint8_t *r = wv.ref + (((qy >> 2) + 4 * ty) * wv.stride + (qx >> 2) + 4 * tx); // one 32-bit offset, one 64-bit add
         const uint8_t *f = s->fenc + ty * 4 * 64 + tx * 4;
         int v;
         const int metric = LOW == 1 ? (group_metric | ((s->aux[c] >> 30) & 1)) : group_metric;
@@ -367,7 +367,7 @@ __device__ __forceinline__ void big_strips(Wave &wv, const int *sel, int count, 
         const int k = (int)(((float)i + 0.5f) * inv_ns), t = i - k * ns, c = sel[k];
         const int ty = (int)(((float)t + 0.5f) * inv_ntx), tx = t - ty * wv.ntx;
         const int qx = s->qx[c], qy = s->qy[c];
-        const uint8_t *r = wv.ref + ((qy >> 2) + 4 * NT * ty) * wv.stride + (qx >> 2) + 4 * tx;
+        const uint8_t *r = wv.ref + (((qy >> 2) + 4 * NT * ty) * wv.stride + (qx >> 2) + 4 * tx);
         const uint8_t *f = s->fenc + ty * 4 * NT * 64 + tx * 4;
         const bool any_diag = __ballot((qx & 3) && (qy & 3)) != 0;
         uint32_t pix[4 * NT][2];
@@ -417,7 +417,7 @@ __device__ __forceinline__ void q_eval_big(Wave &wv, int metric)
         {
             const int k = (int)(((float)i + 0.5f) * inv_ns), t = i - k * ns, c = s->sel[0][k];
             const int sy = (int)(((float)t + 0.5f) * inv_wx), sx = t - sy * wx;
-            gptr_t r = as_global(wv.ref) + ((s->qy[c] >> 2) + 4 * sy) * wv.stride + (s->qx[c] >> 2) + 16 * sx;
+            gptr_t r = as_global(wv.ref) + (((s->qy[c] >> 2) + 4 * sy) * wv.stride + (s->qx[c] >> 2) + 16 * sx);
             const uint8_t *f = s->fenc + sy * 4 * 64 + sx * 16;
             uint32_t a = 0;
 #pragma unroll
