@@ -10,6 +10,9 @@ import numpy as np
 from x265_amd import abi, lib, synth
 from x265_amd.hipmem import DeviceBuffer
 
+if os.environ.get("X265_EXP_LIB"):  # experiments: another build of the library
+    lib.LIB_PATH = os.path.abspath(os.environ["X265_EXP_LIB"])
+
 W, H = (3840, 2160) if (len(sys.argv) < 2 or sys.argv[1] == "4k") else (1920, 1080)
 seq = synth.Sequence(W, H, seed=0x265)
 planes = [synth.Plane(seq.frame(i)) for i in range(4)]

@@ -1829,6 +1829,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lo
 // Lanes read source and reference pixels straight from the planes (a request is a single candidate, nothing
 // is reused); partial sums meet in LDS atomics.
 #define COST_BATCH 32
+#ifndef COST_DIAG_UNIFY
+#define COST_DIAG_UNIFY 1
+#endif
 #define COST_MAX_BLOCKS (256 * 6)
 #define COST_PARTS 64 // counters are 64 bytes apart
 #define COST_CHUNK 8
@@ -2193,7 +2196,8 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                     }
                 }
                 else
-                    ref_strip<2>(L.ref[k] + 8 * ty * rstride + 4 * tx, rstride, xf, yf, pix);
+                    // lanes of this pass that need the diagonal filter pull the half-fractional ones along (one path, not three)
+                    ref_strip<2>(L.ref[k] + 8 * ty * rstride + 4 * tx, rstride, xf, yf, pix, COST_DIAG_UNIFY && __ballot(xf && yf) != 0);
                 if (BIDIR && !(info & (INFO_LOWRES | INFO_MCAVG)))
                 {
                     const int rs1 = L.rstride1[k];
@@ -2239,7 +2243,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                     }
                 }
                 else
-                    ref_strip<1>(L.ref[k] + 4 * ty * rstride + 4 * tx, rstride, xf, yf, pix);
+                    ref_strip<1>(L.ref[k] + 4 * ty * rstride + 4 * tx, rstride, xf, yf, pix, COST_DIAG_UNIFY && __ballot(xf && yf) != 0);
                 if (BIDIR && !(info & INFO_MCAVG))
                 {
                     const int rs1 = L.rstride1[k];
