@@ -41,6 +41,9 @@ __device__ __forceinline__ int s16(int v) { return (int)(int16_t)v; }
 #define PAT_N 57
 #define SPEC_SQ_TILES 4    // speculate the square refine for PUs of at most this many 4x4 tiles
 #define SPEC_QPEL_TILES 16 // same for the quarter-pel ring
+#ifndef ME_DIRECT_STATES
+#define ME_DIRECT_STATES 1
+#endif
 #ifndef ME_SPEC_LOW
 #define ME_SPEC_LOW 1 // Lowres references: SATD re-measure + quarter-pel ring together with the half-pel ring
 #endif
@@ -571,6 +574,7 @@ enum State
 template <bool SMALL, bool LOWRES, bool BIG = false, bool WIDE = false>
 __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_job &j, int &rcost, int &rmx, int &rmy, int patv = 0)
 {
+    constexpr bool DIRECT = LOWRES && ME_DIRECT_STATES;
     // integer-stage state, all wave-uniform
     const int lox = j.mvmin_x, loy = j.mvmin_y, hix = j.mvmax_x, hiy = j.mvmax_y; // full-pel, inclusive
     int bcost = 0, bx = 0, by = 0; // best so far: full-pel during the integer stage, quarter-pel after ST_POST
@@ -1116,8 +1120,15 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
             }
             wv.nq = 0;
             st = ST_INT_BEGIN;
-            break;
         }
+        // In the searches against Lowres references (latency-bound chains) states that queue nothing go straight on to
+        // the next one's code (fall through or goto) instead of round the loop and through the dispatch again:
+        // measured in the lookahead kernel, the state code between evaluations was 37 % of a search's time, a fifth
+        // of it such empty trips.  (In me_kernel's other instantiations the same jumps cost 14 more spilled
+        // registers and 4 % of the bench list, so they stay with the loop.)
+        if (!DIRECT)
+            break;
+        [[fallthrough]];
 
         case ST_INT_BEGIN:
             if (method == X265_HIP_DIA)
@@ -1127,7 +1138,11 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
                 st = ST_DIA;
             }
             else if (SMALL || method == X265_HIP_HEX)
+            {
                 st = ST_HEX_BEGIN;
+                if (DIRECT)
+                    goto hex_begin;
+            }
             else if (method == X265_HIP_UMH)
             {
                 // refine predictors: DIA1_ITER(pmv), DIA1_ITER(0) (motion.cpp:707-712)
@@ -1171,17 +1186,24 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
             if (!take_ring(0, 4, 1))
             {
                 st = ST_POST;
+                if (DIRECT)
+                    goto post_stage;
                 break;
             }
             if (--cnt && IN_RANGE(bx, by))
                 push_pat(wv, bx, by, PAT_SQ + 1, 4, 1, 2, MV_COST);
             else
+            {
                 st = ST_POST;
+                if (DIRECT)
+                    goto post_stage;
+            }
             break;
         }
 
         // ---- HEX: radius-2 hexagon then square refine (motion.cpp:628-700)
         case ST_HEX_BEGIN:
+        hex_begin:
             push_pat(wv, bx, by, PAT_HEX + 1, 6, 1, 2, MV_COST); // hex2[1..6]: directions 0..5
             if (spec_sq)
                 push_square();
@@ -1231,6 +1253,8 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
                 {
                     take_square(nstep); // the centre stayed: the square was evaluated with this step
                     st = ST_POST;
+                    if (DIRECT)
+                        goto post_stage;
                 }
                 else
                 {
@@ -1245,10 +1269,13 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
             take_square(0);
             wv.nq = 0;
             st = ST_POST;
-            break;
+            if (!DIRECT)
+                break;
+            [[fallthrough]];
 
         // ---- after the integer stage (motion.cpp:1039-1119)
         case ST_POST:
+        post_stage:
             if (bprecost < bcost) // pre-test winner bypasses the integer result
             {
                 bx = bpx;
