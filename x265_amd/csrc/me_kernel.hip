@@ -527,9 +527,17 @@ __device__ __forceinline__ int q_argmin(const Wave &wv, int off, int count)
 
 __device__ __constant__ const int8_t k_twopoint[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
                                                           { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
-// {hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd}, motion.cpp:47-57
-__device__ __constant__ const uint8_t k_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
-                                                          { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+// {hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd} per subme level, motion.cpp:47-57:
+// column c of that table, entry i in bits 4 i .. 4 i + 3
+__device__ __forceinline__ constexpr uint32_t workload_column(int c)
+{
+    constexpr uint8_t w[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
+                                  { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+    uint32_t v = 0;
+    for (int i = 0; i < 8; i++)
+        v |= (uint32_t)w[i][c] << (4 * i);
+    return v;
+}
 __device__ __constant__ const int8_t k_umh_oct[8][2] = { { 0, -2 }, { -1, -1 }, { 1, -1 }, { -2, 0 }, { 2, 0 }, { -1, 1 }, { 1, 1 }, { 0, 2 } };
 __device__ __constant__ const int8_t k_umh_hex[8][2] = { { -1, -2 }, { 1, -2 }, { -2, -1 }, { 2, -1 }, { -2, 1 }, { 2, 1 }, { -1, 2 }, { 1, 2 } };
 __device__ __constant__ const uint8_t k_range_mul[4][4] = { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } };
@@ -584,10 +592,12 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
     const int method = j.method & ~X265_HIP_LOWRES_REF;
     const int nmvc = j.num_mvc;
     const int subme = j.subme;
-    // wave-uniform, and said so: left in vector registers they were among the values spilled to scratch
-    const int hpel_iters = uniform(k_workload[subme][0]), hpel_dirs = uniform(k_workload[subme][1]);
-    const int qpel_iters = uniform(k_workload[subme][2]), qpel_dirs = uniform(k_workload[subme][3]);
-    const int hsatd = uniform(k_workload[subme][4]);
+    // workload[subme] (motion.cpp:47-57) out of nibble-packed constants, one per column: scalar arithmetic instead of
+    // five loads from a table in memory whose round trip stood at the head of every call
+    const int wsh = 4 * (subme & 7);
+    const int hpel_iters = (int)(workload_column(0) >> wsh) & 15, hpel_dirs = (int)(workload_column(1) >> wsh) & 15;
+    const int qpel_iters = (int)(workload_column(2) >> wsh) & 15, qpel_dirs = (int)(workload_column(3) >> wsh) & 15;
+    const int hsatd = (int)(workload_column(4) >> wsh) & 15;
 
 #define IN_RANGE(x, y) ((x) >= lox && (x) <= hix && (y) >= loy && (y) <= hiy)
 
