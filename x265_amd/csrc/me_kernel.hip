@@ -122,19 +122,34 @@ __device__ __forceinline__ void wave_init(Wave &wv, WaveLds *s, int w, int h)
     wv.vc = wv.vx = wv.vy = wv.va = 0;
     wv.lowres = false;
     wv.lref1 = wv.lref2 = wv.lref3 = nullptr;
-    if (wv.lane < PAT_N)
-        s->pat[wv.lane] = k_pat[wv.lane]; // made visible by load_fenc's wave_sync
 }
 
+// setSourcePU: the block's pixels into LDS at stride 64, and the pattern table beside them.  Four loads per lane are in
+// flight at a time (a 64x64 block was sixteen load-then-store round trips in a row), the table's load among them.
 __device__ __forceinline__ void load_fenc(Wave &wv, const uint8_t *src, int sstride)
 {
     const int ndw = wv.ntx * wv.h;
     const float inv_ntx = __builtin_amdgcn_rcpf((float)wv.ntx); // i / ntx below is exact: i < 1024, ntx <= 16
-    for (int i = wv.lane; i < ndw; i += 64)
+    const int pat = wv.lane < PAT_N ? k_pat[wv.lane] : 0;
+    for (int base = wv.lane; base < ndw; base += 256)
     {
-        int y = (int)(((float)i + 0.5f) * inv_ntx), x = i - y * wv.ntx;
-        *(uint32_t *)(wv.s->fenc + y * 64 + 4 * x) = ld4g(as_global(src) + y * sstride + 4 * x);
+        uint32_t v[4];
+        int at[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int i = base + 64 * k;
+            const int y = (int)(((float)i + 0.5f) * inv_ntx), x = i - y * wv.ntx;
+            at[k] = y * 64 + 4 * x;
+            v[k] = i < ndw ? ld4g(as_global(src) + (y * sstride + 4 * x)) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (base + 64 * k < ndw)
+                *(uint32_t *)(wv.s->fenc + at[k]) = v[k];
     }
+    if (wv.lane < PAT_N)
+        wv.s->pat[wv.lane] = pat;
     wave_sync();
 }
 
@@ -1713,6 +1728,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lo
     Wave wv;
     wave_init(wv, &lds, 8, 8);
     const int patv = pat_vector();
+    if (lane < PAT_N)
+        lds.pat[lane] = patv; // (load_fenc's part; visible behind the wave_sync in front of the first search)
     const PlaneDesc fp = tabs->planes[lj.fenc_plane], rp = tabs->planes[lj.ref_plane];
     const uint8_t *const r1 = tabs->planes[lj.ref_plane + 1].origin, *const r2 = tabs->planes[lj.ref_plane + 2].origin,
                   *const r3 = tabs->planes[lj.ref_plane + 3].origin;
