@@ -634,14 +634,21 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
     if (nz)
         q_push(wv, 0, 0, MV_COST);
     const int first_mvc = wv.nq;
-    for (int i = 0; i < nmvc; i++)
     {
-        int mx = min((int)j.mvc[2 * i], qhix), my = min((int)j.mvc[2 * i + 1], qhiy);
-        mx = max(mx, qlox);
-        my = max(my, qloy);
-        // zero and pmv are skipped here; "m != bestpre" (motion.cpp:584) is resolved when consuming
-        if ((mx | my) && !(mx == pmx && my == pmy))
-            q_push(wv, mx, my, MV_COST);
+        // lane i takes candidate i (one load for all of them; a loop over the list was one memory round trip per
+        // candidate at the head of the call); the valid ones are queued in list order
+        int mx = 0, my = 0;
+        bool valid = false;
+        if (wv.lane < nmvc)
+        {
+            int pair;
+            __builtin_memcpy(&pair, &j.mvc[2 * wv.lane], 4);
+            mx = max(min((int)(int16_t)pair, qhix), qlox);
+            my = max(min(pair >> 16, qhiy), qloy);
+            // zero and pmv are skipped here; "m != bestpre" (motion.cpp:584) is resolved when consuming
+            valid = (mx | my) && !(mx == pmx && my == pmy);
+        }
+        push_lanes(wv, nmvc, mx, my, MV_COST, valid);
     }
 
     int st = ST_PRE, metric = X265_HIP_SAD, flush = FL_NONE;
