@@ -207,7 +207,10 @@ __device__ __forceinline__ uint32_t pack2(int lo, int hi) { return (uint32_t)lo 
 // (ipfilter.cpp:38-54, 117-160, 204-239, 285-317); `diag` is not used with it.
 __device__ __forceinline__ uint32_t pack_s16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100); }
 
-template <int NT, bool SH = false>
+// AH > 0: the rows of the horizontal and the diagonal path are fetched AH ahead of their use (left alone the compiler,
+// which orders for few registers, waits for every row load right behind it: R or R + 7 memory round trips in a row).
+// For kernels with registers to spare (me_big_kernel); in me_kernel and cost_kernel it cost more in spills than it gave.
+template <int NT, bool SH = false, int AH = 0>
 __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf, int yf, uint32_t P[4 * NT][2],
                                           bool diag = false)
 {
@@ -235,13 +238,34 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
         // luma_hpp: dst = clip((sum_k src[x-3+k]*c[k] + 32) >> 6)
         const uint32_t tlo = k_taps_s8[xf][0], thi = k_taps_s8[xf][1];
         gptr_t p = r_ - 3;
+        uint32_t ah[AH ? AH : 1][3];
+        if (AH)
+#pragma unroll
+            for (int y = 0; y < AH && y < R; y++)
+            {
+                ld12g(p, ah[y][0], ah[y][1], ah[y][2]);
+                p += stride;
+            }
 #pragma unroll
         for (int y = 0; y < R; y++)
         {
             int h[4];
             uint32_t d0, d1, d2;
-            ld12g(p, d0, d1, d2);
-            p += stride;
+            if (AH)
+            {
+                d0 = ah[y % (AH ? AH : 1)][0], d1 = ah[y % (AH ? AH : 1)][1], d2 = ah[y % (AH ? AH : 1)][2];
+                if (y + AH < R)
+                {
+                    ld12g(p, ah[y % (AH ? AH : 1)][0], ah[y % (AH ? AH : 1)][1], ah[y % (AH ? AH : 1)][2]);
+                    p += stride;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            else
+            {
+                ld12g(p, d0, d1, d2);
+                p += stride;
+            }
             if (SH)
             {
                 tap8x4<0>(d0 ^ bias, d1 ^ bias, d2 ^ bias, tlo, thi, h);
@@ -323,21 +347,52 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
         gptr_t p = r_ - 3 * stride - 3;
         constexpr int seed = SH ? 0 : 2048 + (8192 << 6);
         uint32_t q[NP][4];
+        constexpr int ROWS = R + 7, A = AH ? AH : 1;
+        uint32_t ah[A][3];
+        if (AH)
+#pragma unroll
+            for (int y = 0; y < AH && y < ROWS; y++)
+            {
+                ld12g(p, ah[y][0], ah[y][1], ah[y][2]);
+                p += stride;
+            }
         // pairs are produced in order and a pair of output rows is emitted as soon as its five pairs exist,
         // so only a window of five pairs is live at a time
 #pragma unroll
         for (int j = 0; j < NP; j++)
         {
             int a[4], b[4] = { 0, 0, 0, 0 };
-            uint32_t d0, d1, d2;
-            ld12g(p, d0, d1, d2);
-            tap8x4<0>(d0 ^ bias, d1 ^ bias, d2 ^ bias, tlo, thi, a);
-            p += stride;
-            if (j < NP - 1)
+            uint32_t d0, d1, d2, e0 = 0, e1 = 0, e2 = 0;
+            if (AH)
+            {
+                d0 = ah[(2 * j) % A][0], d1 = ah[(2 * j) % A][1], d2 = ah[(2 * j) % A][2];
+                e0 = ah[(2 * j + 1) % A][0], e1 = ah[(2 * j + 1) % A][1], e2 = ah[(2 * j + 1) % A][2];
+                if (2 * j + AH < ROWS)
+                {
+                    ld12g(p, ah[(2 * j) % A][0], ah[(2 * j) % A][1], ah[(2 * j) % A][2]);
+                    p += stride;
+                }
+                if (2 * j + 1 + AH < ROWS)
+                {
+                    ld12g(p, ah[(2 * j + 1) % A][0], ah[(2 * j + 1) % A][1], ah[(2 * j + 1) % A][2]);
+                    p += stride;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            else
             {
                 ld12g(p, d0, d1, d2);
-                tap8x4<0>(d0 ^ bias, d1 ^ bias, d2 ^ bias, tlo, thi, b);
                 p += stride;
+            }
+            tap8x4<0>(d0 ^ bias, d1 ^ bias, d2 ^ bias, tlo, thi, a);
+            if (j < NP - 1)
+            {
+                if (!AH)
+                {
+                    ld12g(p, e0, e1, e2);
+                    p += stride;
+                }
+                tap8x4<0>(e0 ^ bias, e1 ^ bias, e2 ^ bias, tlo, thi, b);
             }
 #pragma unroll
             for (int x = 0; x < 4; x++)

@@ -359,6 +359,9 @@ __device__ __forceinline__ void q_eval(Wave &wv, int group_metric)
 #ifndef ME_WIDE
 #define ME_WIDE 1
 #endif
+#ifndef ME_BIG_AHEAD
+#define ME_BIG_AHEAD 4 // rows of a strip in flight in me_big_kernel's filters
+#endif
 #ifndef ME_BIG_TILES
 #define ME_BIG_TILES 128
 #endif
@@ -389,7 +392,7 @@ __device__ __forceinline__ void big_strips(Wave &wv, const int *sel, int count, 
         const uint8_t *f = s->fenc + ty * 4 * NT * 64 + tx * 4;
         const bool any_diag = __ballot((qx & 3) && (qy & 3)) != 0;
         uint32_t pix[4 * NT][2];
-        ref_strip<NT>(r, wv.stride, qx & 3, qy & 3, pix, any_diag);
+        ref_strip<NT, false, ME_BIG_AHEAD>(r, wv.stride, qx & 3, qy & 3, pix, any_diag);
         int v = 0;
 #pragma unroll
         for (int u = 0; u < NT; u++)
@@ -438,15 +441,23 @@ __device__ __forceinline__ void q_eval_big(Wave &wv, int metric)
             gptr_t r = as_global(wv.ref) + (((s->qy[c] >> 2) + 4 * sy) * wv.stride + (s->qx[c] >> 2) + 16 * sx);
             const uint8_t *f = s->fenc + sy * 4 * 64 + sx * 16;
             uint32_t a = 0;
+            // the four row loads first (left to itself the compiler reuses one register quad and waits for each)
+            uint4 rv[4];
 #pragma unroll
             for (int y = 0; y < 4; y++)
             {
-                const uint4 fv = *(const uint4 *)(f + y * 64), rv = ld16g(r);
+                rv[y] = ld16g(r);
                 r += wv.stride;
-                a = __builtin_amdgcn_sad_u8(fv.x, rv.x, a);
-                a = __builtin_amdgcn_sad_u8(fv.y, rv.y, a);
-                a = __builtin_amdgcn_sad_u8(fv.z, rv.z, a);
-                a = __builtin_amdgcn_sad_u8(fv.w, rv.w, a);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+            {
+                const uint4 fv = *(const uint4 *)(f + y * 64);
+                a = __builtin_amdgcn_sad_u8(fv.x, rv[y].x, a);
+                a = __builtin_amdgcn_sad_u8(fv.y, rv[y].y, a);
+                a = __builtin_amdgcn_sad_u8(fv.z, rv[y].z, a);
+                a = __builtin_amdgcn_sad_u8(fv.w, rv[y].w, a);
             }
             const int v = row_sum16((int)a);
             if ((lane & 15) == 0)
