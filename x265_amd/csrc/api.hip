@@ -121,7 +121,9 @@ int scratch_setup(int device)
     return 0;
 }
 
-int ensure(x265_hip_ctx *c, Buf &b, size_t bytes)
+// `pinned`: also a pinned host mirror of the same size (the staging of the host-array calls); buffers that only the
+// device reads and writes (routing lists, jobs made on the device, lookahead counters) go without
+int ensure(x265_hip_ctx *c, Buf &b, size_t bytes, bool pinned = true)
 {
     if (bytes <= b.cap)
         return 0;
@@ -133,7 +135,8 @@ int ensure(x265_hip_ctx *c, Buf &b, size_t bytes)
     b.d = b.h = nullptr;
     b.cap = 0;
     HIP_TRY(hipMalloc(&b.d, cap));
-    HIP_TRY(hipHostMalloc(&b.h, cap, hipHostMallocDefault));
+    if (pinned)
+        HIP_TRY(hipHostMalloc(&b.h, cap, hipHostMallocDefault));
     b.cap = cap;
     (void)c;
     return 0;
@@ -141,18 +144,18 @@ int ensure(x265_hip_ctx *c, Buf &b, size_t bytes)
 
 // `launches`: whether kernels will run (a call without jobs must not take a counter set: the set is cleared for the
 // launch after next by the launch that uses it)
-MeRoute me_route(x265_hip_ctx *c, bool launches, bool any_big = true)
+MeRoute me_route(x265_hip_ctx *c, bool launches, bool any_routed = true)
 {
-    if (!launches || !any_big)
+    if (!launches || !any_routed)
         return MeRoute{ nullptr, 0, c->stream, nullptr, nullptr, nullptr };
     return MeRoute{ (uint32_t *)c->route.d, c->route_parity++, c->stream, c->side, c->ev_fork, c->ev_join };
 }
 
 template <typename Job>
-bool any_big_job(const Job *jobs, int n)
+bool any_routed_job(const Job *jobs, int n)
 {
     for (int i = 0; i < n; i++)
-        if (me_block_is_big(jobs[i].pu_w, jobs[i].pu_h, jobs[i].method))
+        if (me_job_is_routed(jobs[i].pu_w, jobs[i].pu_h, jobs[i].method))
             return true;
     return false;
 }
@@ -164,7 +167,7 @@ int ensure_route(x265_hip_ctx *c, int n)
     if (c->route.cap >= bytes)
         return 0;
     HIP_TRY(hipStreamSynchronize(c->stream)); // an earlier launch may still read the buffer that is about to be replaced
-    int r = ensure(c, c->route, bytes);
+    int r = ensure(c, c->route, bytes, false);
     if (r)
         return r;
     HIP_TRY(hipMemsetAsync(c->route.d, 0, me_route_counter_words() * sizeof(uint32_t), c->stream)); // both counter sets
@@ -961,7 +964,7 @@ int x265_hip_me_batch(x265_hip_ctx *c, const x265_hip_me_job *jobs, int n, x265_
     // straight from the caller's memory: the runtime pipelines its own staging, which beats a copy into the
     // pinned mirror followed by one DMA
     HIP_TRY(hipMemcpyAsync(c->in.d, jobs, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
-    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, me_route(c, n > 0, any_big_job(jobs, n))));
+    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)c->in.d, n, (x265_hip_me_result *)c->out.d, me_route(c, n > 0, any_routed_job(jobs, n))));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, (size_t)n * sizeof(*results), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(results, c->out.h, (size_t)n * sizeof(*results));
@@ -986,7 +989,7 @@ int x265_hip_inter_search_batch_device(x265_hip_ctx *c, const void *d_jobs, int 
     int r;
     if (c->mejobs.cap < (size_t)n * sizeof(x265_hip_me_job))
         HIP_TRY(hipStreamSynchronize(c->stream)); // an earlier launch may still read the buffer that is about to be replaced
-    if ((r = push_tabs(c)) || (r = ensure(c, c->mejobs, (size_t)n * sizeof(x265_hip_me_job))) || (r = ensure_route(c, n)))
+    if ((r = push_tabs(c)) || (r = ensure(c, c->mejobs, (size_t)n * sizeof(x265_hip_me_job), false)) || (r = ensure_route(c, n)))
         return r;
     LAUNCH(launch_inter_search(c->dev_tabs, (const x265_hip_inter_job *)d_jobs, n, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d,
                                (x265_hip_inter_result *)d_results, me_route(c, n > 0)));
@@ -1009,11 +1012,11 @@ int x265_hip_inter_search_batch(x265_hip_ctx *c, const x265_hip_inter_job *jobs,
     int r;
     const size_t ob = (size_t)n * sizeof(*results);
     if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*jobs))) || (r = ensure(c, c->out, ob)) ||
-        (r = ensure(c, c->mejobs, (size_t)n * sizeof(x265_hip_me_job))) || (r = ensure_route(c, n)))
+        (r = ensure(c, c->mejobs, (size_t)n * sizeof(x265_hip_me_job), false)) || (r = ensure_route(c, n)))
         return r;
     HIP_TRY(hipMemcpyAsync(c->in.d, jobs, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
     LAUNCH(launch_inter_search(c->dev_tabs, (const x265_hip_inter_job *)c->in.d, n, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d,
-                               (x265_hip_inter_result *)c->out.d, me_route(c, n > 0, any_big_job(jobs, n))));
+                               (x265_hip_inter_result *)c->out.d, me_route(c, n > 0, any_routed_job(jobs, n))));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(results, c->out.h, ob);

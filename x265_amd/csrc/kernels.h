@@ -66,9 +66,10 @@ struct PrimAddAvgArgs
 
 void launch_prim_addavg(const PrimAddAvgArgs &a, hipStream_t st);
 // What a motionEstimate launch needs besides its arguments.  `route`: me_route_words(n) 32-bit words of device scratch
-// (the list of large-block jobs, made and used by the launch) whose first me_route_counter_words() words were zeroed
-// once; `parity` flips with every launch that uses the buffer.  The launch is ordered on `stream`; with `side`
-// (another stream) and the two events it runs its large-block kernel beside the other one.
+// (the lists that split the jobs between the kernels, me_shared.h: made and used by the launch) whose first
+// me_route_counter_words() words were zeroed once; `parity` flips with every launch that uses the buffer.  The launch
+// is ordered on `stream`; with `side` (another stream) and the two events it runs its large-block kernel beside the
+// other ones.
 struct MeRoute
 {
     uint32_t *route;
@@ -78,8 +79,9 @@ struct MeRoute
 };
 size_t me_route_words(int n);
 size_t me_route_counter_words();
-// what me_kernel leaves to me_big_kernel; a launch whose MeRoute::route is null has no such job (host-array callers check)
-bool me_block_is_big(int w, int h, int method);
+// whether a job goes to one of the specialised kernels; a launch whose MeRoute::route is null has no such job
+// (host-array callers check) and runs me_kernel with one workgroup per job
+bool me_job_is_routed(int w, int h, int method);
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, const MeRoute &r);
 // the steps of predInterSearch in front of motionEstimate, then me_kernel on the jobs they produce (`mejobs`: n records of scratch)
 void launch_inter_search(const DeviceTables *tabs, const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h, x265_hip_me_job *mejobs,

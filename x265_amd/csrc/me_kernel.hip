@@ -24,21 +24,14 @@
 
 #include "kernels.h"
 #include "me_device.h"
+#include "me_shared.h"
 
 namespace x265hip {
-
-__device__ __forceinline__ int s16(int v) { return (int)(int16_t)v; }
 
 #define QMAX 16
 #ifndef ME_ONE_D
 #define ME_ONE_D 1 // hpp and vpp tiles of q_eval through one routine (ref_tile_1d); 2: only in the diamond / hexagon instantiations
 #endif
-#define PAT_HEX 0
-#define PAT_SQ 8
-#define PAT_STAR8 17  // small star ring in visiting order, units of dist / 2
-#define PAT_STAR16 25 // large star ring (dist > 8) in visiting order, units of dist / 4
-#define PAT_HEX4 41   // UMH hexagon grid, units of the ring index
-#define PAT_N 57
 #define SPEC_SQ_TILES 4    // speculate the square refine for PUs of at most this many 4x4 tiles
 #define SPEC_QPEL_TILES 16 // same for the quarter-pel ring
 #ifndef ME_DIRECT_STATES
@@ -89,24 +82,6 @@ struct Wave
     bool lowres;
     const uint8_t *lref1, *lref2, *lref3;
 };
-
-#define PAT(dx, dy) (int)(((uint32_t)(uint16_t)(dy) << 16) | (uint16_t)(dx))
-// hex2 (motion.cpp:68-70) and square1 (motion.cpp:71-73)
-__device__ __constant__ const int k_pat[PAT_N] = {
-    PAT(-1, -2), PAT(-2, 0), PAT(-1, 2), PAT(1, 2), PAT(2, 0), PAT(1, -2), PAT(-1, -2), PAT(-2, 0),
-    PAT(0, 0), PAT(0, -1), PAT(0, 1), PAT(-1, 0), PAT(1, 0), PAT(-1, -1), PAT(-1, 1), PAT(1, -1), PAT(1, 1),
-    // StarPatternSearch, dist <= 8 (motion.cpp:300-420): points 2,1,3,4,5,6,8,7; the diagonal ones sit at dist / 2
-    PAT(0, -2), PAT(-1, -1), PAT(1, -1), PAT(-2, 0), PAT(2, 0), PAT(-1, 1), PAT(1, 1), PAT(0, 2),
-    // dist > 8 (motion.cpp:421-520): top, left, right, bottom, then three steps along each edge of the diamond
-    PAT(0, -4), PAT(-4, 0), PAT(4, 0), PAT(0, 4),
-    PAT(-1, -3), PAT(1, -3), PAT(-1, 3), PAT(1, 3), PAT(-2, -2), PAT(2, -2), PAT(-2, 2), PAT(2, 2),
-    PAT(-3, -1), PAT(3, -1), PAT(-3, 1), PAT(3, 1),
-    // hex4 (motion.cpp:132-138)
-    PAT(0, -4), PAT(0, 4), PAT(-2, -3), PAT(2, -3), PAT(-4, -2), PAT(4, -2), PAT(-4, -1), PAT(4, -1),
-    PAT(-4, 0), PAT(4, 0), PAT(-4, 1), PAT(4, 1), PAT(-4, 2), PAT(4, 2), PAT(-2, 3), PAT(2, 3),
-};
-__device__ __forceinline__ int pat_dx(int p) { return (int)(int16_t)p; }
-__device__ __forceinline__ int pat_dy(int p) { return p >> 16; }
 
 __device__ __forceinline__ void wave_init(Wave &wv, WaveLds *s, int w, int h)
 {
@@ -362,10 +337,6 @@ __device__ __forceinline__ void q_eval(Wave &wv, int group_metric)
 #ifndef ME_BIG_AHEAD
 #define ME_BIG_AHEAD 4 // rows of a strip in flight in me_big_kernel's filters
 #endif
-#ifndef ME_BIG_TILES
-#define ME_BIG_TILES 128
-#endif
-__device__ __forceinline__ bool big_block(int w, int h) { return (w & 15) == 0 && (w >> 2) * (h >> 2) >= ME_BIG_TILES; }
 
 __device__ __forceinline__ int row_sum16(int v)
 {
@@ -553,17 +524,6 @@ __device__ __forceinline__ int q_argmin(const Wave &wv, int off, int count)
 
 __device__ __constant__ const int8_t k_twopoint[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
                                                           { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
-// {hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd} per subme level, motion.cpp:47-57:
-// column c of that table, entry i in bits 4 i .. 4 i + 3
-__device__ __forceinline__ constexpr uint32_t workload_column(int c)
-{
-    constexpr uint8_t w[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
-                                  { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
-    uint32_t v = 0;
-    for (int i = 0; i < 8; i++)
-        v |= (uint32_t)w[i][c] << (4 * i);
-    return v;
-}
 __device__ __constant__ const int8_t k_umh_oct[8][2] = { { 0, -2 }, { -1, -1 }, { 1, -1 }, { -2, 0 }, { 2, 0 }, { -1, 1 }, { 1, 1 }, { 0, 2 } };
 __device__ __constant__ const int8_t k_umh_hex[8][2] = { { -1, -2 }, { 1, -2 }, { -2, -1 }, { 2, -1 }, { -2, 1 }, { 2, 1 }, { -1, 2 }, { 1, 2 } };
 __device__ __constant__ const uint8_t k_range_mul[4][4] = { { 3, 3, 4, 4 }, { 3, 4, 4, 4 }, { 4, 4, 4, 5 }, { 4, 4, 5, 6 } };
@@ -1529,29 +1489,12 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
 #ifndef ME_BIG_WAVES
 #define ME_BIG_WAVES 4
 #endif
-// One motionEstimate call per wave.  me_kernel, one workgroup per job, takes the jobs q_eval suits; a job of big_block()
-// size against a full-resolution reference it only notes in a list (`route`), and me_big_kernel (more registers per
-// lane, fewer waves per SIMD), launched behind it, has its waves take jobs from that list until it is empty.
-// The list of big jobs.  One counter for the whole grid would serialise (an atomic on one address takes ~12 ns), so
-// the list is kept in ME_PARTS parts: job i belongs to part i mod ME_PARTS (at most `cap` = ceil(n / ME_PARTS) entries)
-// and part p is served by the waves p, p + ME_PARTS, ... of me_big_kernel.  Per part one append counter (me_kernel) and
-// one hand-out counter (me_big_kernel), 64 bytes apart.  Two sets of counters alternate between launches (`parity`):
-// a launch's me_big_kernel clears the set of the next one, so nothing is memset per call.
-#define ME_PARTS 64
-#define ME_ROUTE_SET (2 * ME_PARTS * 16)  // words per counter set: append counters, then hand-out counters
-#define ME_ROUTE_HEAD (2 * ME_ROUTE_SET) // the lists start behind the two sets
-
-__device__ __forceinline__ bool job_is_big(const x265_hip_me_job &j)
-{
-    return big_block(j.pu_w, j.pu_h) && !(j.method & X265_HIP_LOWRES_REF);
-}
-
-// BIG: me_big_kernel's side.  Otherwise `skip_big` makes the wave leave a big job to that kernel; it does so after
-// the set-up, where the choice between the instantiations of the search is made anyway: a test in front of it puts
-// one more round of memory latency at the start of every small call (the loads of the set-up wait behind the
-// branch), 4 % of an 8x8 call.
+// One motionEstimate call per wave (me_kernel, me_big_kernel).  A launch that routes (me_shared.h) splits the list by
+// kind first: me_big_kernel takes the MC_BIG jobs (more registers per lane, fewer waves per SIMD), me_team_kernel
+// (me_team.hip) the small diamond / hexagon searches, several per wave, and me_kernel in its list mode the rest.  Without
+// routing (host-array callers whose list holds nothing but MC_REST jobs) me_kernel runs one workgroup per job.
 template <bool BIG>
-__device__ __forceinline__ void me_job(WaveLds &lds, const DeviceTables *tabs, const x265_hip_me_job &j, x265_hip_me_result *out, bool skip_big = false)
+__device__ __forceinline__ void me_job(WaveLds &lds, const DeviceTables *tabs, const x265_hip_me_job &j, x265_hip_me_result *out)
 {
     Wave wv;
     wave_init(wv, &lds, j.pu_w, j.pu_h);
@@ -1570,63 +1513,97 @@ __device__ __forceinline__ void me_job(WaveLds &lds, const DeviceTables *tabs, c
         wv.lref3 = tabs->planes[j.ref_plane + 3].origin + off;
     }
     load_fenc(wv, fp.origin + (long)j.pu_y * fp.stride + j.pu_x, fp.stride);
-    if (!BIG && skip_big && job_is_big(j))
-        return;
     motion_estimate<BIG>(wv, j, out);
+}
+
+// The waves of a list kernel: gridDim.x is a multiple of ME_PARTS; wave b serves part b mod ME_PARTS, starts with the
+// list entry of its own rank within the part and takes further ones from the part's hand-out counter; it leaves when
+// that has passed the end of the part's list (it only grows), so every wave reaches its exit.
+template <bool BIG>
+__device__ __forceinline__ void me_list_loop(WaveLds &lds, const DeviceTables *tabs, const x265_hip_me_job *jobs, uint32_t *route, int parity, int cap,
+                                             x265_hip_me_result *out, int out_stride)
+{
+    constexpr int cls = BIG ? MC_BIG : MC_REST;
+    const int p = blockIdx.x & (ME_PARTS - 1), waves = gridDim.x / ME_PARTS;
+    const uint32_t count = min(*route_append(route, parity, cls, p), (uint32_t)cap);
+    const uint32_t *const list = route_list(route, cap, cls, p);
+    uint32_t k = blockIdx.x / ME_PARTS;
+    while (k < count)
+    {
+        const uint32_t id = list[k];
+        me_job<BIG>(lds, tabs, jobs[id], (x265_hip_me_result *)((char *)out + (size_t)id * out_stride));
+        wave_sync();
+        k = 0;
+        if ((threadIdx.x & 63) == 0)
+            k = (uint32_t)waves + atomicAdd(route_handout(route, parity, cls, p), 1u);
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    }
 }
 
 // results are out_stride bytes apart: 8 for x265_hip_me_result arrays, more when they head a larger record
 #ifndef ME_WAVES
 #define ME_WAVES 7
 #endif
+// route == nullptr: one workgroup per job of the list; otherwise the MC_REST jobs of a routed launch
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_WAVES))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
-                                                x265_hip_me_result *out, int out_stride, int skip_big)
+                                                x265_hip_me_result *out, int out_stride, uint32_t *route, int parity, int cap)
 {
     __shared__ WaveLds lds;
+    if (route)
+    {
+        me_list_loop<false>(lds, tabs, jobs, route, parity, cap, out, out_stride);
+        return;
+    }
     if ((int)blockIdx.x >= n)
         return;
     const int id = xcd_chunked(blockIdx.x, n, ME_XCD_CHUNK);
-    me_job<false>(lds, tabs, jobs[id], (x265_hip_me_result *)((char *)out + (size_t)id * out_stride), skip_big != 0);
+    me_job<false>(lds, tabs, jobs[id], (x265_hip_me_result *)((char *)out + (size_t)id * out_stride));
 }
 
-// the list of big jobs for me_big_kernel: a wave's big jobs go to their parts in one atomic per part and wave at most
-// (consecutive jobs go to consecutive parts)
-__global__ __launch_bounds__(256) void me_route_kernel(const x265_hip_me_job *jobs, int n, uint32_t *route, int parity, int cap)
+// The lists of a routed launch (me_shared.h).  A wave's 64 consecutive jobs go to one part, each kind with one atomic
+// per wave; list order inside a part follows job order inside a wave.  Block 0 also clears the counter set of the next
+// launch: that set was last used by the launch before this one, which is over (launches of a context are ordered).
+__global__ __launch_bounds__(256) void me_route_kernel(const x265_hip_me_job *jobs, int n, uint32_t *route, int parity, int cap, int team_on)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && job_is_big(jobs[i]))
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < ME_ROUTE_SET; k += 256)
+            route[(parity ^ 1) * ME_ROUTE_SET + k] = 0u;
+    int cls = -1;
+    if (i < n)
     {
-        const int p = i & (ME_PARTS - 1);
-        const uint32_t slot = atomicAdd(&route[parity * ME_ROUTE_SET + p * 16], 1u);
-        if (slot < (uint32_t)cap) // always, with counters that start at zero; never write outside the list
-            route[ME_ROUTE_HEAD + p * cap + slot] = (uint32_t)i;
+        cls = me_job_class(jobs[i].pu_w, jobs[i].pu_h, jobs[i].method);
+        if (!team_on && cls >= MC_T4)
+            cls = MC_REST;
+    }
+    const int p = (i >> 6) & (ME_PARTS - 1);
+#pragma unroll
+    for (int k = 0; k < ME_CLASSES; k++)
+    {
+        const unsigned long long m = __ballot(cls == k);
+        if (!m)
+            continue;
+        uint32_t base = 0;
+        if ((threadIdx.x & 63) == 0)
+            base = atomicAdd(route_append(route, parity, k, p), (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (cls == k)
+        {
+            const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (slot < (uint32_t)cap) // always, with counters that start at zero; never write outside the list
+                const_cast<uint32_t *>(route_list(route, cap, k, p))[slot] = (uint32_t)i;
+        }
     }
 }
 
-// gridDim.x is a multiple of ME_PARTS.  A wave starts with the list entry of its own rank within the part and takes
-// further ones from the part's counter; it leaves when that has passed the end of the part's list (it only grows).
+#ifndef ME_BIG_WAVES
+#define ME_BIG_WAVES 4
+#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_BIG_WAVES))) void me_big_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs,
                                                 uint32_t *route, int parity, int cap, x265_hip_me_result *out, int out_stride)
 {
     __shared__ WaveLds lds;
-    const int p = blockIdx.x & (ME_PARTS - 1), waves = gridDim.x / ME_PARTS;
-    // the next launch's counters (in me_kernel this loop cost a dozen spilled registers)
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < ME_ROUTE_SET; i += 64)
-            route[(parity ^ 1) * ME_ROUTE_SET + i] = 0u;
-    uint32_t *const counters = route + parity * ME_ROUTE_SET;
-    const uint32_t count = min(counters[p * 16], (uint32_t)cap);
-    uint32_t k = blockIdx.x / ME_PARTS;
-    while (k < count)
-    {
-        const uint32_t id = route[ME_ROUTE_HEAD + p * cap + k];
-        me_job<true>(lds, tabs, jobs[id], (x265_hip_me_result *)((char *)out + (size_t)id * out_stride));
-        wave_sync();
-        k = 0;
-        if ((threadIdx.x & 63) == 0)
-            k = (uint32_t)waves + atomicAdd(&counters[ME_PARTS * 16 + p * 16], 1u);
-        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-    }
+    me_list_loop<true>(lds, tabs, jobs, route, parity, cap, out, out_stride);
 }
 
 // The steps of predInterSearch in front of motionEstimate (reference Lib/TLibEncoder/TEncSearch.cpp:2315-2339), one wave
@@ -2393,26 +2370,41 @@ static int cost_blocks(int n, int)
     return (n + 3) / 4;
 }
 
-static int me_route_cap(int n) { return (n + ME_PARTS - 1) / ME_PARTS; }
-size_t me_route_words(int n) { return (size_t)ME_ROUTE_HEAD + (size_t)ME_PARTS * me_route_cap(n > 0 ? n : 0); }
+size_t me_route_words(int n) { return (size_t)ME_ROUTE_HEAD + (size_t)ME_CLASSES * ME_PARTS * me_route_cap(n > 0 ? n : 0); }
 size_t me_route_counter_words() { return ME_ROUTE_HEAD; }
-bool me_block_is_big(int w, int h, int method) { return (w & 15) == 0 && (w >> 2) * (h >> 2) >= ME_BIG_TILES && !(method & X265_HIP_LOWRES_REF); }
+bool me_job_is_routed(int w, int h, int method) { return me_job_class(w, h, method) != MC_REST; }
+
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// waves per part for a list kernel that can hold `resident` waves on the chip, for a launch of n jobs (a list of a
+// routed launch is at most the whole list)
+static int list_grid(int n, int per_wave, int resident)
+{
+    const int want = (n + ME_PARTS * per_wave - 1) / (ME_PARTS * per_wave);
+    const int most = resident / ME_PARTS;
+    return ME_PARTS * (want < 1 ? 1 : want > most ? most : want);
+}
 
 static void me_launch_both(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, int out_stride, const MeRoute &r)
 {
     if (n <= 0)
         return;
-    if (!r.route) // the caller knows that the list holds no big job
+    if (!r.route) // the caller knows that the list holds nothing but MC_REST jobs
     {
-        hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, r.stream, tabs, jobs, n, out, out_stride, 0);
+        hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, r.stream, tabs, jobs, n, out, out_stride, (uint32_t *)nullptr, 0, 0);
         return;
     }
     const int cap = me_route_cap(n), parity = r.parity & 1;
-    // The list first (made beside me_kernel on the side stream it had to find room among that kernel's half a million
-    // workgroups and sometimes ended with it: nothing ran side by side), then the big jobs on the side stream and the
-    // other jobs on the main one: the small jobs fill what the big ones leave idle (their last round, or most of the
-    // chip when there are few of them).
-    hipLaunchKernelGGL(me_route_kernel, dim3((n + 255) / 256), dim3(256), 0, r.stream, jobs, n, r.route, parity, cap);
+    static const int team_on = env_int("X265_HIP_ME_TEAM", 1); // experiments: 0 sends the small searches to me_kernel
+    // The lists first (made beside the searches on a side stream the kernel had to find room among their workgroups and
+    // sometimes ended with them: nothing ran side by side), then the big jobs on the side stream and the other jobs on
+    // the main one: the small jobs fill what the big ones leave idle (their last round, or most of the chip when
+    // there are few of them).
+    hipLaunchKernelGGL(me_route_kernel, dim3((n + 255) / 256), dim3(256), 0, r.stream, jobs, n, r.route, parity, cap, team_on);
     hipStream_t sb = r.side ? r.side : r.stream;
     if (r.side)
     {
@@ -2420,12 +2412,14 @@ static void me_launch_both(const DeviceTables *tabs, const x265_hip_me_job *jobs
         (void)hipStreamWaitEvent(r.side, r.fork, 0);
     }
     static const int big_grid = [] {
-        const char *e = getenv("X265_HIP_ME_BIG_GRID"); // experiments; a multiple of ME_PARTS
-        const int g = e ? atoi(e) : 0;
+        const int g = env_int("X265_HIP_ME_BIG_GRID", 0); // experiments; a multiple of ME_PARTS
         return g >= ME_PARTS ? g / ME_PARTS * ME_PARTS : 256 * 4 * ME_BIG_WAVES;
     }();
-    hipLaunchKernelGGL(me_big_kernel, dim3(big_grid), dim3(64), 0, sb, tabs, jobs, r.route, parity, cap, out, out_stride);
-    hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, r.stream, tabs, jobs, n, out, out_stride, 1);
+    const int bg = list_grid(n, 1, big_grid);
+    hipLaunchKernelGGL(me_big_kernel, dim3(bg), dim3(64), 0, sb, tabs, jobs, r.route, parity, cap, out, out_stride);
+    if (team_on)
+        launch_me_team(tabs, jobs, n, r.route, parity, cap, out, out_stride, r.stream);
+    hipLaunchKernelGGL(me_kernel, dim3(list_grid(n, 1, 256 * 4 * ME_WAVES)), dim3(64), 0, r.stream, tabs, jobs, n, out, out_stride, r.route, parity, cap);
     if (r.side)
     {
         (void)hipEventRecord(r.join, r.side);

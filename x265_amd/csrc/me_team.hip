@@ -1,0 +1,495 @@
+// me_team.hip -- MotionEstimate::motionEstimate for small blocks, several calls per wavefront in lockstep.
+//
+// Reference: encoder/motion.cpp:526-1164, the diamond and hexagon searches (:605-700) with the pre-tests (:551-598)
+// and the sub-pel stage (:1039-1119, workload[] :47-57) of a full-resolution reference.
+//
+// Why.  me_kernel gives a call a whole wave: a round of the search (pre-tests, a hexagon step, the square, a sub-pel
+// ring) is a pass of the 64 lanes over (candidate, 4x4 tile) items plus ~165 VALU and ~200 SALU instructions of queue,
+// arg-min and state code, and for an 8x8 block (four tiles) that bookkeeping is most of the call: 1200 VALU
+// instructions per 8x8 call, of which the arithmetic on pixels is a third.  Here a call gets a *team*
+// of L lanes, one lane per 4x4 tile of the block (L = 4: 8x8 and smaller, sixteen calls per wave; L = 16: up to
+// 16x16, four calls per wave), and the wave runs the searches of its teams in lockstep:
+//   * every lane keeps its tile of the source block in four registers for the whole call (no LDS copy of the block);
+//   * a round evaluates the teams' candidate lists one candidate per pass: lane = tile, so a pass is one tile
+//     comparison per lane, the tile sums meet in two (L = 4) or four (L = 16) DPP steps, and every lane of the team
+//     ends up with the candidate's cost -- no LDS atomics, no queue of costs, the strict-less update in visiting order
+//     (COPYn_IF_LT) is a running minimum of (cost << 4 | index);
+//   * all search state is per team and lives in vector registers (uniform inside a team), so the state code runs
+//     once per round for all teams of the wave; teams in different states take their branches one after the other.
+// Teams wait for each other once, between the integer stage and the sub-pel stage, so that the passes of a round run
+// one kind of tile arithmetic (full-pel SAD, or the filters) instead of both.
+// Results are those of me_kernel bit for bit (same candidates, same order, same ties); tests/test_gpu_parity.py and
+// the encoder captures run through this kernel whenever a list has such jobs (me_job_class, me_shared.h).
+#include <stddef.h>
+
+#include "me_shared.h"
+
+namespace x265hip {
+
+#define TQ 16 // candidates per round at most: 3 + X265_HIP_MAX_MVC pre-tests
+static_assert(3 + X265_HIP_MAX_MVC <= TQ, "the pre-test list must fit a round");
+static_assert(sizeof(x265_hip_me_job) == 80 && offsetof(x265_hip_me_job, pu_x) == 8 && offsetof(x265_hip_me_job, pu_w) == 12 &&
+                  offsetof(x265_hip_me_job, mvmin_x) == 16 && offsetof(x265_hip_me_job, qmvp_x) == 24 && offsetof(x265_hip_me_job, merange) == 28 &&
+                  offsetof(x265_hip_me_job, qp) == 30 && offsetof(x265_hip_me_job, num_mvc) == 31 && offsetof(x265_hip_me_job, mvc) == 32,
+              "team_chunk reads the job record as five 16-byte words");
+
+enum TeamState { TS_PRE, TS_DIA, TS_HEX1, TS_HEXN, TS_SQ, TS_POST_WAIT, TS_HPEL, TS_QPEL, TS_DONE };
+
+template <int L>
+struct TeamLds
+{
+    int cand[64 / L][TQ]; // candidate positions of the round, quarter-pel, (y << 16) | (x & 0xffff)
+    int cost[64 / L][TQ]; // the pre-tests' costs (the other rounds keep a running minimum)
+};
+
+__device__ __forceinline__ int pack_mv(int x, int y) { return (int)(((uint32_t)y << 16) | (uint32_t)(uint16_t)x); }
+
+// sum over the L lanes of a team; every lane gets it
+template <int L>
+__device__ __forceinline__ int team_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); // quad_perm 1,0,3,2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false); // quad_perm 2,3,0,1
+    if (L >= 8)
+        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false); // row_half_mirror
+    if (L >= 16)
+        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); // row_mirror
+    return v;
+}
+
+// The searches of one chunk of a part's list: entries chunk * G .. chunk * G + G - 1, one per team.
+template <int L>
+__device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, const DeviceTables *tabs, const x265_hip_me_job *jobs, const uint32_t *list,
+                                           uint32_t count, uint32_t chunk, x265_hip_me_result *out, int out_stride)
+{
+    constexpr int G = 64 / L;
+    const int lane = threadIdx.x & 63, team = lane / L, tl = lane % L;
+    const uint32_t e = chunk * G + team;
+    const bool has_job = e < count;
+    // a team without a job (the ragged end of a list) goes through the set-up with the chunk's first job, so that all
+    // its addresses are valid ones, never has a candidate and writes no result
+    const uint32_t id = list[has_job ? e : chunk * G];
+    const gptr_t jp = as_global((const uint8_t *)(jobs + id));
+    const uint4 h0 = ld16g(jp), h1 = ld16g(jp + 16);
+    const uint4 m0 = ld16g(jp + 32), m1 = ld16g(jp + 48), m2 = ld16g(jp + 64);
+    const int pu_x = (int)(int16_t)h0.z, pu_y = (int)h0.z >> 16;
+    const int w = (int)(h0.w & 0xff), h = (int)((h0.w >> 8) & 0xff), method = (int)((h0.w >> 16) & 0xff), subme = (int)(h0.w >> 24);
+    const int lox = (int)(int16_t)h1.x, loy = (int)h1.x >> 16, hix = (int)(int16_t)h1.y, hiy = (int)h1.y >> 16; // full-pel, inclusive
+    const int mvpx = (int)(int16_t)h1.z, mvpy = (int)h1.z >> 16;
+    const int merange = (int)(int16_t)h1.w, qp = (int)((h1.w >> 16) & 0xff), nmvc = (int)(h1.w >> 24);
+    const PlaneDesc fp = tabs->planes[(int)h0.x], rp = tabs->planes[(int)h0.y];
+    const uint16_t *const tab = tabs->costtab[qp];
+    const int stride = rp.stride;
+
+    // this lane's tile
+    const int ntx = w >> 2, nt = ntx * (h >> 2);
+    const bool has_tile = tl < nt;
+    const int tu = has_tile ? tl : 0;
+    const int ty = (int)(((float)tu + 0.5f) * __builtin_amdgcn_rcpf((float)ntx)), tx = tu - ty * ntx; // exact: tu < 16, ntx <= 16
+    uint32_t frow[4], ft[4]; // the source tile (setSourcePU, motion.cpp:110-126), by rows and by columns
+    {
+        const gptr_t f = as_global(fp.origin) + ((long)(pu_y + 4 * ty) * fp.stride + pu_x + 4 * tx);
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+            ft[y] = frow[y] = ld4g(f + y * fp.stride);
+        transpose4x4_u8(ft);
+    }
+    const uint8_t *const rbase = rp.origin + ((long)(pu_y + 4 * ty) * stride + pu_x + 4 * tx);
+
+    // workload[subme] (motion.cpp:47-57)
+    const int wsh = 4 * (subme & 7);
+    const int hpel_iters = (int)(workload_column(0) >> wsh) & 15, hpel_dirs = (int)(workload_column(1) >> wsh) & 15;
+    const int qpel_iters = (int)(workload_column(2) >> wsh) & 15, qpel_dirs = (int)(workload_column(3) >> wsh) & 15;
+    const int hsatd = (int)(workload_column(4) >> wsh) & 15;
+
+#define IN_RANGE(x, y) ((x) >= lox && (x) <= hix && (y) >= loy && (y) <= hiy)
+    // clipped quarter-pel predictor (motion.cpp:552; MV::clipped, mv.h:89-94) and its full-pel rounding (mv.h:76)
+    const int qlox = s16(lox << 2), qloy = s16(loy << 2), qhix = s16(hix << 2), qhiy = s16(hiy << 2);
+    const int pmx = max(min(mvpx, qhix), qlox), pmy = max(min(mvpy, qhiy), qloy);
+    const int fpx = s16(s16(pmx + 2) >> 2), fpy = s16(s16(pmy + 2) >> 2);
+    const bool sub = ((pmx | pmy) & 3) != 0, nz = (pmx | pmy) != 0;
+
+    // ---- the pre-tests' list (motion.cpp:551-598).  Slots are by kind, so that the passes of the round are of one
+    // kind for all teams: 0 the predictor (no mv rate), 1 its full-pel rounding (if the predictor is fractional), 2 the
+    // zero vector (if the predictor is not zero), 3 .. the candidate vectors that are neither zero nor the predictor,
+    // in list order ("m != bestpre", :584, is resolved when the costs are consumed)
+    uint32_t vmask = has_job ? (1u | (sub ? 2u : 0u) | (nz ? 4u : 0u)) : 0u; // the round's candidates, a bit per slot
+    if (tl == 0)
+    {
+        lds.cand[team][0] = pack_mv(pmx, pmy);
+        lds.cand[team][1] = pack_mv(s16(fpx << 2), s16(fpy << 2));
+        lds.cand[team][2] = 0;
+    }
+    {
+        const uint32_t mw[X265_HIP_MAX_MVC] = { m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w };
+        int slot = 3;
+#pragma unroll
+        for (int i = 0; i < X265_HIP_MAX_MVC; i++)
+            if (i < nmvc)
+            {
+                const int mx = max(min((int)(int16_t)mw[i], qhix), qlox), my = max(min((int)mw[i] >> 16, qhiy), qloy);
+                if ((mx | my) && !(mx == pmx && my == pmy))
+                {
+                    if (tl == 0)
+                        lds.cand[team][slot] = pack_mv(mx, my);
+                    if (has_job)
+                        vmask |= 1u << slot;
+                    slot++;
+                }
+            }
+    }
+
+    int st = has_job ? TS_PRE : TS_DONE;
+    int bcost = 0, bx = 0, by = 0; // best so far: full-pel during the integer stage, quarter-pel after it
+    int bprecost = 0, bp = pack_mv(pmx, pmy); // bestpre
+    int cnt = 0, dir = 0, sub_it = 0, metric = X265_HIP_SAD;
+    bool cf = false; // the round's first candidate re-measures the centre: its cost replaces bcost (motion.cpp:1082-1086, 1103-1105)
+
+    // the next round: [the centre,] centre + pat[first + i] * mul for i < count, quarter-pel after << sh (int16 wrap
+    // as in the reference's MV arithmetic); lanes of the team write the slots
+    auto ring = [&](int cx, int cy, int first, int count, int mul, int sh, bool centre) {
+        const int off = centre ? 1 : 0;
+        if (centre && tl == 0)
+            lds.cand[team][0] = pack_mv(cx, cy);
+        for (int i = tl; i < count; i += L)
+        {
+            const int p = pat[first + i];
+            lds.cand[team][off + i] = pack_mv(s16(s16(cx + pat_dx(p) * mul) << sh), s16(s16(cy + pat_dy(p) * mul) << sh));
+        }
+        vmask = (1u << (count + off)) - 1u;
+        cf = centre;
+    };
+
+    int guard = 0;
+    while (__ballot(st != TS_DONE) != 0 && ++guard < 8192)
+    {
+        wave_sync(); // the lists
+        // ---- evaluate: pass c takes candidate c of every team that has one -------------------------------------------
+        int key = 0x7fffffff; // min over the round of (cost << 4) | index: the first minimum in visiting order
+        const bool pre = st == TS_PRE;
+        for (int c = 0; c < TQ; c++)
+        {
+            if (__ballot((vmask >> c) != 0u) == 0)
+                break;
+            const bool act = ((vmask >> c) & 1u) != 0;
+            if (__ballot(act) == 0)
+                continue;
+            int v = 0, seed = 0;
+            if (act)
+            {
+                const int pos = lds.cand[team][c];
+                const int qx = (int)(int16_t)pos, qy = pos >> 16;
+                if (!(pre && c == 0)) // BitCost::mvcost (bitcost.h:45); the predictor's own test has none (:559)
+                    seed = (int)(uint16_t)(tab_at(tab, mvpx, qx) + tab_at(tab, mvpy, qy));
+                const int xf = qx & 3, yf = qy & 3;
+                const uint8_t *r = rbase + ((qy >> 2) * stride + (qx >> 2));
+                // one path per pass, the cheapest that serves all its lanes: full-pel, one-dimensional filter (a full-pel
+                // position goes through it with the tap row {0,0,0,64,...}), two-stage filter (ditto)
+                const bool anyfrac = __ballot((xf | yf) != 0) != 0, anydiag = __ballot(xf != 0 && yf != 0) != 0;
+                if (!anyfrac)
+                {
+                    uint32_t rr[4];
+#pragma unroll
+                    for (int y = 0; y < 4; y++)
+                        rr[y] = ld4g(as_global(r) + y * stride);
+                    if (metric == X265_HIP_SAD)
+                    {
+                        uint32_t a = 0;
+#pragma unroll
+                        for (int y = 0; y < 4; y++)
+                            a = __builtin_amdgcn_sad_u8(frow[y], rr[y], a);
+                        v = (int)a;
+                    }
+                    else
+                    {
+                        uint32_t pix[4][2];
+#pragma unroll
+                        for (int y = 0; y < 4; y++)
+                        {
+                            pix[y][0] = __builtin_amdgcn_perm(0, rr[y], 0x0c010c00);
+                            pix[y][1] = __builtin_amdgcn_perm(0, rr[y], 0x0c030c02);
+                        }
+                        v = tile_metric_rows(frow, pix, X265_HIP_SATD);
+                    }
+                }
+                else if (!anydiag)
+                {
+                    uint32_t pix[4][2], fs[4];
+                    ref_tile_1d(r, stride, xf, yf, pix); // a vertical position comes back transposed
+#pragma unroll
+                    for (int y = 0; y < 4; y++)
+                        fs[y] = xf == 0 ? ft[y] : frow[y];
+                    v = tile_metric_rows(fs, pix, metric);
+                }
+                else
+                {
+                    uint32_t pix[4][2];
+                    ref_tile(r, stride, xf, yf, pix, true);
+                    v = tile_metric_rows(frow, pix, metric);
+                }
+                if (!has_tile)
+                    v = 0;
+            }
+            const int cost = team_sum<L>(v) + seed;
+            if (act)
+            {
+                if (pre)
+                {
+                    if (tl == 0)
+                        lds.cost[team][c] = cost;
+                }
+                else if (c == 0 && cf)
+                    bcost = cost;
+                else
+                    key = min(key, (cost << 4) | (c - (cf ? 1 : 0)));
+            }
+        }
+        wave_sync(); // the pre-tests' costs
+
+        // ---- the teams' state code -----------------------------------------------------------------------------------
+        const bool better = (key >> 4) < bcost; // the round's first minimum beats the centre (strict)
+        const int kk = key & 15;
+        if (st == TS_PRE)
+        {
+            bprecost = lds.cost[team][0];
+            bx = fpx;
+            by = fpy;
+            bcost = bprecost;
+            if (sub)
+                bcost = lds.cost[team][1]; // full-pel start re-measured with its mv rate (:562-567)
+            if (nz)
+            {
+                const int cz = lds.cost[team][2]; // zero vector (:570-578)
+                if (cz < bcost)
+                {
+                    bcost = cz;
+                    bx = by = 0;
+                }
+            }
+            const int nslot = 32 - __clz((int)vmask);
+            for (int k = 3; k < nslot; k++)
+            {
+                const int pos = lds.cand[team][k];
+                if (pos == bp)
+                    continue;
+                const int cc = lds.cost[team][k];
+                if (cc < bprecost) // candidates compete with bprecost only (:592)
+                {
+                    bprecost = cc;
+                    bp = pos;
+                }
+            }
+            if (method == X265_HIP_DIA)
+            {
+                cnt = merange;
+                ring(bx, by, PAT_SQ + 1, 4, 1, 2, false); // (0,-1) (0,1) (-1,0) (1,0)
+                st = TS_DIA;
+            }
+            else
+            {
+                ring(bx, by, PAT_HEX + 1, 6, 1, 2, false); // hex2[1..6]: directions 0..5
+                st = TS_HEX1;
+            }
+        }
+        else if (st == TS_DIA)
+        {
+            // radius-1 diamond, the centre wins ties (motion.cpp:605-626)
+            bool go_on = false;
+            if (better)
+            {
+                bcost = key >> 4;
+                const int p = pat[PAT_SQ + 1 + kk];
+                bx = s16(bx + pat_dx(p));
+                by = s16(by + pat_dy(p));
+                go_on = --cnt != 0 && IN_RANGE(bx, by);
+            }
+            if (go_on)
+                ring(bx, by, PAT_SQ + 1, 4, 1, 2, false);
+            else
+            {
+                st = TS_POST_WAIT;
+                vmask = 0;
+            }
+        }
+        else if (st == TS_HEX1 || st == TS_HEXN)
+        {
+            // radius-2 hexagon, then half hexagons in the direction of the move (motion.cpp:628-683)
+            bool go_on = false;
+            if (better)
+            {
+                bcost = key >> 4;
+                if (st == TS_HEX1)
+                {
+                    dir = kk;
+                    cnt = (merange >> 1) - 1;
+                }
+                else
+                {
+                    dir += kk - 1;
+                    dir = dir < 0 ? dir + 6 : (dir >= 6 ? dir - 6 : dir); // mod6m1
+                    cnt--;
+                }
+                const int p = pat[PAT_HEX + dir + 1];
+                bx = s16(bx + pat_dx(p));
+                by = s16(by + pat_dy(p));
+                go_on = cnt > 0 && IN_RANGE(bx, by);
+            }
+            if (go_on)
+            {
+                ring(bx, by, PAT_HEX + dir, 3, 1, 2, false);
+                st = TS_HEXN;
+            }
+            else
+            {
+                ring(bx, by, PAT_SQ + 1, 8, 1, 2, false); // square refine (:687-698)
+                st = TS_SQ;
+            }
+        }
+        else if (st == TS_SQ)
+        {
+            if (better)
+            {
+                bcost = key >> 4;
+                const int p = pat[PAT_SQ + 1 + kk];
+                bx = s16(bx + pat_dx(p));
+                by = s16(by + pat_dy(p));
+            }
+            st = TS_POST_WAIT;
+            vmask = 0;
+        }
+        else if (st == TS_HPEL || st == TS_QPEL)
+        {
+            // a sub-pel ring around a fixed centre, one move at its end (motion.cpp:1090-1118)
+            if (better)
+            {
+                bcost = key >> 4;
+                const int p = pat[PAT_SQ + 1 + kk], mul = st == TS_HPEL ? 2 : 1;
+                bx = s16(bx + pat_dx(p) * mul);
+                by = s16(by + pat_dy(p) * mul);
+            }
+            sub_it++;
+            if (st == TS_HPEL)
+            {
+                if (sub_it < hpel_iters)
+                    ring(bx, by, PAT_SQ + 1, hpel_dirs, 2, 0, false);
+                else
+                {
+                    // half-pel used SAD: the winner is re-measured with SATD in front of the quarter-pel ring (:1103-1105),
+                    // whose positions do not depend on that cost: one round
+                    sub_it = 0;
+                    metric = X265_HIP_SATD;
+                    if (!hsatd || qpel_iters > 0)
+                    {
+                        ring(bx, by, PAT_SQ + 1, qpel_iters > 0 ? qpel_dirs : 0, 1, 0, !hsatd);
+                        st = TS_QPEL;
+                    }
+                    else
+                    {
+                        st = TS_DONE;
+                        vmask = 0;
+                    }
+                }
+            }
+            else if (sub_it < qpel_iters)
+                ring(bx, by, PAT_SQ + 1, qpel_dirs, 1, 0, false);
+            else
+            {
+                st = TS_DONE;
+                vmask = 0;
+            }
+        }
+        // after the integer stage (motion.cpp:1039-1088), once every team of the wave is there
+        if (__ballot(st < TS_POST_WAIT) == 0 && st == TS_POST_WAIT)
+        {
+            if (bprecost < bcost) // pre-test winner bypasses the integer result
+            {
+                bx = (int)(int16_t)bp;
+                by = bp >> 16;
+                bcost = bprecost;
+            }
+            else
+            {
+                bx = s16(bx << 2);
+                by = s16(by << 2);
+            }
+            if (!bcost)
+            {
+                bcost = mvcost_q(tab, mvpx, mvpy, bx, by); // zero residual: rate only (:1049-1054)
+                st = TS_DONE;
+            }
+            else
+            {
+                sub_it = 0;
+                metric = hsatd ? X265_HIP_SATD : X265_HIP_SAD;
+                // with hpel_satd the SATD re-measure of the centre heads the first ring (:1082-1086)
+                ring(bx, by, PAT_SQ + 1, hpel_dirs, 2, 0, hsatd != 0);
+                st = TS_HPEL;
+            }
+        }
+    }
+#undef IN_RANGE
+    if (has_job && tl == 0)
+    {
+        x265_hip_me_result *o = (x265_hip_me_result *)((char *)out + (size_t)id * out_stride);
+        o->cost = bcost;
+        o->mvx = (int16_t)bx;
+        o->mvy = (int16_t)by;
+    }
+    wave_sync(); // the next chunk rewrites the lists
+}
+
+#ifndef ME_TEAM_WAVES
+#define ME_TEAM_WAVES 4
+#endif
+
+template <int L>
+__device__ __forceinline__ void team_lists(TeamLds<L> &lds, const int *pat, const DeviceTables *tabs, const x265_hip_me_job *jobs, uint32_t *route,
+                                           int parity, int cap, int cls, x265_hip_me_result *out, int out_stride)
+{
+    constexpr int G = 64 / L;
+    const int p = blockIdx.x & (ME_PARTS - 1), waves = gridDim.x / ME_PARTS;
+    const uint32_t count = min(*route_append(route, parity, cls, p), (uint32_t)cap);
+    const uint32_t nchunk = (count + G - 1) / G;
+    const uint32_t *const list = route_list(route, cap, cls, p);
+    uint32_t k = blockIdx.x / ME_PARTS;
+    while (k < nchunk)
+    {
+        team_chunk<L>(lds, pat, tabs, jobs, list, count, k, out, out_stride);
+        k = 0;
+        if ((threadIdx.x & 63) == 0)
+            k = (uint32_t)waves + atomicAdd(route_handout(route, parity, cls, p), 1u);
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    }
+}
+
+// gridDim.x is a multiple of ME_PARTS; every wave works through its part of the MC_T16 list, then of the MC_T4 list
+// (one launch for both: the second list fills the end of the first), and leaves when both hand-out counters have
+// passed the ends of the lists
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_TEAM_WAVES))) void me_team_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs,
+                                                                                                    uint32_t *route, int parity, int cap,
+                                                                                                    x265_hip_me_result *out, int out_stride)
+{
+    __shared__ TeamLds<16> lds16;
+    __shared__ TeamLds<4> lds4;
+    __shared__ int pat[PAT_N];
+    if (threadIdx.x < PAT_N)
+        pat[threadIdx.x] = k_pat[threadIdx.x];
+    wave_sync();
+    team_lists<16>(lds16, pat, tabs, jobs, route, parity, cap, MC_T16, out, out_stride);
+    team_lists<4>(lds4, pat, tabs, jobs, route, parity, cap, MC_T4, out, out_stride);
+}
+
+void launch_me_team(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, uint32_t *route, int parity, int cap, x265_hip_me_result *out,
+                    int out_stride, hipStream_t st)
+{
+    static const int resident = [] {
+        const char *e = getenv("X265_HIP_ME_TEAM_GRID"); // experiments; a multiple of ME_PARTS
+        const int g = e ? atoi(e) : 0;
+        return g >= ME_PARTS ? g / ME_PARTS * ME_PARTS : 256 * 4 * ME_TEAM_WAVES;
+    }();
+    const int want = (n + ME_PARTS * 4 - 1) / (ME_PARTS * 4), most = resident / ME_PARTS;
+    const int grid = ME_PARTS * (want < 1 ? 1 : want > most ? most : want);
+    hipLaunchKernelGGL(me_team_kernel, dim3(grid), dim3(64), 0, st, tabs, jobs, route, parity, cap, out, out_stride);
+}
+
+} // namespace x265hip
