@@ -80,6 +80,55 @@ __device__ __forceinline__ uint4 ld16g(gptr_t p)
     return make_uint4(w.x, w.y, w.z, w.w);
 }
 
+// The same loads from LDS (a window of a reference plane staged there), for the tile routines below, which take the
+// pointer type as a template parameter.  The LDS of gfx950 does accept ds_read_b32 / b96 at any byte address
+// (tools/ubench/lds_unaligned.hip checks it on the box), but slowly: with the rows of me_team_kernel's windows read that
+// way SQ_LDS_UNALIGNED_STALL was 90 % of the LDS's active cycles and the kernel LDS-bound (profiles/r03_team_pmc.txt).
+// So a read at byte address a fetches the aligned dwords around it and shifts (v_alignbyte_b32).
+struct ldsa_t
+{
+    uint32_t a; // byte address in LDS
+    __device__ __forceinline__ ldsa_t() : a(0) {}
+    __device__ __forceinline__ explicit ldsa_t(const uint8_t *generic)
+        : a((uint32_t)(size_t)(const __attribute__((address_space(3))) uint8_t *)generic)
+    {
+    }
+    __device__ __forceinline__ ldsa_t operator+(int o) const
+    {
+        ldsa_t r;
+        r.a = a + (uint32_t)o;
+        return r;
+    }
+    __device__ __forceinline__ ldsa_t operator-(int o) const
+    {
+        ldsa_t r;
+        r.a = a - (uint32_t)o;
+        return r;
+    }
+    __device__ __forceinline__ ldsa_t &operator+=(int o)
+    {
+        a += (uint32_t)o;
+        return *this;
+    }
+};
+__device__ __forceinline__ uint32_t lds_dword(uint32_t aligned_addr)
+{
+    return *(const __attribute__((address_space(3))) uint32_t *)aligned_addr;
+}
+__device__ __forceinline__ uint32_t ld4g(ldsa_t p)
+{
+    const uint32_t al = p.a & ~3u;
+    return __builtin_amdgcn_alignbyte(lds_dword(al + 4), lds_dword(al), p.a & 3u);
+}
+__device__ __forceinline__ void ld12g(ldsa_t p, uint32_t &d0, uint32_t &d1, uint32_t &d2)
+{
+    const uint32_t al = p.a & ~3u, sh = p.a & 3u;
+    const uint32_t w0 = lds_dword(al), w1 = lds_dword(al + 4), w2 = lds_dword(al + 8), w3 = lds_dword(al + 12);
+    d0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    d1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    d2 = __builtin_amdgcn_alignbyte(w3, w2, sh);
+}
+
 __device__ __forceinline__ int byte_of(uint32_t v, int i)
 {
     return (int)((v >> (8 * i)) & 0xffu);
@@ -210,13 +259,13 @@ __device__ __forceinline__ uint32_t pack_s16(int lo, int hi) { return __builtin_
 // AH > 0: the rows of the horizontal and the diagonal path are fetched AH ahead of their use (left alone the compiler,
 // which orders for few registers, waits for every row load right behind it: R or R + 7 memory round trips in a row).
 // For kernels with registers to spare (me_big_kernel); in me_kernel and cost_kernel it cost more in spills than it gave.
-template <int NT, bool SH = false, int AH = 0>
+template <int NT, bool SH = false, int AH = 0, typename PT = gptr_t>
 __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf, int yf, uint32_t P[4 * NT][2],
                                           bool diag = false)
 {
     constexpr int R = 4 * NT;
     const uint32_t bias = 0x80808080u;
-    const gptr_t r_ = as_global(ref);
+    const PT r_ = (PT)ref;
     if ((xf | yf) == 0)
     {
 #pragma unroll
@@ -237,7 +286,7 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
     {
         // luma_hpp: dst = clip((sum_k src[x-3+k]*c[k] + 32) >> 6)
         const uint32_t tlo = k_taps_s8[xf][0], thi = k_taps_s8[xf][1];
-        gptr_t p = r_ - 3;
+        PT p = r_ - 3;
         uint32_t ah[AH ? AH : 1][3];
         if (AH)
 #pragma unroll
@@ -288,7 +337,7 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
         constexpr int NB = NT + 2;
         const uint32_t tlo = k_taps_s8[yf][0], thi = k_taps_s8[yf][1];
         uint32_t c[4][NB];
-        gptr_t p = r_ - 3 * stride;
+        PT p = r_ - 3 * stride;
 #pragma unroll
         for (int b = 0; b < NB; b++)
         {
@@ -344,7 +393,7 @@ __device__ __forceinline__ void ref_strip(const uint8_t *ref, int stride, int xf
         const uint32_t tlo = k_taps_s8[xf][0], thi = k_taps_s8[xf][1];
         const uint4 ve = *(const uint4 *)&k_vtaps_s16[yf][0], vo = *(const uint4 *)&k_vtaps_s16[yf][4];
         const uint32_t vo4 = k_vtaps_s16[yf][8];
-        gptr_t p = r_ - 3 * stride - 3;
+        PT p = r_ - 3 * stride - 3;
         constexpr int seed = SH ? 0 : 2048 + (8192 << 6);
         uint32_t q[NP][4];
         constexpr int ROWS = R + 7, A = AH ? AH : 1;
@@ -457,17 +506,18 @@ __device__ __forceinline__ void transpose4x4_u8(uint32_t d[4])
 // on the transposed rows and comes back transposed (P[x] = column x of the prediction); SAD and the 4x4 Hadamard
 // SATD are invariant under transposing both operands, so the caller transposes its source tile for those lanes
 // (xf == 0) and compares as usual.
+template <typename PT = gptr_t>
 __device__ __forceinline__ void ref_tile_1d(const uint8_t *ref, int stride, int xf, int yf, uint32_t P[4][2])
 {
     const uint32_t bias = 0x80808080u;
     const bool vert = xf == 0;
     const int fr = vert ? yf : xf;
     const uint32_t tlo = k_taps_s8[fr][0], thi = k_taps_s8[fr][1];
-    const gptr_t r_ = as_global(ref);
+    const PT r_ = (PT)ref;
     uint32_t c[4][3];
     if (vert)
     {
-        gptr_t p = r_ - 3 * stride;
+        PT p = r_ - 3 * stride;
 #pragma unroll
         for (int b = 0; b < 3; b++)
         {
@@ -490,7 +540,7 @@ __device__ __forceinline__ void ref_tile_1d(const uint8_t *ref, int stride, int 
     }
     else
     {
-        gptr_t p = r_ - 3;
+        PT p = r_ - 3;
 #pragma unroll
         for (int y = 0; y < 4; y++)
         {

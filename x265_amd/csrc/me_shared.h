@@ -50,9 +50,9 @@ __device__ __forceinline__ constexpr uint32_t workload_column(int c)
 // A motionEstimate launch splits its job list by kind (me_route_kernel), and each kind has a kernel of its own:
 //   MC_BIG   blocks of at least ME_BIG_TILES 4x4 tiles whose width is a multiple of 16, full-resolution reference:
 //            me_big_kernel (one wave per call, strips of 16 x 4 pixels / stacked tiles, 4 waves per SIMD)
-//   MC_T4    diamond / hexagon searches of blocks of at most 4 tiles (8x8, 16x4, 4x16 ...), full-resolution reference:
-//            me_team_kernel, sixteen calls per wave in lockstep (a team of 4 lanes per call, one lane per tile)
-//   MC_T16   the same for blocks of 5 .. 16 tiles (16x16, 16x8, 8x16, 12x16 ...): four calls per wave, 16 lanes each
+//   MC_T4    diamond / hexagon searches of blocks up to 8x8, full-resolution reference: me_team_kernel, sixteen calls
+//            per wave in lockstep (a team of 4 lanes per call, one lane per 4x4 tile)
+//   MC_T16   the same for the other blocks up to 16x16 (16x16, 16x8, 8x16, 12x16, 16x4 ...): four calls per wave, 16 lanes each
 //   MC_REST  everything else (UMH / STAR / FULL, Lowres references, 32x32 ...): me_rest_kernel, one wave per call
 // A list per kind is kept in ME_PARTS parts (one counter for a whole grid would serialise: an atomic on one address
 // takes ~12 ns): the jobs of one wave of me_route_kernel (64 consecutive jobs) go to one part, consecutive waves to
@@ -94,9 +94,8 @@ __host__ __device__ inline int me_job_class(int w, int h, int method)
         return MC_REST;
     if (big_block(w, h))
         return MC_BIG;
-    const int nt = (w >> 2) * (h >> 2);
-    if (method <= X265_HIP_HEX && nt <= 16)
-        return nt <= 4 ? MC_T4 : MC_T16;
+    if (method <= X265_HIP_HEX && w <= 16 && h <= 16 && (w >= 8 || h <= 8)) // (a window row of MC_T16 is 32 samples: not for 4x16)
+        return w <= 8 && h <= 8 ? MC_T4 : MC_T16;
     return MC_REST;
 }
 

@@ -18,6 +18,15 @@
 //     once per round for all teams of the wave; teams in different states take their branches one after the other.
 // Teams wait for each other once, between the integer stage and the sub-pel stage, so that the passes of a round run
 // one kind of tile arithmetic (full-pel SAD, or the filters) instead of both.
+//   * Reference pixels come from a window in LDS.  With this little arithmetic per load the first version (every
+//     candidate's rows fetched from the plane) was bound by the vector memory path: one 64-byte line per clock and CU,
+//     and a 4x4 tile row is a line of its own -- 11 k line look-ups per sixteen 8x8 calls, 70 us per chunk where the
+//     VALU work is 10 us (profiles/r03_team_pmc.txt).  Now a team keeps the (w + 16) x (h + 16) samples around the
+//     centre of its search in LDS (24 x 24 bytes for an 8x8 block, 32 x 32 for 16x16), loaded with 12- / 16-byte loads,
+//     two per row; the candidates of the hexagon, square and sub-pel rounds -- within +-2 samples of a centre that moves
+//     by at most 2 per round -- read their tile rows from there (aligned dwords + v_alignbyte: unaligned LDS reads
+//     work but stall, me_device.h), and the window is loaded again only when a round's candidates (with the filters'
+//     margins) no longer fit it.  The pre-tests' candidates lie anywhere and are read from the plane.
 // Results are those of me_kernel bit for bit (same candidates, same order, same ties); tests/test_gpu_parity.py and
 // the encoder captures run through this kernel whenever a list has such jobs (me_job_class, me_shared.h).
 #include <stddef.h>
@@ -35,11 +44,27 @@ static_assert(sizeof(x265_hip_me_job) == 80 && offsetof(x265_hip_me_job, pu_x) =
 
 enum TeamState { TS_PRE, TS_DIA, TS_HEX1, TS_HEXN, TS_SQ, TS_POST_WAIT, TS_HPEL, TS_QPEL, TS_DONE };
 
+#define TEAM_RY 6 // rows of the window above and below the block at its centre position
+// L lanes per team; the window of a team is ROWS rows of PITCH bytes, loaded in units of UNIT bytes, two per row
 template <int L>
-struct TeamLds
+struct TeamGeo;
+template <>
+struct TeamGeo<4> // blocks up to 8x8
+{
+    enum { PITCH = 24, ROWS = 8 + 2 * TEAM_RY, UNIT = 12, MAXW = 8 };
+};
+template <>
+struct TeamGeo<16> // blocks up to 16x16
+{
+    enum { PITCH = 32, ROWS = 16 + 2 * TEAM_RY, UNIT = 16, MAXW = 16 };
+};
+template <int L>
+struct __attribute__((aligned(16))) TeamLds
 {
     int cand[64 / L][TQ]; // candidate positions of the round, quarter-pel, (y << 16) | (x & 0xffff)
     int cost[64 / L][TQ]; // the pre-tests' costs (the other rounds keep a running minimum)
+    uint8_t win[64 / L][TeamGeo<L>::PITCH * TeamGeo<L>::ROWS];
+    uint8_t pad[16]; // a 12-byte row read at the window's last bytes runs into this
 };
 
 __device__ __forceinline__ int pack_mv(int x, int y) { return (int)(((uint32_t)y << 16) | (uint32_t)(uint16_t)x); }
@@ -57,12 +82,57 @@ __device__ __forceinline__ int team_sum(int v)
     return v;
 }
 
+// SAD or SATD of this lane's source tile against the reference tile at `r` (rows `stride` apart; PT: plane memory or
+// the LDS window, whose pitch is a constant) at fraction (xf, yf).  One path per pass of the wave, the cheapest that
+// serves all its lanes: full-pel, one-dimensional filter (a full-pel position goes through it with the tap row
+// {0,0,0,64,...}), two-stage filter (ditto).  frow / ft: the source tile by rows / by columns.
+template <typename PT, int AH>
+__device__ __forceinline__ int team_tile(const uint8_t *r, int stride, int xf, int yf, const uint32_t frow[4], const uint32_t ft[4], int metric)
+{
+    const bool anyfrac = __ballot((xf | yf) != 0) != 0, anydiag = __ballot(xf != 0 && yf != 0) != 0;
+    if (!anyfrac)
+    {
+        uint32_t rr[4];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+            rr[y] = ld4g((PT)r + y * stride);
+        if (metric == X265_HIP_SAD)
+        {
+            uint32_t a = 0;
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+                a = __builtin_amdgcn_sad_u8(frow[y], rr[y], a);
+            return (int)a;
+        }
+        uint32_t pix[4][2];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            pix[y][0] = __builtin_amdgcn_perm(0, rr[y], 0x0c010c00);
+            pix[y][1] = __builtin_amdgcn_perm(0, rr[y], 0x0c030c02);
+        }
+        return tile_metric_rows(frow, pix, X265_HIP_SATD);
+    }
+    if (!anydiag)
+    {
+        uint32_t pix[4][2], fs[4];
+        ref_tile_1d<PT>(r, stride, xf, yf, pix); // a vertical position comes back transposed
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+            fs[y] = xf == 0 ? ft[y] : frow[y];
+        return tile_metric_rows(fs, pix, metric);
+    }
+    uint32_t pix[4][2];
+    ref_strip<1, false, AH, PT>(r, stride, xf, yf, pix, true);
+    return tile_metric_rows(frow, pix, metric);
+}
+
 // The searches of one chunk of a part's list: entries chunk * G .. chunk * G + G - 1, one per team.
 template <int L>
 __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, const DeviceTables *tabs, const x265_hip_me_job *jobs, const uint32_t *list,
                                            uint32_t count, uint32_t chunk, x265_hip_me_result *out, int out_stride)
 {
-    constexpr int G = 64 / L;
+    constexpr int G = 64 / L, PITCH = TeamGeo<L>::PITCH, UNIT = TeamGeo<L>::UNIT;
     const int lane = threadIdx.x & 63, team = lane / L, tl = lane % L;
     const uint32_t e = chunk * G + team;
     const bool has_job = e < count;
@@ -94,7 +164,9 @@ __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, cons
             ft[y] = frow[y] = ld4g(f + y * fp.stride);
         transpose4x4_u8(ft);
     }
-    const uint8_t *const rbase = rp.origin + ((long)(pu_y + 4 * ty) * stride + pu_x + 4 * tx);
+    const uint8_t *const pbase = rp.origin + ((long)pu_y * stride + pu_x); // the block's position in the reference plane
+    const int toff = 4 * ty * stride + 4 * tx;                             // this lane's tile inside the block, plane
+    const int ltoff = 4 * ty * PITCH + 4 * tx;                             // and window
 
     // workload[subme] (motion.cpp:47-57)
     const int wsh = 4 * (subme & 7);
@@ -108,6 +180,72 @@ __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, cons
     const int pmx = max(min(mvpx, qhix), qlox), pmy = max(min(mvpy, qhiy), qloy);
     const int fpx = s16(s16(pmx + 2) >> 2), fpy = s16(s16(pmy + 2) >> 2);
     const bool sub = ((pmx | pmy) & 3) != 0, nz = (pmx | pmy) != 0;
+
+    // ---- the window.  It holds the samples [wx, wx + PITCH) x [wy, wy + h + 2 TEAM_RY) relative to the block's
+    // position; loads stay inside the samples the job may touch at all (what the host checks of a job, check_job in
+    // api.hip: the search range and the zero vector, plus the steps the search may take outside them, plus the filters'
+    // margins): a window at the edge of that region is shifted sideways into it and repeats its outermost rows instead
+    // of reading outside the plane's buffer; no candidate of the search uses the repeated rows.
+    const int wrows = h + 2 * TEAM_RY, rx = (PITCH - w) >> 1;
+    int wx = 0, wy = 0;
+    bool wok = false; // the window holds something
+    const int over = (method == X265_HIP_DIA ? 1 : 3) + (int)((0x22122111u >> wsh) & 15); // k_int_over + (k_qsteps + 3) / 4
+    const int gx0 = min(lox, 0) - over - 6, gx1 = max(hix, 0) + over + w + 16 - PITCH; // first / last start of a window row
+    const int gy0 = min(loy, 0) - over - 3, gy1 = max(hiy, 0) + over + h + 3;          // first / last row
+    auto load_window = [&](int ccx, int ccy, bool mine) {
+        // units u = 2 row + half, dealt to the lanes of the team; a lane's loads are in flight together, half of them
+        // at a time (registers)
+        constexpr int NU = (2 * TeamGeo<L>::ROWS + L - 1) / L, NH = (NU + 1) / 2;
+        // (the region is at least PITCH wide for the blocks of a class: w + 26 samples, me_job_class)
+        const int nwx = min(max(ccx - rx, gx0), gx1), nwy = ccy - TEAM_RY;
+#pragma unroll
+        for (int k0 = 0; k0 < NU; k0 += NH)
+        {
+            uint32_t v[NH][4];
+#pragma unroll
+            for (int k = 0; k < NH; k++)
+            {
+                const int u = tl + (k0 + k) * L, row = u >> 1, half = u & 1;
+                const int ax = nwx + half * UNIT, ay = min(max(nwy + row, gy0), gy1);
+                // every lane loads (a lane without a unit, or of a team that keeps its window, from a valid address
+                // all the same): behind a branch per unit the loads waited for each other
+                const gptr_t src = as_global(pbase) + (ay * stride + ax);
+                if (UNIT == 12)
+                {
+                    ld12g(src, v[k][0], v[k][1], v[k][2]);
+                    v[k][3] = 0;
+                }
+                else
+                {
+                    const uint4 q = ld16g(src);
+                    v[k][0] = q.x, v[k][1] = q.y, v[k][2] = q.z, v[k][3] = q.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NH; k++)
+            {
+                const int u = tl + (k0 + k) * L, row = u >> 1, half = u & 1;
+                if (mine && k0 + k < NU && row < wrows)
+                {
+                    __attribute__((address_space(3))) uint32_t *dst = (__attribute__((address_space(3))) uint32_t *)&lds.win[team][row * PITCH + half * UNIT];
+#pragma unroll
+                    for (int i = 0; i < UNIT / 4; i++)
+                        dst[i] = v[k][i];
+                }
+            }
+        }
+        if (mine)
+        {
+            wx = nwx;
+            wy = nwy;
+            wok = true;
+        }
+    };
+    // whether the candidates of a ring around (ccx, ccy) (full-pel) with integer parts within `reach` of it and the
+    // margins (ml, mr) of their footprints lie in the window
+    auto fits = [&](int ccx, int ccy, int reach, int ml, int mr) {
+        return wok && ccx - reach - ml >= wx && ccx + reach + w + mr <= wx + PITCH && ccy - reach - ml >= wy && ccy + reach + h + mr <= wy + wrows;
+    };
 
     // ---- the pre-tests' list (motion.cpp:551-598).  Slots are by kind, so that the passes of the round are of one
     // kind for all teams: 0 the predictor (no mv rate), 1 its full-pel rounding (if the predictor is fractional), 2 the
@@ -144,6 +282,8 @@ __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, cons
     int bprecost = 0, bp = pack_mv(pmx, pmy); // bestpre
     int cnt = 0, dir = 0, sub_it = 0, metric = X265_HIP_SAD;
     bool cf = false; // the round's first candidate re-measures the centre: its cost replaces bcost (motion.cpp:1082-1086, 1103-1105)
+    bool need_win = false; // the next round's candidates do not fit the window: load it around (ncx, ncy)
+    int ncx = 0, ncy = 0;
 
     // the next round: [the centre,] centre + pat[first + i] * mul for i < count, quarter-pel after << sh (int16 wrap
     // as in the reference's MV arithmetic); lanes of the team write the slots
@@ -158,15 +298,66 @@ __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, cons
         }
         vmask = (1u << (count + off)) - 1u;
         cf = centre;
+        // integer rings: points within 2 of the centre, no margins; sub-pel rings: integer parts within 1 of the
+        // centre's, the filters' 3 samples before and 4 behind (a 12-byte row read takes one more)
+        ncx = sh ? cx : cx >> 2;
+        ncy = sh ? cy : cy >> 2;
+        need_win = sh ? !fits(ncx, ncy, 2, 0, 0) : !fits(ncx, ncy, 1, 3, 4);
     };
 
     int guard = 0;
     while (__ballot(st != TS_DONE) != 0 && ++guard < 8192)
     {
-        wave_sync(); // the lists
+        if (__ballot(need_win && vmask != 0u) != 0)
+            load_window(ncx, ncy, need_win && vmask != 0u);
+        need_win = false;
+        wave_sync(); // the lists, the windows
         // ---- evaluate: pass c takes candidate c of every team that has one -------------------------------------------
         int key = 0x7fffffff; // min over the round of (cost << 4) | index: the first minimum in visiting order
         const bool pre = st == TS_PRE;
+        typedef const __attribute__((address_space(3))) uint8_t *lptr_t;
+        const lptr_t lbase = (lptr_t)&lds.win[team][0] + (ltoff - wy * PITCH - wx); // this lane's tile at the zero vector, were it in the window
+        if (__ballot(vmask != 0u && !(st >= TS_DIA && st <= TS_SQ)) == 0)
+        {
+            // A round of the integer stage for every team that has candidates: full-pel positions, SAD, out of the
+            // windows.  Straight-line code over groups of four slots; slots without a candidate read the window's first
+            // bytes and are not used.
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+            {
+                if (g && __ballot((vmask >> 4) != 0u) == 0)
+                    break;
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                const i32x4 pv = *(const i32x4 *)&lds.cand[team][4 * g];
+                const int pos[4] = { pv.x, pv.y, pv.z, pv.w };
+                uint32_t rr[4][4];
+                int ta[4], tb[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    const bool act = ((vmask >> (4 * g + j)) & 1u) != 0;
+                    const int qx = (int)(int16_t)pos[j], qy = pos[j] >> 16;
+                    const ldsa_t r((const uint8_t *)(act ? lbase + ((qy >> 2) * PITCH + (qx >> 2)) : (lptr_t)&lds.win[team][0]));
+                    ta[j] = tab_at(tab, mvpx, qx);
+                    tb[j] = tab_at(tab, mvpy, qy);
+#pragma unroll
+                    for (int y = 0; y < 4; y++)
+                        rr[j][y] = ld4g(r + y * PITCH);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    uint32_t a = 0;
+#pragma unroll
+                    for (int y = 0; y < 4; y++)
+                        a = __builtin_amdgcn_sad_u8(frow[y], rr[j][y], a);
+                    const int cost = team_sum<L>(has_tile ? (int)a : 0) + (int)(uint16_t)(ta[j] + tb[j]);
+                    if ((vmask >> (4 * g + j)) & 1u)
+                        key = min(key, (cost << 4) | (4 * g + j));
+                }
+            }
+        }
+        else
         for (int c = 0; c < TQ; c++)
         {
             if (__ballot((vmask >> c) != 0u) == 0)
@@ -179,56 +370,16 @@ __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, cons
             {
                 const int pos = lds.cand[team][c];
                 const int qx = (int)(int16_t)pos, qy = pos >> 16;
-                if (!(pre && c == 0)) // BitCost::mvcost (bitcost.h:45); the predictor's own test has none (:559)
-                    seed = (int)(uint16_t)(tab_at(tab, mvpx, qx) + tab_at(tab, mvpy, qy));
-                const int xf = qx & 3, yf = qy & 3;
-                const uint8_t *r = rbase + ((qy >> 2) * stride + (qx >> 2));
-                // one path per pass, the cheapest that serves all its lanes: full-pel, one-dimensional filter (a full-pel
-                // position goes through it with the tap row {0,0,0,64,...}), two-stage filter (ditto)
-                const bool anyfrac = __ballot((xf | yf) != 0) != 0, anydiag = __ballot(xf != 0 && yf != 0) != 0;
-                if (!anyfrac)
-                {
-                    uint32_t rr[4];
-#pragma unroll
-                    for (int y = 0; y < 4; y++)
-                        rr[y] = ld4g(as_global(r) + y * stride);
-                    if (metric == X265_HIP_SAD)
-                    {
-                        uint32_t a = 0;
-#pragma unroll
-                        for (int y = 0; y < 4; y++)
-                            a = __builtin_amdgcn_sad_u8(frow[y], rr[y], a);
-                        v = (int)a;
-                    }
-                    else
-                    {
-                        uint32_t pix[4][2];
-#pragma unroll
-                        for (int y = 0; y < 4; y++)
-                        {
-                            pix[y][0] = __builtin_amdgcn_perm(0, rr[y], 0x0c010c00);
-                            pix[y][1] = __builtin_amdgcn_perm(0, rr[y], 0x0c030c02);
-                        }
-                        v = tile_metric_rows(frow, pix, X265_HIP_SATD);
-                    }
-                }
-                else if (!anydiag)
-                {
-                    uint32_t pix[4][2], fs[4];
-                    ref_tile_1d(r, stride, xf, yf, pix); // a vertical position comes back transposed
-#pragma unroll
-                    for (int y = 0; y < 4; y++)
-                        fs[y] = xf == 0 ? ft[y] : frow[y];
-                    v = tile_metric_rows(fs, pix, metric);
-                }
+                // BitCost::mvcost (bitcost.h:45); the predictor's own test has none (:559).  Loaded whether used or not:
+                // behind a branch the loads had a wait of their own in front of the pixel loads
+                const int ta = tab_at(tab, mvpx, qx), tb = tab_at(tab, mvpy, qy);
+                if (__ballot(pre) != 0) // the pre-tests (all teams of a wave are there together): from the plane
+                    v = team_tile<gptr_t, 11>(pbase + (toff + (qy >> 2) * stride + (qx >> 2)), stride, qx & 3, qy & 3, frow, ft, metric);
                 else
-                {
-                    uint32_t pix[4][2];
-                    ref_tile(r, stride, xf, yf, pix, true);
-                    v = tile_metric_rows(frow, pix, metric);
-                }
+                    v = team_tile<ldsa_t, 0>((const uint8_t *)(lbase + ((qy >> 2) * PITCH + (qx >> 2))), PITCH, qx & 3, qy & 3, frow, ft, metric);
                 if (!has_tile)
                     v = 0;
+                seed = (pre && c == 0) ? 0 : (int)(uint16_t)(ta + tb);
             }
             const int cost = team_sum<L>(v) + seed;
             if (act)
@@ -439,7 +590,7 @@ __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, cons
 }
 
 #ifndef ME_TEAM_WAVES
-#define ME_TEAM_WAVES 4
+#define ME_TEAM_WAVES 3
 #endif
 
 template <int L>
@@ -469,14 +620,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_TEAM_WAVE
                                                                                                     uint32_t *route, int parity, int cap,
                                                                                                     x265_hip_me_result *out, int out_stride)
 {
-    __shared__ TeamLds<16> lds16;
-    __shared__ TeamLds<4> lds4;
+    __shared__ union TeamLdsBoth
+    {
+        TeamLds<16> t16;
+        TeamLds<4> t4;
+    } lds; // one list after the other
     __shared__ int pat[PAT_N];
     if (threadIdx.x < PAT_N)
         pat[threadIdx.x] = k_pat[threadIdx.x];
     wave_sync();
-    team_lists<16>(lds16, pat, tabs, jobs, route, parity, cap, MC_T16, out, out_stride);
-    team_lists<4>(lds4, pat, tabs, jobs, route, parity, cap, MC_T4, out, out_stride);
+    team_lists<16>(lds.t16, pat, tabs, jobs, route, parity, cap, MC_T16, out, out_stride);
+    team_lists<4>(lds.t4, pat, tabs, jobs, route, parity, cap, MC_T4, out, out_stride);
 }
 
 void launch_me_team(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, uint32_t *route, int parity, int cap, x265_hip_me_result *out,
