@@ -175,6 +175,30 @@ int x265_hip_plane_release(x265_hip_ctx *ctx, int plane_id);
 /* copy a plane's buffer back to the host (synchronous; `bytes` at most the size it was created with) */
 int x265_hip_plane_download(x265_hip_ctx *ctx, int plane_id, uint8_t *host_buf, size_t bytes);
 
+/* ---- asynchronous transfers (BASELINE configs[4]: a long sequence streamed through a GPU) -------
+ * The reference overlaps pictures on the host: a frame encoder starts on a CTU row once the rows it references have
+ * been reconstructed (source/encoder/frameencoder.cpp:1039-1099).  The counterpart here is overlapping the arrival
+ * of the next closed GOP segment's pictures (and the departure of results) with the searches of the current one:
+ * a second set of planes, a copy stream inside the context, two fences.  No reference interface is replaced.
+ *   x265_hip_plane_alloc         an owned plane of `bytes` with the given layout, contents undefined (synchronises the
+ *                                context once; the directory entry is set, so later uploads change no metadata)
+ *   x265_hip_plane_upload_async  host_buf (pinned memory: x265_hip_host_alloc) -> that plane, on the copy stream;
+ *                                `bytes` must be the plane's size.  Returns at once.
+ *   x265_hip_download_async      device memory (e.g. a result array) -> pinned host memory, on the copy stream
+ *   x265_hip_copy_wait_compute   transfers queued from now on start after every kernel queued so far on the context
+ *   x265_hip_compute_wait_copy   kernels queued from now on start after every transfer queued so far
+ *   x265_hip_copy_sync           block until the copy stream is idle
+ * Ordering is the caller's: a plane must not be overwritten while queued searches read it, nor searched before its
+ * upload is fenced.  x265_amd/runner.py (SegmentStreamer) shows the double-buffered loop. */
+int x265_hip_host_alloc(size_t bytes, void **out);
+void x265_hip_host_free(void *p);
+int x265_hip_plane_alloc(x265_hip_ctx *ctx, int plane_id, size_t bytes, int stride, int origin_offset);
+int x265_hip_plane_upload_async(x265_hip_ctx *ctx, int plane_id, const uint8_t *host_buf, size_t bytes);
+int x265_hip_download_async(x265_hip_ctx *ctx, const void *d_src, void *host_dst, size_t bytes);
+int x265_hip_copy_wait_compute(x265_hip_ctx *ctx);
+int x265_hip_compute_wait_copy(x265_hip_ctx *ctx);
+int x265_hip_copy_sync(x265_hip_ctx *ctx);
+
 /* ---- lookahead planes ---------------------------------------------------
  * Lowres::create + Lowres::init (source/common/lowres.cpp:30-69, 164-174): the half-resolution plane and
  * its three half-pel companions (frame_init_lowres_core, source/common/pixel.cpp:595-618), edge-extended
@@ -398,12 +422,16 @@ typedef struct x265_hip_refine_section
 int x265_hip_refine_sections_device(x265_hip_ctx *ctx, const void *d_reqs, const x265_hip_refine_section *sections, int nsections,
                                     void *d_costs9);
 
-/* x265_hip_cost_batch_device for callers that cannot allocate device memory (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same requests, same costs;
- * the kernel's batch counters live in a static 8 KiB device array of the library (one copy per GPU, held until the
- * process ends) instead of the context's buffer, so the call allocates and frees nothing.  At most
- * X265_HIP_NOALLOC_MAX_REQUESTS requests per call (X265_HIP_ERANGE beyond).  All calls on one GPU share the array:
- * calls that overlap on one GPU (two contexts, two threads) race and must be serialised by the caller.
+/* x265_hip_cost_batch_device for callers that cannot allocate device memory (tight serving loops, harnesses that
+ * forbid hipMalloc, code that must not grow buffers).  No counterpart in the reference.  Same requests, same costs;
+ * the kernel's batch counters live in a static device array of the library (512 KiB: 64 slots of 8 KiB; one copy per
+ * GPU, held until the process ends) instead of the context's buffer, so the call allocates and frees nothing.  At
+ * most X265_HIP_NOALLOC_MAX_REQUESTS requests per call (X265_HIP_ERANGE beyond).  A context takes a slot of its GPU's
+ * array at its first call here and keeps it until x265_hip_ctx_destroy: 64 contexts per GPU at most can use this
+ * entry point at a time (X265_HIP_ERANGE for the 65th), and calls of different contexts may overlap on one GPU; calls
+ * on one context are ordered on its stream like every other call.  The call is not meant for HIP graph capture as it
+ * stands: when the context's plane / cost-table directory has changed since its last call it copies the directory
+ * and waits for the stream first, and record-check mode synchronises too.
  * Asynchronous on the context's stream like the other `_device` forms. */
 #define X265_HIP_NOALLOC_MAX_REQUESTS (1 << 24)
 int x265_hip_cost_batch_device_noalloc(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs);

@@ -69,3 +69,73 @@ def test_a_64_picture_segment_with_its_lookahead_planes_fits_the_plane_directory
     res = ctx.me_batch(jobs)
     assert len(res) == len(jobs) and (res["cost"] >= 0).all()
     ctx.close()
+
+
+def test_streamed_sequence_of_144_pictures_sharded_equals_unsharded_and_the_oracle(oracle):
+    """configs[4]'s runner with the transfers overlapped (runner.SegmentStreamer: double-buffered plane sets, uploads of
+    the next segment and downloads of finished results on the copy stream beside the searches): 144 distinct 416x240
+    pictures in closed GOPs of 16 -- as one rank, as two ranks (two contexts on device 0), and through the
+    synchronous runner must all give the same results; sampled pictures equal the oracle."""
+    from x265_amd import abi, lib, runner, shard, synth
+    from x265_amd.hipmem import DeviceBuffer
+    w, h, frames, gop = 416, 240, 144, 16
+    seq = synth.Sequence(w, h, seed=0x51, n_patches=3)
+    geo = (synth.Plane.nbytes_for(w, h),) + synth.Plane(seq.frame(0)).as_tuple()[2:0:-1]  # bytes, stride, origin
+    host_planes, pinned = {}, {}
+
+    def frame(pic):
+        if pic not in pinned:
+            p = synth.Plane(seq.frame(pic))
+            host_planes[pic] = p
+            b = lib.PinnedBuffer(p.buf.nbytes)
+            b.array[:] = p.buf.reshape(-1)
+            pinned[pic] = b
+        return pinned[pic]
+
+    def stream(rank, world):
+        ctx = lib.Context(0)
+        for q in range(28, 40):
+            ctx.set_qp(q)
+        lists = {}
+
+        def jobs(cur, seg, s):
+            refs = dict(shard.reference_pairs(seg, 3))[cur]
+            j = synth.me_jobs(w, h, s * gop + cur - seg[0], [s * gop + r - seg[0] for r in refs], [seq.global_motion(cur, r) for r in refs],
+                              method=abi.HEX, subme=2, merange=57, seed=cur)
+            lists[cur] = DeviceBuffer.from_array(j)
+            return lists[cur].ptr, len(j)
+        st = runner.SegmentStreamer(ctx, geo, gop, 3 * len(synth.square_pus(w, h, (64, 32, 16, 8))))
+        out = {}
+        st.run(shard.segments_for_rank(frames, gop, rank, world), frame, jobs, on_result=lambda pic, res: out.__setitem__(pic, res.copy()))
+        assert st.uploaded_bytes == geo[0] * sum(b - a for a, b in shard.segments_for_rank(frames, gop, rank, world))
+        st.close()
+        ctx.close()
+        return out
+
+    whole = stream(0, 1)
+    assert sorted(whole) == [p for p in range(frames) if p % gop]
+    parts = {}
+    for r in range(2):
+        mine = stream(r, 2)
+        assert not set(mine) & set(parts)
+        parts.update(mine)
+    assert sorted(parts) == sorted(whole)
+    for cur in whole:
+        assert np.array_equal(parts[cur], whole[cur]), cur
+    # the synchronous runner on the same sequence (plane ids of set 0)
+    ctx = lib.Context(0)
+    sync = runner.run_sequence(ctx, seq, frames, gop, n_refs=3)
+    ctx.close()
+    for cur in whole:
+        assert np.array_equal(sync[cur], whole[cur]), cur
+    # sampled pictures against the oracle: one of an even segment (plane set 0), one of an odd one (set 1)
+    tabs = {q: lib.costtab_build(q) for q in range(28, 40)}
+    for cur in (37, 21, 143):
+        seg = (cur // gop * gop, min(cur // gop * gop + gop, frames))
+        refs = dict(shard.reference_pairs(seg, 3))[cur]
+        j = synth.me_jobs(w, h, cur - seg[0], [r - seg[0] for r in refs], [seq.global_motion(cur, r) for r in refs], method=abi.HEX, subme=2,
+                          merange=57, seed=cur)
+        planes = [host_planes[p].as_tuple() for p in range(seg[0], seg[1])]
+        assert np.array_equal(whole[cur], oracle.me_batch(planes, tabs, j, nthreads=16)), cur
+    for b in pinned.values():
+        b.free()

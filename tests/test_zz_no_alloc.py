@@ -52,6 +52,38 @@ def test_noalloc_entry_point_matches_cost_batch_device(gpu_ctx, small_seq, oracl
     other.close()
 
 
+def test_noalloc_calls_of_two_contexts_overlap(gpu_ctx, small_seq):
+    """Two contexts on one GPU call the entry point back to back with no synchronisation in between: each has a slot of
+    the array of its own, so neither disturbs the other's batch counters (with one shared set of counters a call of one
+    context cleared the counts of the other's kernel in flight, and that kernel then skipped batches silently)."""
+    from x265_amd import lib
+    from x265_amd.hipmem import DeviceBuffer
+    rng = np.random.default_rng(78)
+    a, b = gpu_ctx, lib.Context(0)
+    for i, p in enumerate(small_seq[:3]):
+        b.plane_upload(i, p.buf, p.stride, p.origin)
+    n = 60000
+    ra, rb = _requests(rng, n, 416, 240), _requests(rng, n, 416, 240)
+    da, db = DeviceBuffer.from_array(ra), DeviceBuffer.from_array(rb)
+    wa, wb = DeviceBuffer(4 * n), DeviceBuffer(4 * n)
+    a.cost_batch_device(da.ptr, n, wa.ptr)
+    b.cost_batch_device(db.ptr, n, wb.ptr)
+    a.sync(), b.sync()
+    want_a, want_b = wa.download(np.int32), wb.download(np.int32)
+    for _ in range(6):
+        ga, gb = DeviceBuffer(4 * n), DeviceBuffer(4 * n)
+        ga.fill(0xDD), gb.fill(0xDD)
+        a.sync(), b.sync()
+        for _ in range(3):  # several launches in flight on both streams
+            a.cost_batch_device_noalloc(da.ptr, n, ga.ptr)
+            b.cost_batch_device_noalloc(db.ptr, n, gb.ptr)
+        a.sync(), b.sync()
+        assert np.array_equal(ga.download(np.int32), want_a)
+        assert np.array_equal(gb.download(np.int32), want_b)
+        ga.free(), gb.free()
+    b.close()
+
+
 def test_noalloc_entry_point_rejects_sizes_beyond_the_limit(gpu_ctx):
     from x265_amd import lib
     with pytest.raises(lib.X265HipError, match="exceed the limit"):

@@ -72,6 +72,8 @@ struct x265_hip_ctx
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;            // me_big_kernel runs here, beside me_kernel on `stream`
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t copy = nullptr;            // asynchronous plane uploads / result downloads (made at their first use)
+    hipEvent_t ev_copy = nullptr, ev_compute = nullptr;
     std::mutex mu;
     DeviceTables host_tabs;
     DeviceTables *dev_tabs = nullptr;
@@ -79,6 +81,8 @@ struct x265_hip_ctx
     uint32_t *batch_counter = nullptr; // batch counters of the cost kernels (two sets, see launch_cost)
     int batch_parity = 0;
     int route_parity = 0; // counter set of the next motionEstimate launch (me_kernel.hip)
+    int noalloc_slot = -1; // this context's part of the GPU's `scratch` array (taken at the first noalloc call)
+    int noalloc_parity = 0;
     bool check_records = false; // record-check mode of the device-array entry points
     void *owned_plane[X265_HIP_MAX_PLANES] = {};
     size_t plane_bytes[X265_HIP_MAX_PLANES] = {};
@@ -93,16 +97,23 @@ struct x265_hip_ctx
 
 // ---- scratch of the entry point that allocates nothing (x265_hip_cost_batch_device_noalloc) --------------
 // The cost kernels hand their batches out through counters in device memory.  Contexts keep theirs in a buffer
-// from hipMalloc; callers that cannot allocate get this array instead: one copy per GPU, held until the process
-// ends, shared by every call on that GPU.  In host code `scratch` is only a handle for hipGetSymbolAddress; the
-// device address it yields (one per device) is what host code passes on.
+// from hipMalloc; callers that cannot allocate get a slot of this array instead: one copy of the array per GPU, held
+// until the process ends, X265HIP_NOALLOC_SLOTS slots of X265HIP_COST_COUNTER_BYTES (512 KiB in all).  A context
+// takes a slot of its GPU's copy at its first noalloc call and keeps it until it is destroyed, so contexts never
+// share counters: calls of different contexts may overlap on one GPU (with one shared set a memset from one context
+// zeroed the hand-out counters of another's kernel in flight, which then skipped batches without any error).  In host
+// code `scratch` is only a handle for hipGetSymbolAddress; the device address it yields (one per device) is what
+// host code passes on.
 #define X265HIP_MAX_DEVICES 64
-static __device__ __align__(256) uint32_t scratch[X265HIP_COST_COUNTER_BYTES / sizeof(uint32_t)];
+#define X265HIP_NOALLOC_SLOTS 64
+static __device__ __align__(256) uint32_t scratch[X265HIP_NOALLOC_SLOTS * (X265HIP_COST_COUNTER_BYTES / sizeof(uint32_t))];
 
 namespace {
 
 uint32_t *g_scratch_ptr[X265HIP_MAX_DEVICES] = {};
+uint64_t g_scratch_used[X265HIP_MAX_DEVICES] = {}; // a bit per slot
 std::mutex g_scratch_mu;
+static_assert(X265HIP_NOALLOC_SLOTS <= 64, "one bit per slot");
 
 // once per device, with that device current
 int scratch_setup(int device)
@@ -119,6 +130,45 @@ int scratch_setup(int device)
         g_scratch_ptr[device] = (uint32_t *)p;
     }
     return 0;
+}
+
+// the context's slot of its GPU's array (device current), taken and cleared at the first call; null when none is left
+uint32_t *scratch_slot(x265_hip_ctx *c)
+{
+    if (c->device < 0 || c->device >= X265HIP_MAX_DEVICES || !g_scratch_ptr[c->device])
+        return nullptr;
+    if (c->noalloc_slot < 0)
+    {
+        std::lock_guard<std::mutex> g(g_scratch_mu);
+        for (int k = 0; k < X265HIP_NOALLOC_SLOTS && c->noalloc_slot < 0; k++)
+            if (!(g_scratch_used[c->device] >> k & 1))
+            {
+                g_scratch_used[c->device] |= 1ull << k;
+                c->noalloc_slot = k;
+            }
+        if (c->noalloc_slot < 0)
+            return nullptr;
+        // the slot's last owner left its counts behind: both sets start at zero (on the stream, in front of the launch;
+        // from then on every launch clears the set of the next one)
+        uint32_t *slot = g_scratch_ptr[c->device] + (size_t)c->noalloc_slot * (X265HIP_COST_COUNTER_BYTES / sizeof(uint32_t));
+        if (hipMemsetAsync(slot, 0, X265HIP_COST_COUNTER_BYTES, c->stream) != hipSuccess)
+        {
+            g_scratch_used[c->device] &= ~(1ull << c->noalloc_slot);
+            c->noalloc_slot = -1;
+            return nullptr;
+        }
+        c->noalloc_parity = 0;
+    }
+    return g_scratch_ptr[c->device] + (size_t)c->noalloc_slot * (X265HIP_COST_COUNTER_BYTES / sizeof(uint32_t));
+}
+
+void scratch_release(x265_hip_ctx *c)
+{
+    if (c->noalloc_slot < 0)
+        return;
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    g_scratch_used[c->device] &= ~(1ull << c->noalloc_slot);
+    c->noalloc_slot = -1;
 }
 
 // `pinned`: also a pinned host mirror of the same size (the staging of the host-array calls); buffers that only the
@@ -272,6 +322,9 @@ void x265_hip_ctx_destroy(x265_hip_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     if (c->side)
         (void)hipStreamSynchronize(c->side);
+    if (c->copy)
+        (void)hipStreamSynchronize(c->copy);
+    scratch_release(c); // (its last kernel is over)
     for (int i = 0; i < X265_HIP_MAX_PLANES; i++)
         if (c->owned_plane[i])
             (void)hipFree(c->owned_plane[i]);
@@ -294,6 +347,12 @@ void x265_hip_ctx_destroy(x265_hip_ctx *c)
         (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join)
         (void)hipEventDestroy(c->ev_join);
+    if (c->ev_copy)
+        (void)hipEventDestroy(c->ev_copy);
+    if (c->ev_compute)
+        (void)hipEventDestroy(c->ev_compute);
+    if (c->copy)
+        (void)hipStreamDestroy(c->copy);
     if (c->side)
         (void)hipStreamDestroy(c->side);
     if (c->stream)
@@ -400,6 +459,124 @@ int x265_hip_plane_download(x265_hip_ctx *c, int id, uint8_t *host_buf, size_t b
     HIP_TRY(hipMemcpyAsync(host_buf, c->host_tabs.planes[id].origin - c->plane_origin[id], bytes, hipMemcpyDeviceToHost,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return X265_HIP_OK;
+}
+
+// ---- asynchronous transfers: planes in and results out beside the kernels ----------------------------------------
+// A sequence runner keeps two sets of planes: while the searches of one closed GOP segment run on the context's
+// stream, the pictures of the next segment arrive in the other set over a copy stream of the context, and finished
+// results leave over it.  (The reference's analogue is the frame-parallel pipeline, encoder/frameencoder.cpp:1039-1099:
+// a frame encoder starts on a row as soon as the rows it references are there.)  Ordering is the caller's, with two
+// fences: x265_hip_copy_wait_compute (transfers queued from now on start after every kernel queued so far) and
+// x265_hip_compute_wait_copy (kernels queued from now on start after every transfer queued so far).
+
+static int copy_stream(x265_hip_ctx *c)
+{
+    if (c->copy)
+        return 0;
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_compute, hipEventDisableTiming));
+    return 0;
+}
+
+int x265_hip_host_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0)
+        return fail(X265_HIP_EINVAL, "host_alloc: bad argument");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess)
+        return fail(X265_HIP_ENOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return X265_HIP_OK;
+}
+
+void x265_hip_host_free(void *p)
+{
+    if (p)
+        (void)hipHostFree(p);
+}
+
+int x265_hip_plane_alloc(x265_hip_ctx *c, int id, size_t bytes, int stride, int origin)
+{
+    if (!c || id < 0 || id >= X265_HIP_MAX_PLANES || bytes == 0)
+        return fail(X265_HIP_EINVAL, "plane_alloc: bad argument (id %d)", id);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->owned_plane[id] || c->plane_bytes[id] != bytes)
+    {
+        plane_clear(c, id);
+        HIP_TRY(hipMalloc(&c->owned_plane[id], bytes + 64));
+        HIP_TRY(hipMemsetAsync((uint8_t *)c->owned_plane[id] + bytes, 0, 64, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return plane_set(c, id, c->owned_plane[id], bytes, stride, origin);
+}
+
+int x265_hip_plane_upload_async(x265_hip_ctx *c, int id, const uint8_t *host_buf, size_t bytes)
+{
+    if (!c || !host_buf || id < 0 || id >= X265_HIP_MAX_PLANES)
+        return fail(X265_HIP_EINVAL, "plane_upload_async: bad argument (id %d)", id);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (!c->owned_plane[id] || c->plane_bytes[id] != bytes)
+        return fail(X265_HIP_EINVAL, "plane_upload_async: plane %d is not an owned plane of %zu bytes (x265_hip_plane_alloc / x265_hip_plane_upload first)",
+                    id, bytes);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = copy_stream(c);
+    if (r)
+        return r;
+    HIP_TRY(hipMemcpyAsync(c->owned_plane[id], host_buf, bytes, hipMemcpyHostToDevice, c->copy));
+    return X265_HIP_OK;
+}
+
+int x265_hip_download_async(x265_hip_ctx *c, const void *d_src, void *host_dst, size_t bytes)
+{
+    if (!c || !d_src || !host_dst)
+        return fail(X265_HIP_EINVAL, "download_async: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = copy_stream(c);
+    if (r)
+        return r;
+    HIP_TRY(hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, c->copy));
+    return X265_HIP_OK;
+}
+
+int x265_hip_copy_wait_compute(x265_hip_ctx *c)
+{
+    if (!c)
+        return fail(X265_HIP_EINVAL, "null context");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = copy_stream(c);
+    if (r)
+        return r;
+    HIP_TRY(hipEventRecord(c->ev_compute, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->copy, c->ev_compute, 0));
+    return X265_HIP_OK;
+}
+
+int x265_hip_compute_wait_copy(x265_hip_ctx *c)
+{
+    if (!c)
+        return fail(X265_HIP_EINVAL, "null context");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = copy_stream(c);
+    if (r)
+        return r;
+    HIP_TRY(hipEventRecord(c->ev_copy, c->copy));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+    return X265_HIP_OK;
+}
+
+int x265_hip_copy_sync(x265_hip_ctx *c)
+{
+    if (!c)
+        return fail(X265_HIP_EINVAL, "null context");
+    if (c->copy)
+        HIP_TRY(hipStreamSynchronize(c->copy));
     return X265_HIP_OK;
 }
 
@@ -1109,10 +1286,10 @@ int x265_hip_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void 
     return X265_HIP_OK;
 }
 
-// x265_hip_cost_batch_device without any allocation: the batch counters are this GPU's `scratch` array (through
-// the address taken at context creation) instead of the context's buffer.  Every call on a GPU shares that array,
-// so it is cleared on the stream in front of the launch (another context's call leaves its counts behind) and the
-// kernel counts in set 0.  No hipMalloc / hipFree / growing staging on this path.
+// x265_hip_cost_batch_device without any allocation: the batch counters are this context's slot of the GPU's
+// `scratch` array (through the address taken at context creation) instead of the context's buffer.  The slot is
+// cleared once, when the context takes it; after that the two counter sets alternate as in the context's own buffer
+// (a launch clears the set of the next one).  No hipMalloc / hipFree / growing staging on this path.
 int x265_hip_cost_batch_device_noalloc(x265_hip_ctx *c, const void *d_reqs, int n, void *d_costs)
 {
     if (!c || n < 0 || (n && (!d_reqs || !d_costs)))
@@ -1129,14 +1306,14 @@ int x265_hip_cost_batch_device_noalloc(x265_hip_ctx *c, const void *d_reqs, int 
         if (vr)
             return vr;
     }
-    uint32_t *const ptr = c->device < X265HIP_MAX_DEVICES ? g_scratch_ptr[c->device] : nullptr;
+    uint32_t *const ptr = scratch_slot(c);
     if (!ptr)
-        return fail(X265_HIP_ERUNTIME, "cost_batch_device_noalloc: no scratch address for device %d", c->device);
+        return fail(X265_HIP_ERANGE, "cost_batch_device_noalloc: no scratch slot left on device %d (%d contexts at most use this entry point per GPU)",
+                    c->device, X265HIP_NOALLOC_SLOTS);
     int r = push_tabs(c); // a copy into the context's directory, nothing is allocated
     if (r)
         return r;
-    HIP_TRY(hipMemsetAsync(ptr, 0, X265HIP_COST_COUNTER_BYTES, c->stream));
-    LAUNCH(launch_cost(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, ptr, 0, c->stream));
+    LAUNCH(launch_cost(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, ptr, c->noalloc_parity ^= 1, c->stream));
     return X265_HIP_OK;
 }
 

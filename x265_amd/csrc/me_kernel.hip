@@ -1544,20 +1544,27 @@ __device__ __forceinline__ void me_list_loop(WaveLds &lds, const DeviceTables *t
 #ifndef ME_WAVES
 #define ME_WAVES 7
 #endif
-// route == nullptr: one workgroup per job of the list; otherwise the MC_REST jobs of a routed launch
+// one workgroup per job of the list (launches that do not route)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_WAVES))) void me_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n,
-                                                x265_hip_me_result *out, int out_stride, uint32_t *route, int parity, int cap)
+                                                x265_hip_me_result *out, int out_stride)
 {
     __shared__ WaveLds lds;
-    if (route)
-    {
-        me_list_loop<false>(lds, tabs, jobs, route, parity, cap, out, out_stride);
-        return;
-    }
     if ((int)blockIdx.x >= n)
         return;
     const int id = xcd_chunked(blockIdx.x, n, ME_XCD_CHUNK);
     me_job<false>(lds, tabs, jobs[id], (x265_hip_me_result *)((char *)out + (size_t)id * out_stride));
+}
+
+// the MC_REST jobs of a routed launch.  Six waves per SIMD: with the list loop's state around the search, seven (72
+// registers) spilled 23 of them
+#ifndef ME_REST_WAVES
+#define ME_REST_WAVES 6
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_REST_WAVES))) void me_rest_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs,
+                                                uint32_t *route, int parity, int cap, x265_hip_me_result *out, int out_stride)
+{
+    __shared__ WaveLds lds;
+    me_list_loop<false>(lds, tabs, jobs, route, parity, cap, out, out_stride);
 }
 
 // The lists of a routed launch (me_shared.h).  A wave's 64 consecutive jobs go to one part, each kind with one atomic
@@ -2395,7 +2402,7 @@ static void me_launch_both(const DeviceTables *tabs, const x265_hip_me_job *jobs
         return;
     if (!r.route) // the caller knows that the list holds nothing but MC_REST jobs
     {
-        hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, r.stream, tabs, jobs, n, out, out_stride, (uint32_t *)nullptr, 0, 0);
+        hipLaunchKernelGGL(me_kernel, dim3(n), dim3(64), 0, r.stream, tabs, jobs, n, out, out_stride);
         return;
     }
     const int cap = me_route_cap(n), parity = r.parity & 1;
@@ -2419,7 +2426,7 @@ static void me_launch_both(const DeviceTables *tabs, const x265_hip_me_job *jobs
     hipLaunchKernelGGL(me_big_kernel, dim3(bg), dim3(64), 0, sb, tabs, jobs, r.route, parity, cap, out, out_stride);
     if (team_on)
         launch_me_team(tabs, jobs, n, r.route, parity, cap, out, out_stride, r.stream);
-    hipLaunchKernelGGL(me_kernel, dim3(list_grid(n, 1, 256 * 4 * ME_WAVES)), dim3(64), 0, r.stream, tabs, jobs, n, out, out_stride, r.route, parity, cap);
+    hipLaunchKernelGGL(me_rest_kernel, dim3(list_grid(n, 1, 256 * 4 * ME_REST_WAVES)), dim3(64), 0, r.stream, tabs, jobs, r.route, parity, cap, out, out_stride);
     if (r.side)
     {
         (void)hipEventRecord(r.join, r.side);

@@ -38,6 +38,8 @@ EXPORTS = [
     "x265_hip_cost_batch_device_noalloc", "x265_hip_refine_batch", "x265_hip_refine_batch_device",
     "x265_hip_inter_search_batch", "x265_hip_inter_search_batch_device",
     "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device", "x265_hip_ctx_check_records", "x265_hip_refine_sections_device",
+    "x265_hip_host_alloc", "x265_hip_host_free", "x265_hip_plane_alloc", "x265_hip_plane_upload_async", "x265_hip_download_async",
+    "x265_hip_copy_wait_compute", "x265_hip_compute_wait_copy", "x265_hip_copy_sync",
 ]
 
 
@@ -124,6 +126,28 @@ def device_count():
     return load().x265_hip_device_count()
 
 
+class PinnedBuffer:
+    """page-locked host memory from x265_hip_host_alloc, as a numpy view (`array`, uint8)"""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _check(load().x265_hip_host_alloc(C.c_size_t(int(nbytes)), C.byref(p)))
+        self.ptr, self.nbytes = p.value, int(nbytes)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self.ptr))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            load().x265_hip_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Context:
     """x265_hip_ctx: one device, one stream, planes and cost tables resident in HBM."""
 
@@ -161,6 +185,27 @@ class Context:
 
     def plane_release(self, plane_id):
         _check(load().x265_hip_plane_release(self._h, C.c_int(plane_id)))
+
+    # asynchronous transfers on the context's copy stream (include/x265_hip.h)
+    def plane_alloc(self, plane_id, nbytes, stride, origin):
+        _check(load().x265_hip_plane_alloc(self._h, C.c_int(plane_id), C.c_size_t(nbytes), C.c_int(stride), C.c_int(origin)))
+
+    def plane_upload_async(self, plane_id, pinned):
+        """`pinned`: a PinnedBuffer (or any object with .ptr / .nbytes) holding the whole plane"""
+        _check(load().x265_hip_plane_upload_async(self._h, C.c_int(plane_id), C.c_void_p(pinned.ptr), C.c_size_t(pinned.nbytes)))
+
+    def download_async(self, d_src, pinned, nbytes=None):
+        _check(load().x265_hip_download_async(self._h, C.c_void_p(d_src), C.c_void_p(pinned.ptr),
+                                              C.c_size_t(pinned.nbytes if nbytes is None else nbytes)))
+
+    def copy_wait_compute(self):
+        _check(load().x265_hip_copy_wait_compute(self._h))
+
+    def compute_wait_copy(self):
+        _check(load().x265_hip_compute_wait_copy(self._h))
+
+    def copy_sync(self):
+        _check(load().x265_hip_copy_sync(self._h))
 
     def plane_download(self, plane_id, nbytes):
         out = np.zeros(nbytes, np.uint8)

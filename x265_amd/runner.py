@@ -100,6 +100,112 @@ class SegmentRunner:
         return out
 
 
+class SegmentStreamer:
+    """The ME stage of a rank's closed GOP segments with the transfers overlapped (BASELINE.json configs[4]).
+
+    Two sets of `gop` planes alternate: while the searches of segment k read one set on the context's stream, the
+    pictures of segment k + 1 arrive in the other over the context's copy stream from pinned host memory, and the
+    results of every finished picture leave over it (x265_hip_plane_upload_async / x265_hip_download_async and the
+    two fences, include/x265_hip.h).  Per picture of segment k, in host program order:
+
+        compute_wait_copy()                       # this search starts after the transfers queued one picture ago
+        copy_wait_compute()                       # transfers from here on start after the kernels queued so far ...
+        download_async(results of the picture before)        # ... so this one follows that picture's search
+        plane_upload_async(one picture of segment k + 1)      # its plane set was last read by segment k - 1, long over
+        me_batch_device(this picture)
+
+    so one picture's transfers run beside that picture's search.  Plane ids are segment-local and the two sets
+    are addressed by the same ids (set 1 = ids + gop), so a picture's job list exists once per set.
+
+    `frames(pic)` -> PinnedBuffer with the padded plane of picture `pic`; `jobs(cur, segment, set)` -> (device
+    address, count) of that picture's job list for a plane set; both are the caller's (bench.py cycles one segment's
+    worth of synthetic pictures so that generating them is not what is timed, the tests use distinct pictures).
+    """
+
+    def __init__(self, ctx, plane_geometry, gop, n_out_max, n_refs=3):
+        from . import lib
+        from .hipmem import DeviceBuffer
+        self.ctx, self.gop, self.n_refs = ctx, gop, n_refs
+        self.nbytes, self.stride, self.origin = plane_geometry
+        for i in range(2 * gop):
+            ctx.plane_alloc(i, self.nbytes, self.stride, self.origin)
+        # results: two device arrays and two pinned arrays in turn
+        self.d_out = [DeviceBuffer(8 * n_out_max) for _ in range(2)]
+        self.h_out = [lib.PinnedBuffer(8 * n_out_max) for _ in range(2)]
+        self.uploaded_bytes = self.downloaded_bytes = 0
+
+    def close(self):
+        self.ctx.sync()
+        self.ctx.copy_sync()
+        for b in self.d_out:
+            b.free()
+        for b in self.h_out:
+            b.free()
+        for i in range(2 * self.gop):
+            self.ctx.plane_release(i)
+
+    def run(self, segments, frames, jobs, on_result=None):
+        """`segments`: this rank's [(first, last_exclusive)]; `frames(pic)` -> PinnedBuffer; `jobs(cur, segment, set)`
+        -> (device address, count); on_result(pic, ME_RESULT array) for every P picture, called once the picture's
+        results are on the host (the array is only valid during the call)"""
+        ctx = self.ctx
+        if not segments:
+            return
+        pending = None  # (pic, slot, count): searched, download not yet queued
+        queued = None   # download queued, not yet handed to the host
+        n_launch = 0
+
+        def upload(pic, seg, s):
+            ctx.plane_upload_async(s * self.gop + (pic - seg[0]), frames(pic))
+            self.uploaded_bytes += self.nbytes
+
+        def hand_over(done):
+            if done is not None and on_result is not None:
+                ctx.copy_sync()  # the copy stream has passed the slot's download
+                pic, slot, n = done
+                on_result(pic, self.h_out[slot].array[: 8 * n].view(abi.ME_RESULT))
+
+        def transfers():
+            """one picture's worth of transfers behind the kernels queued so far"""
+            nonlocal pending, queued
+            ctx.copy_wait_compute()
+            hand_over(queued)
+            queued = None
+            if pending is not None:
+                pic, slot, n = pending
+                ctx.download_async(self.d_out[slot].ptr, self.h_out[slot], 8 * n)
+                self.downloaded_bytes += 8 * n
+                queued, pending = pending, None
+
+        for pic in range(*segments[0]):
+            upload(pic, segments[0], 0)
+        for k, seg in enumerate(segments):
+            s = k & 1
+            nxt = segments[k + 1] if k + 1 < len(segments) else None
+            nxt_pics = list(range(*nxt)) if nxt else []
+            pairs = shard.reference_pairs(seg, self.n_refs)
+            for j, (cur, refs) in enumerate(pairs):
+                d_jobs, n = jobs(cur, seg, s)
+                # this launch starts after the transfers queued one launch ago and earlier: its pictures have arrived (they
+                # were queued during the segment before), and the results that last used its output slot have left
+                ctx.compute_wait_copy()
+                transfers()
+                # the next segment's pictures, spread over this segment's launches (its plane set was last read by the
+                # segment before this one)
+                for _ in range(-(-len(nxt_pics) // (len(pairs) - j))):
+                    upload(nxt_pics.pop(0), nxt, s ^ 1)
+                slot = n_launch & 1
+                ctx.me_batch_device(d_jobs, n, self.d_out[slot].ptr)
+                pending = (cur, slot, n)
+                n_launch += 1
+            for pic in nxt_pics:  # (a segment without P pictures has no launches to spread them over)
+                upload(pic, nxt, s ^ 1)
+        transfers()
+        hand_over(queued)
+        ctx.sync()
+        ctx.copy_sync()
+
+
 def run_sequence(ctx, seq, n_frames, gop, rank=0, world=1, **kw):
     """ME stage of this rank's segments of an n_frames sequence: {cur: results}"""
     runner = SegmentRunner(ctx, seq, **kw)
