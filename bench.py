@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10, help="untimed steps per leg; every leg also warms up for 60 ms (clock ramp)")
     ap.add_argument("--gop", type=int, default=8, help="pictures per closed GOP segment")
     ap.add_argument("--segments-per-rank", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=1024, help="pictures of the streamed sequence (key `sequence`, strong scaling)")
+    ap.add_argument("--seq-gop", type=int, default=32, help="pictures per closed GOP segment of the streamed sequence")
+    ap.add_argument("--no-sequence", action="store_true", help="skip the streamed sequence (key `sequence`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hd", action="store_true", help="skip the 1080p legs (key hd)")
     args = ap.parse_args()
@@ -209,11 +212,82 @@ def main():
     pics, runners, n_frames = load_pictures(seq, args.gop, args.segments_per_rank)
     (dt_sp, ev_sp, acc_sp), (dt_c1, ev_c1, acc_c1), (dt_me, ev_me, acc_me), (dt_fs, ev_fs, acc_fs) = three_legs(pics, args.steps, args.warmup)
 
+    # ---- configs[4] as stated: a --frames picture 4K sequence in closed GOPs of --seq-gop, cut over the ranks (strong
+    # scaling), streamed: the pictures of the next segment arrive from pinned host memory and the results of finished
+    # pictures leave while the current segment is searched (runner.SegmentStreamer); the bracket holds the transfers.
+    # One segment's worth of synthetic pictures is cycled (every segment has the same content), so that generating
+    # pictures and job lists is not what is timed.
+    seq_leg = None
+    if not args.no_sequence:
+        from x265_amd.hipmem import DeviceBuffer
+        for r in runners:
+            r.release()
+        sg = args.seq_gop
+        my_segments = shard.segments_for_rank(args.frames, sg, rank, world)
+        probe = synth.Plane(seq.frame(0))
+        geo = (probe.buf.nbytes, probe.stride, probe.origin)
+        pinned = []
+        for i in range(sg):
+            b = lib.PinnedBuffer(geo[0])
+            b.array[:] = synth.Plane(seq.frame(i)).buf.reshape(-1)
+            pinned.append(b)
+        lists = {}
+        for pos, refs in shard.reference_pairs((0, sg), 3):
+            j = synth.me_jobs(UW, UH, pos, refs, [seq.global_motion(pos, r) for r in refs], method=abi.HEX, subme=2, merange=57, seed=pos)
+            lists[(pos, 0)] = (DeviceBuffer.from_array(j), len(j))
+            j["fenc_plane"] += sg
+            j["ref_plane"] += sg
+            lists[(pos, 1)] = (DeviceBuffer.from_array(j), len(j))
+        n_out = max(n for _, n in lists.values())
+        st = rn.SegmentStreamer(ctx, geo, sg, n_out)
+
+        def seq_jobs(cur, seg, s):
+            b, n = lists[(cur - seg[0], s)]
+            return b.ptr, n
+
+        def seq_frame(pic):
+            return pinned[pic % sg]
+        st.run(my_segments[:2], seq_frame, seq_jobs)  # warm-up: both plane sets, the clocks
+        st.uploaded_bytes = st.downloaded_bytes = 0
+        barrier()
+        t0 = time.perf_counter()
+        st.run(my_segments, seq_frame, seq_jobs)
+        barrier()
+        dt_seq = max_over_ranks(time.perf_counter() - t0)
+        # the same launches with the planes resident and nothing transferred (set 0 holds a whole segment)
+        o_res = DeviceBuffer(8 * n_out)
+        barrier()
+        t0 = time.perf_counter()
+        for seg in my_segments:
+            for cur, _ in shard.reference_pairs(seg, 3):
+                b, n = lists[(cur - seg[0], 0)]
+                ctx.me_batch_device(b.ptr, n, o_res.ptr)
+        barrier()
+        dt_res = max_over_ranks(time.perf_counter() - t0)
+        my_pics = sum(b - a for a, b in my_segments)
+        seq_leg = {"workload": f"configs[4]: {args.frames} pictures of 3840x2160 in closed GOPs of {sg}, segment s on rank s mod {world} (strong "
+                               "scaling), ME stage of every P picture (HEX, subme 2, merange 57, up to 3 references of its segment); planes "
+                               "uploaded from pinned host memory and results downloaded inside the timed region, overlapped with the searches "
+                               "(two plane sets, copy stream; x265_amd/runner.py SegmentStreamer)",
+                   "frames": args.frames, "gop": sg, "segments_this_rank": len(my_segments),
+                   "pictures_per_s": args.frames / dt_seq, "seconds": dt_seq,
+                   "h2d_GBps_per_gpu": st.uploaded_bytes / dt_seq / 1e9, "d2h_GBps_per_gpu": st.downloaded_bytes / dt_seq / 1e9,
+                   "resident_pictures_per_s": args.frames / dt_res,
+                   "transfer_overhead": dt_seq / dt_res - 1.0,
+                   "note": "pictures_per_s counts every picture of the sequence (the first of a segment is uploaded, not searched)"}
+        assert my_pics * geo[0] == st.uploaded_bytes
+        st.close()
+        o_res.free()
+        for b, _ in lists.values():
+            b.free()
+        for b in pinned:
+            b.free()
+
     hd = None
     if not args.no_hd:
         hseq = synth.Sequence(1920, 1080, seed=0x265)
         for r in runners:
-            r.release()
+            r.release()  # (nothing to do when the sequence leg has released them)
         hpics, hrunners, _ = load_pictures(hseq, 4, 1)
         (_, h_sp, a_sp), (_, h_c1, a_c1), (_, h_me, a_me), (_, h_fs, a_fs) = three_legs(hpics, args.steps, 0)
         hd = {"workload": "the same three legs on 1920x1080 pictures (configs[1], configs[2]): one closed segment of 4 pictures per "
@@ -291,7 +365,7 @@ def main():
         # what the searches of that picture evaluate, priced at SURVEY.md 8(d)'s algorithmic lane-ops (oracle work model)
         _, me_model = pyoracle.load_oracle().me_batch_ops(pl, tabs, p0.me_host, nthreads=cores)
         me_model["calls"] = p0.n_me
-        if not args.no_hd:  # the 1080p legs released the 4K planes: put this picture's back
+        if not (args.no_hd and args.no_sequence):  # the later legs released the 4K planes: put this picture's back
             for pid, (buf, origin, stride) in host_planes.items():
                 ctx.plane_upload(pid, buf, stride, origin)
         o_model = torch.empty(p0.n_me * 8, dtype=torch.uint8, device=dev)
@@ -357,12 +431,14 @@ def main():
         if me_model:
             ms = me_model["kernel_ms"]  # that picture's list timed on its own
             line["me_stage"]["roofline"] = {
-                "bound": "valu", "kernel": "me_kernel + me_big_kernel", "kernel_ms": ms, "algorithmic_lane_ops": me_model["lane_ops"],
+                "bound": "valu", "kernel": "me_team_kernel + me_rest_kernel + me_big_kernel (one routed launch)", "kernel_ms": ms, "algorithmic_lane_ops": me_model["lane_ops"],
                 "achieved": me_model["lane_ops"] / (ms * 1e-3) / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-op/s",
                 "frac": me_model["lane_ops"] / (ms * 1e-3) / VALU_PEAK,
                 "issue_ceiling": {"peak": VALU_ISSUE_4CYC / 1e12, "frac": me_model["lane_ops"] / (ms * 1e-3) / VALU_ISSUE_4CYC},
                 "model": {k: me_model[k] for k in ("sad_ops", "satd_ops", "interp_ops", "sad_candidates", "subpel_candidates", "calls")},
                 "traffic": (sum(traffic.get(k + "_4k", 0) for k in ("me_kernel", "me_big_kernel", "me_route_kernel")) or None)}
+        if seq_leg:
+            line["sequence"] = seq_leg
         if hd:
             line["hd"] = hd
         if cpu:
