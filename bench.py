@@ -78,6 +78,19 @@ class Picture:
         # the four lists back to back: one list of four runs, submitted in one launch
         self.d_rings = torch.from_numpy(np.concatenate(rings).view(np.uint8).copy()).to(dev)
         self.ring_sections = [(len(r), int(r["pu_w"][0]), int(r["pu_h"][0])) for r in rings if len(r)]
+        # the medium preset's own sub-pel stage (motion.cpp:51: 1 + 4 half-pel candidates, 4 quarter-pel) around the integer
+        # search's winners: two ring lists, each four runs by PU size
+        from x265_amd import abi
+        self.s2 = []
+        self.n_s2 = self.n_s2_rings = 0
+        self.s2_ops = 0.0
+        for rings in runner.subme2_rings(cur, refs):
+            creqs, used = abi.refine_as_cost_reqs(np.concatenate(rings))
+            self.n_s2 += int(used.sum())
+            self.n_s2_rings += len(creqs)
+            self.s2_ops += synth.satd_lane_ops(creqs[used])
+            self.s2.append((torch.from_numpy(np.concatenate(rings).view(np.uint8).copy()).to(dev),
+                            [(len(r), int(r["pu_w"][0]), int(r["pu_h"][0])) for r in rings if len(r)]))
         self.me_host = runner.me_jobs(cur, refs)
         self.n_me = len(self.me_host)
         self.d_me = torch.from_numpy(self.me_host.view(np.uint8).copy()).to(dev)
@@ -199,18 +212,25 @@ def main():
             ctx.me_batch_device(p.d_me.data_ptr(), p.n_me, o_me.data_ptr())
             return p
 
+        def run_s2(s):
+            p = pics[s % n]
+            for d, sections in p.s2:
+                ctx.refine_sections_device(d.data_ptr(), sections, o_ring.data_ptr())
+            return p
+
         def run_fs(s):
             p = pics[s % n]
             ctx.fullsearch_device(p.d_fs.data_ptr(), p.n_ctu, o_fs.data_ptr())
             return p
 
-        return leg(run_ring, steps, warmup), leg(run_satd, steps, warmup), leg(run_me, steps, warmup), leg(run_fs, steps, warmup)
+        return leg(run_ring, steps, warmup), leg(run_satd, steps, warmup), leg(run_me, steps, warmup), leg(run_fs, steps, warmup), leg(run_s2, steps, warmup)
 
     # ---- configs[3] / configs[4]: 4K, GOP-sharded ----------------------------------------------------------------
     UW, UH = 3840, 2160
     seq = synth.Sequence(UW, UH, seed=0x265)
     pics, runners, n_frames = load_pictures(seq, args.gop, args.segments_per_rank)
-    (dt_sp, ev_sp, acc_sp), (dt_c1, ev_c1, acc_c1), (dt_me, ev_me, acc_me), (dt_fs, ev_fs, acc_fs) = three_legs(pics, args.steps, args.warmup)
+    (dt_sp, ev_sp, acc_sp), (dt_c1, ev_c1, acc_c1), (dt_me, ev_me, acc_me), (dt_fs, ev_fs, acc_fs), (dt_s2, ev_s2, acc_s2) = \
+        three_legs(pics, args.steps, args.warmup)
 
     # ---- configs[4] as stated: a --frames picture 4K sequence in closed GOPs of --seq-gop, cut over the ranks (strong
     # scaling), streamed: the pictures of the next segment arrive from pinned host memory and the results of finished
@@ -289,12 +309,14 @@ def main():
         for r in runners:
             r.release()  # (nothing to do when the sequence leg has released them)
         hpics, hrunners, _ = load_pictures(hseq, 4, 1)
-        (_, h_sp, a_sp), (_, h_c1, a_c1), (_, h_me, a_me), (_, h_fs, a_fs) = three_legs(hpics, args.steps, 0)
+        (_, h_sp, a_sp), (_, h_c1, a_c1), (_, h_me, a_me), (_, h_fs, a_fs), (_, h_s2, a_s2) = three_legs(hpics, args.steps, 0)
         hd = {"workload": "the same three legs on 1920x1080 pictures (configs[1], configs[2]): one closed segment of 4 pictures per "
                           "GPU, kernel time (HIP events), per GPU",
               "satd_candidates_per_s": sum(p.n_satd for p in a_sp) / h_sp * 1e3,
               "satd_candidates_per_s_single_requests": sum(p.n_satd for p in a_c1) / h_c1 * 1e3,
               "satd_frac_of_valu_peak": sum(p.satd_ops for p in a_sp) / (h_sp * 1e-3) / VALU_PEAK,
+              "satd_candidates_per_s_subme2_rings": sum(p.n_s2 for p in a_s2) / h_s2 * 1e3,
+              "satd_subme2_frac_of_valu_peak": sum(p.s2_ops for p in a_s2) / (h_s2 * 1e-3) / VALU_PEAK,
               "me_frames_per_s": len(a_me) / h_me * 1e3, "me_calls_per_s": sum(p.n_me for p in a_me) / h_me * 1e3,
               "fullsearch_candidates_per_s": sum(p.fs_units for p in a_fs) / h_fs * 1e3,
               "fullsearch_frac_of_sad_peak": sum(p.fs_pos for p in a_fs) * 4096 / (h_fs * 1e-3) / SAD_PX_PEAK}
@@ -417,6 +439,16 @@ def main():
                                                   "achieved": sum(p.satd_ops for p in acc_c1) / (ev_c1 * 1e-3) / 1e12, "peak": VALU_PEAK / 1e12,
                                                   "unit": "Tlane-op/s", "frac": sum(p.satd_ops for p in acc_c1) / (ev_c1 * 1e-3) / VALU_PEAK,
                                                   "traffic": traffic.get("cost_kernel_4k")}},
+            "satd_rings_subme2": {"workload": "what the medium preset's sub-pel stage asks for (workload[2], motion.cpp:51): per square PU and "
+                                              "reference a 4-point half-pel ring with the centre, then a 4-point quarter-pel ring, around "
+                                              "the winners of the integer search of that PU (x265_hip_fullsearch, +-64) and of the first "
+                                              "ring: 9 candidates per (PU, reference), two launches per picture (x265_hip_refine_sections_device)",
+                                  "candidates_per_s": sum(p.n_s2 for p in acc_s2) * world / dt_s2, "ms_per_frame": dt_s2 / K * 1e3,
+                                  "rings_per_frame": sum(p.n_s2_rings for p in acc_s2) / K,
+                                  "roofline": {"bound": "valu", "kernel": "refine_kernel", "kernel_ms": ev_s2 / K, "launches_per_step": 2,
+                                               "achieved": sum(p.s2_ops for p in acc_s2) / (ev_s2 * 1e-3) / 1e12, "peak": VALU_PEAK / 1e12,
+                                               "unit": "Tlane-op/s", "frac": sum(p.s2_ops for p in acc_s2) / (ev_s2 * 1e-3) / VALU_PEAK,
+                                               "algorithmic_lane_ops": sum(p.s2_ops for p in acc_s2) / K}},
             "me_stage": {"workload": "motionEstimate replay of the same pictures: HEX, subme 2, merange 57, square PUs 64..8 x the "
                                      "segment's references (x265_hip_me_batch)",
                          "frames_per_s": K * world / dt_me, "me_calls_per_s": sum(p.n_me for p in acc_me) * world / dt_me,

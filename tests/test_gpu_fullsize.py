@@ -208,6 +208,31 @@ def test_satd_rings_whole_4k_frame_three_refs(uhd, oracle):
     assert len(bad) == 0, (len(bad), creqs[used][bad[0]], got[used][bad[0]], want[bad[0]])
 
 
+def test_subme2_rings_whole_4k_frame_three_refs(uhd, oracle):
+    """what the medium preset's sub-pel stage asks for (workload[2]: a 4-point half-pel ring with the centre, then a
+    4-point quarter-pel ring), around the integer search's winners of every PU of a 4K picture x 3 references (the list of
+    bench.py's satd_rings_subme2 leg): every one of the 9 x 516,060 costs equal to the oracle's subpelCompare + satd"""
+    from x265_amd import abi, runner
+    seq, planes, ctx = uhd
+    run = runner.SegmentRunner(ctx, seq, n_refs=3)
+    run.segment = (0, 4)  # the fixture's planes 0..3 are pictures 0..3
+    hp, qp = run.subme2_rings(3, [2, 1, 0])
+    assert sum(len(r) for r in hp) == sum(len(r) for r in qp) == 3 * 172020
+    # the winners are integer vectors, and they differ from PU to PU (not the global-motion vector everywhere)
+    allh = np.concatenate(hp)
+    assert ((allh["qmv_x"] & 3) == 0).all() and ((allh["qmv_y"] & 3) == 0).all()
+    assert len(np.unique(allh["qmv_x"])) > 8
+    for rings, per in ((hp, 5), (qp, 4)):
+        rr = np.concatenate(rings)
+        got = ctx.refine_batch(rr)
+        creqs, used = abi.refine_as_cost_reqs(rr)
+        assert used.sum() == per * 3 * 172020
+        want = oracle.cost_batch([p.as_tuple() for p in planes], creqs[used], nthreads=THREADS)
+        assert (got[~used] == 0x7fffffff).all()
+        bad = np.nonzero(got[used] != want)[0]
+        assert len(bad) == 0, (len(bad), creqs[used][bad[0]], got[used][bad[0]], want[bad[0]])
+
+
 def test_fullsearch_whole_4k_frame(uhd, oracle):
     """all 2040 CTUs of a 4K picture: a sample of CTUs exactly against the oracle, every one of the 173,400 results by
     the size-independent properties (cost == SAD at the returned vector + its rate, vector inside the window, winner

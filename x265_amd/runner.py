@@ -74,6 +74,20 @@ class SegmentRunner:
         rq = synth.refine_requests(self.w, self.h, self.plane_of(cur), [self.plane_of(r) for r in refs], self._motions(cur, refs))
         return [rq[rq["pu_w"] == s] for s in (64, 32, 16, 8)]
 
+    def subme2_rings(self, cur, refs, search_range=64):
+        """the medium preset's sub-pel stage of picture `cur` as two ring lists (synth.subme2_hpel_rings / _qpel_rings),
+        centred on the winners of the integer search of every PU (x265_hip_fullsearch, +-search_range) and, for the
+        second ring, of the first: ([half-pel lists per PU size], [quarter-pel lists per PU size]).  Runs the
+        searches and the first rings on the device (set-up, not timed by anyone)."""
+        mask = synth.ctu_pu_mask(self.w, self.h)
+        winners = []
+        for r in refs:
+            fs = self.ctx.fullsearch(self.ctu_jobs(cur, r, search_range)).reshape(-1)[mask]
+            winners.append(np.stack([fs["mvx"], fs["mvy"]], axis=1).astype(np.int64))
+        hp = synth.subme2_hpel_rings(self.w, self.h, self.plane_of(cur), [self.plane_of(r) for r in refs], winners)
+        qp = synth.subme2_qpel_rings(hp, self.ctx.refine_batch(hp))
+        return [hp[hp["pu_w"] == s] for s in (64, 32, 16, 8)], [qp[qp["pu_w"] == s] for s in (64, 32, 16, 8)]
+
     def ctu_jobs(self, cur, ref, search_range=64, qp=30):
         """integer full search of every CTU of `cur` against `ref` (configs[1] at this picture size)"""
         from .lib import CTU_JOB

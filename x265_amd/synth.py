@@ -225,6 +225,54 @@ def subpel_requests(w, h, cur, refs, motions):
     return out
 
 
+def ctu_pu_mask(w, h, sizes=(64, 32, 16, 8)):
+    """which of a CTU-major list of all PUs (85 per CTU in the order 64, 32s, 16s, 8s, each raster: the result order of
+    x265_hip_fullsearch) lie wholly inside the picture -- the PUs of square_pus(), in its order"""
+    out = []
+    ncx, ncy = ctu_grid(w, h)
+    for cy in range(ncy):
+        for cx in range(ncx):
+            for s in sizes:
+                n = CTU // s
+                for by in range(n):
+                    for bx in range(n):
+                        out.append(cx * CTU + bx * s + s <= w and cy * CTU + by * s + s <= h)
+    return np.array(out, bool)
+
+
+def subme2_hpel_rings(w, h, cur, refs, winners, metric=SATD):
+    """The sub-pel stage the medium preset asks for (workload[2], motion.cpp:51: one half-pel iteration of 4 points with
+    the centre re-measured by SATD, one quarter-pel iteration of 4), first ring: per square PU and reference the
+    4-point half-pel ring + centre around the integer search's winner.  `winners[i]`: (n_pus, 2) quarter-pel vectors
+    (multiples of 4) for reference refs[i], PUs in square_pus() order.  Reference-major."""
+    from .abi import REFINE_REQ, RING_CENTRE, RING_HPEL
+    pus = square_pus(w, h)
+    n = len(pus)
+    out = np.zeros(n * len(refs), REFINE_REQ)
+    for i, (rp, mv) in enumerate(zip(refs, winners)):
+        r = out[i * n:(i + 1) * n]
+        r["fenc_plane"], r["ref_plane"] = cur, rp
+        r["pu_x"], r["pu_y"] = pus[:, 0], pus[:, 1]
+        r["pu_w"] = r["pu_h"] = pus[:, 2]
+        r["metric"], r["pattern"] = metric, RING_HPEL | RING_CENTRE
+        r["qmv_x"], r["qmv_y"] = mv[:, 0], mv[:, 1]
+    return out
+
+
+def subme2_qpel_rings(hpel_reqs, hpel_costs):
+    """second ring: the 4-point quarter-pel ring around the first ring's winner (first minimum of centre, then the
+    ring in visiting order: the strict-less updates of motion.cpp:1090-1101; distortion only)"""
+    from .abi import RING_QPEL, SQUARE1
+    c = np.asarray(hpel_costs).reshape(len(hpel_reqs), -1)[:, :5].astype(np.int64)
+    k = np.argmin(c, axis=1)  # the first minimum
+    sq = np.array(SQUARE1, np.int64)
+    out = hpel_reqs.copy()
+    out["pattern"] = RING_QPEL
+    out["qmv_x"] = hpel_reqs["qmv_x"] + 2 * sq[k, 0]
+    out["qmv_y"] = hpel_reqs["qmv_y"] + 2 * sq[k, 1]
+    return out
+
+
 def satd_lane_ops(reqs):
     """Algorithmic 32-bit lane-ops of a request list (SURVEY.md 8(d)): the comparison (SATD 111 per 4x4 tile;
     sa8d 575 per 8x8 block = 64 differences, sixteen 8-point transforms of 24 butterflies, 64 absolute values,
