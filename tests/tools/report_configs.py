@@ -72,6 +72,14 @@ def run(w, h, tag):
         ms = timed(ext, ctx, lambda: ctx.me_batch_device(d.data_ptr(), len(mj), o.data_ptr()), 10)
         res["me_stage_" + name] = {"calls": len(mj), "references": 3, "ms_per_picture": ms, "pictures_per_s": 1e3 / ms,
                                    "calls_per_s": len(mj) / ms * 1e3}
+        # roofline by the checker's op model of what these searches evaluate (SURVEY.md 8(d) lane-ops)
+        from oracle import pyoracle
+        tabs = {q: lib.costtab_build(q) for q in range(28, 40)}
+        _, model = pyoracle.load_oracle().me_batch_ops([p.as_tuple() for p in planes], tabs, mj, nthreads=16)
+        res["me_stage_" + name]["roofline"] = {
+            "bound": "valu", "algorithmic_lane_ops": model["lane_ops"], "achieved": model["lane_ops"] / (ms * 1e-3) / 1e12,
+            "peak": LANE_PEAK / 1e12, "unit": "Tlane-op/s", "frac": model["lane_ops"] / (ms * 1e-3) / LANE_PEAK,
+            "model": {k: model[k] for k in ("sad_ops", "satd_ops", "interp_ops", "sad_candidates", "subpel_candidates")}}
 
     # lookahead: lowres planes of four pictures, then every 8x8 CU of one picture against
     # two Lowres references (HEX, subme 1, merange 16, QP 12: the lookahead's settings, slicetype.h:73-77)

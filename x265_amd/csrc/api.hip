@@ -287,7 +287,19 @@ int x265_hip_ctx_create(int device, x265_hip_ctx **out)
     memset(&c->host_tabs, 0, sizeof(c->host_tabs));
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess && !(getenv("X265_HIP_ME_ONE_STREAM") && atoi(getenv("X265_HIP_ME_ONE_STREAM"))))
-        e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    {
+        // X265_HIP_ME_SIDE_PRIORITY=1: the side stream at the highest priority, an experiment of round 2 that hung once
+        // in the GPU suite and is kept only to examine that; never set in production
+        if (getenv("X265_HIP_ME_SIDE_PRIORITY") && atoi(getenv("X265_HIP_ME_SIDE_PRIORITY")))
+        {
+            int least = 0, greatest = 0;
+            e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (e == hipSuccess)
+                e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, greatest);
+        }
+        else
+            e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    }
     if (e == hipSuccess)
         e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess)
