@@ -52,7 +52,8 @@ __device__ __forceinline__ constexpr uint32_t workload_column(int c)
 //            me_big_kernel (one wave per call, strips of 16 x 4 pixels / stacked tiles, 4 waves per SIMD)
 //   MC_T4    diamond / hexagon searches of blocks up to 8x8, full-resolution reference: me_team_kernel, sixteen calls
 //            per wave in lockstep (a team of 4 lanes per call, one lane per 4x4 tile)
-//   MC_T16   the same for the other blocks up to 16x16 (16x16, 16x8, 8x16, 12x16, 16x4 ...): four calls per wave, 16 lanes each
+//   MC_T8    the same for 16x16, 16x8, 8x16, 12x16: eight calls per wave, a team of 8 lanes, one lane per 4x8 strip
+//   MC_T32   the same for 32x32, 32x16, 32x24, 24x32, 32x8: four calls per wave, a team of 16 lanes, one lane per 8x8 cell
 //   MC_REST  everything else (UMH / STAR / FULL, Lowres references, 32x32 ...): me_rest_kernel, one wave per call
 // A list per kind is kept in ME_PARTS parts (one counter for a whole grid would serialise: an atomic on one address
 // takes ~12 ns): the jobs of one wave of me_route_kernel (64 consecutive jobs) go to one part, consecutive waves to
@@ -61,7 +62,7 @@ __device__ __forceinline__ constexpr uint32_t workload_column(int c)
 // (me_route_kernel) and one hand-out counter (the consumer), 64 bytes apart.  Two sets of counters alternate between
 // launches (`parity`): a launch's me_route_kernel clears the set of the next launch.
 #define ME_PARTS 64
-enum { MC_REST = 0, MC_BIG = 1, MC_T4 = 2, MC_T16 = 3, ME_CLASSES = 4 };
+enum { MC_REST = 0, MC_BIG = 1, MC_T4 = 2, MC_T8 = 3, MC_T32 = 4, ME_CLASSES = 5 };
 #define ME_ROUTE_SET (2 * ME_CLASSES * ME_PARTS * 16) // words per counter set: append counters, then hand-out counters
 #define ME_ROUTE_HEAD (2 * ME_ROUTE_SET)              // the lists start behind the two sets
 #ifndef ME_BIG_TILES
@@ -94,8 +95,17 @@ __host__ __device__ inline int me_job_class(int w, int h, int method)
         return MC_REST;
     if (big_block(w, h))
         return MC_BIG;
-    if (method <= X265_HIP_HEX && w <= 16 && h <= 16 && (w >= 8 || h <= 8)) // (a window row of MC_T16 is 32 samples: not for 4x16)
-        return w <= 8 && h <= 8 ? MC_T4 : MC_T16;
+    // (the region a job may touch is w + 26 samples wide at least and must hold a row of the class's window, w + 16 for
+    // the class's widest block: hence the lower bounds on w)
+    if (method <= X265_HIP_HEX)
+    {
+        if (w <= 8 && h <= 8)
+            return MC_T4;
+        if (w >= 8 && w <= 16 && h <= 16 && (h & 7) == 0)
+            return MC_T8;
+        if (w >= 24 && w <= 32 && h <= 32 && (w & 7) == 0 && (h & 7) == 0)
+            return MC_T32;
+    }
     return MC_REST;
 }
 

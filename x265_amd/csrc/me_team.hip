@@ -44,26 +44,37 @@ static_assert(sizeof(x265_hip_me_job) == 80 && offsetof(x265_hip_me_job, pu_x) =
 
 enum TeamState { TS_PRE, TS_DIA, TS_HEX1, TS_HEXN, TS_SQ, TS_POST_WAIT, TS_HPEL, TS_QPEL, TS_DONE };
 
+#ifndef TEAM_AH1
+#define TEAM_AH1 6 // rows in flight in the two-stage filter of the pre-tests (from the plane), single tiles / strips
+#endif
+#ifndef TEAM_AH2
+#define TEAM_AH2 0
+#endif
 #define TEAM_RY 6 // rows of the window above and below the block at its centre position
-// L lanes per team; the window of a team is ROWS rows of PITCH bytes, loaded in units of UNIT bytes, two per row
-template <int L>
-struct TeamGeo;
-template <>
-struct TeamGeo<4> // blocks up to 8x8
+// A class of blocks: L lanes per team, a lane owns a cell of CW x CH 4x4 tiles of the block (its source pixels stay in
+// registers for the whole call); the window of a team is ROWS rows of PITCH bytes, loaded in units of UNIT bytes.
+//   TeamT4   blocks up to 8x8:   4 lanes, cell = one tile            (16 calls per wave)
+//   TeamT8   blocks up to 16x16: 8 lanes, cell = a strip of 4 x 8    ( 8 calls per wave; 15 filtered rows per 8 rows of output
+//                                                                      instead of 2 x 11, ref_strip<2>)
+//   TeamT32  blocks up to 32x32: 16 lanes, cell = 8 x 8 (two strips) ( 4 calls per wave)
+struct TeamT4
 {
-    enum { PITCH = 24, ROWS = 8 + 2 * TEAM_RY, UNIT = 12, MAXW = 8 };
+    enum { L = 4, CW = 1, CH = 1, PITCH = 24, ROWS = 8 + 2 * TEAM_RY, UNIT = 12, CLS = MC_T4 };
 };
-template <>
-struct TeamGeo<16> // blocks up to 16x16
+struct TeamT8
 {
-    enum { PITCH = 32, ROWS = 16 + 2 * TEAM_RY, UNIT = 16, MAXW = 16 };
+    enum { L = 8, CW = 1, CH = 2, PITCH = 32, ROWS = 16 + 2 * TEAM_RY, UNIT = 16, CLS = MC_T8 };
 };
-template <int L>
+struct TeamT32
+{
+    enum { L = 16, CW = 2, CH = 2, PITCH = 48, ROWS = 32 + 2 * TEAM_RY, UNIT = 16, CLS = MC_T32 };
+};
+template <typename T>
 struct __attribute__((aligned(16))) TeamLds
 {
-    int cand[64 / L][TQ]; // candidate positions of the round, quarter-pel, (y << 16) | (x & 0xffff)
-    int cost[64 / L][TQ]; // the pre-tests' costs (the other rounds keep a running minimum)
-    uint8_t win[64 / L][TeamGeo<L>::PITCH * TeamGeo<L>::ROWS];
+    int cand[64 / T::L][TQ]; // candidate positions of the round, quarter-pel, (y << 16) | (x & 0xffff)
+    int cost[64 / T::L][TQ]; // the pre-tests' costs (the other rounds keep a running minimum)
+    uint8_t win[64 / T::L][T::PITCH * T::ROWS];
     uint8_t pad[16]; // a 12-byte row read at the window's last bytes runs into this
 };
 
@@ -82,57 +93,83 @@ __device__ __forceinline__ int team_sum(int v)
     return v;
 }
 
-// SAD or SATD of this lane's source tile against the reference tile at `r` (rows `stride` apart; PT: plane memory or
-// the LDS window, whose pitch is a constant) at fraction (xf, yf).  One path per pass of the wave, the cheapest that
-// serves all its lanes: full-pel, one-dimensional filter (a full-pel position goes through it with the tap row
-// {0,0,0,64,...}), two-stage filter (ditto).  frow / ft: the source tile by rows / by columns.
-template <typename PT, int AH>
-__device__ __forceinline__ int team_tile(const uint8_t *r, int stride, int xf, int yf, const uint32_t frow[4], const uint32_t ft[4], int metric)
+// SAD or SATD of this lane's source cell (CW x CH tiles, f[cx][row]) against the reference at `r` (rows `stride` apart;
+// PT: plane memory or the LDS window, whose pitch is a constant) at fraction (xf, yf).  One path per pass of the wave,
+// the cheapest that serves all its lanes.  A single tile (CW = CH = 1): full-pel, one-dimensional filter (a full-pel
+// position goes through it with the tap row {0,0,0,64,...}; ft: the source tile by columns), two-stage filter
+// (ditto).  Larger cells: strips of CH tiles through ref_strip (full-pel / horizontal / vertical / two-stage, the last
+// for all lanes of a pass as soon as one of them needs it).
+template <typename PT, int AH, int CW, int CH>
+__device__ __forceinline__ int team_cell(const uint8_t *r, int stride, int xf, int yf, const uint32_t (&f)[CW][4 * CH], const uint32_t ft[4], int metric)
 {
     const bool anyfrac = __ballot((xf | yf) != 0) != 0, anydiag = __ballot(xf != 0 && yf != 0) != 0;
     if (!anyfrac)
     {
-        uint32_t rr[4];
+        int v = 0;
 #pragma unroll
-        for (int y = 0; y < 4; y++)
-            rr[y] = ld4g((PT)r + y * stride);
-        if (metric == X265_HIP_SAD)
+        for (int cx = 0; cx < CW; cx++)
         {
-            uint32_t a = 0;
+            uint32_t rr[4 * CH];
+#pragma unroll
+            for (int y = 0; y < 4 * CH; y++)
+                rr[y] = ld4g((PT)r + (y * stride + 4 * cx));
+            if (metric == X265_HIP_SAD)
+            {
+                uint32_t a = 0;
+#pragma unroll
+                for (int y = 0; y < 4 * CH; y++)
+                    a = __builtin_amdgcn_sad_u8(f[cx][y], rr[y], a);
+                v += (int)a;
+            }
+            else
+            {
+#pragma unroll
+                for (int t = 0; t < CH; t++)
+                {
+                    uint32_t pix[4][2];
+#pragma unroll
+                    for (int y = 0; y < 4; y++)
+                    {
+                        pix[y][0] = __builtin_amdgcn_perm(0, rr[4 * t + y], 0x0c010c00);
+                        pix[y][1] = __builtin_amdgcn_perm(0, rr[4 * t + y], 0x0c030c02);
+                    }
+                    v += tile_metric_rows(&f[cx][4 * t], pix, X265_HIP_SATD);
+                }
+            }
+        }
+        return v;
+    }
+    if constexpr (CW == 1 && CH == 1)
+    {
+        if (!anydiag)
+        {
+            uint32_t pix[4][2], fs[4];
+            ref_tile_1d<PT>(r, stride, xf, yf, pix); // a vertical position comes back transposed
 #pragma unroll
             for (int y = 0; y < 4; y++)
-                a = __builtin_amdgcn_sad_u8(frow[y], rr[y], a);
-            return (int)a;
+                fs[y] = xf == 0 ? ft[y] : f[0][y];
+            return tile_metric_rows(fs, pix, metric);
         }
-        uint32_t pix[4][2];
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-        {
-            pix[y][0] = __builtin_amdgcn_perm(0, rr[y], 0x0c010c00);
-            pix[y][1] = __builtin_amdgcn_perm(0, rr[y], 0x0c030c02);
-        }
-        return tile_metric_rows(frow, pix, X265_HIP_SATD);
     }
-    if (!anydiag)
+    int v = 0;
+#pragma unroll
+    for (int cx = 0; cx < CW; cx++)
     {
-        uint32_t pix[4][2], fs[4];
-        ref_tile_1d<PT>(r, stride, xf, yf, pix); // a vertical position comes back transposed
+        uint32_t pix[4 * CH][2];
+        ref_strip<CH, false, AH, PT>(r + 4 * cx, stride, xf, yf, pix, anydiag);
 #pragma unroll
-        for (int y = 0; y < 4; y++)
-            fs[y] = xf == 0 ? ft[y] : frow[y];
-        return tile_metric_rows(fs, pix, metric);
+        for (int t = 0; t < CH; t++)
+            v += tile_metric_rows(&f[cx][4 * t], &pix[4 * t], metric);
     }
-    uint32_t pix[4][2];
-    ref_strip<1, false, AH, PT>(r, stride, xf, yf, pix, true);
-    return tile_metric_rows(frow, pix, metric);
+    return v;
 }
 
 // The searches of one chunk of a part's list: entries chunk * G .. chunk * G + G - 1, one per team.
-template <int L>
-__device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, const DeviceTables *tabs, const x265_hip_me_job *jobs, const uint32_t *list,
+template <typename T>
+__device__ __forceinline__ void team_chunk(TeamLds<T> &lds, const int *pat, const DeviceTables *tabs, const x265_hip_me_job *jobs, const uint32_t *list,
                                            uint32_t count, uint32_t chunk, x265_hip_me_result *out, int out_stride)
 {
-    constexpr int G = 64 / L, PITCH = TeamGeo<L>::PITCH, UNIT = TeamGeo<L>::UNIT;
+    constexpr int L = T::L, CW = T::CW, CH = T::CH, G = 64 / L, PITCH = T::PITCH, UNIT = T::UNIT;
     const int lane = threadIdx.x & 63, team = lane / L, tl = lane % L;
     const uint32_t e = chunk * G + team;
     const bool has_job = e < count;
@@ -151,22 +188,28 @@ __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, cons
     const uint16_t *const tab = tabs->costtab[qp];
     const int stride = rp.stride;
 
-    // this lane's tile
-    const int ntx = w >> 2, nt = ntx * (h >> 2);
-    const bool has_tile = tl < nt;
+    // this lane's cell
+    const int cells_x = w / (4 * CW), ncell = cells_x * (h / (4 * CH));
+    const bool has_tile = tl < ncell;
     const int tu = has_tile ? tl : 0;
-    const int ty = (int)(((float)tu + 0.5f) * __builtin_amdgcn_rcpf((float)ntx)), tx = tu - ty * ntx; // exact: tu < 16, ntx <= 16
-    uint32_t frow[4], ft[4]; // the source tile (setSourcePU, motion.cpp:110-126), by rows and by columns
+    const int ty = (int)(((float)tu + 0.5f) * __builtin_amdgcn_rcpf((float)cells_x)), tx = tu - ty * cells_x; // exact: tu < 16, cells_x <= 16
+    const int cell_x = 4 * CW * tx, cell_y = 4 * CH * ty;
+    uint32_t frow[CW][4 * CH], ft[4]; // the source pixels (setSourcePU, motion.cpp:110-126); a single tile also by columns
     {
-        const gptr_t f = as_global(fp.origin) + ((long)(pu_y + 4 * ty) * fp.stride + pu_x + 4 * tx);
+        const gptr_t f = as_global(fp.origin) + ((long)(pu_y + cell_y) * fp.stride + pu_x + cell_x);
+#pragma unroll
+        for (int cx = 0; cx < CW; cx++)
+#pragma unroll
+            for (int y = 0; y < 4 * CH; y++)
+                frow[cx][y] = ld4g(f + (y * fp.stride + 4 * cx));
 #pragma unroll
         for (int y = 0; y < 4; y++)
-            ft[y] = frow[y] = ld4g(f + y * fp.stride);
+            ft[y] = frow[0][y];
         transpose4x4_u8(ft);
     }
     const uint8_t *const pbase = rp.origin + ((long)pu_y * stride + pu_x); // the block's position in the reference plane
-    const int toff = 4 * ty * stride + 4 * tx;                             // this lane's tile inside the block, plane
-    const int ltoff = 4 * ty * PITCH + 4 * tx;                             // and window
+    const int toff = cell_y * stride + cell_x;                             // this lane's cell inside the block, plane
+    const int ltoff = cell_y * PITCH + cell_x;                             // and window
 
     // workload[subme] (motion.cpp:47-57)
     const int wsh = 4 * (subme & 7);
@@ -193,9 +236,9 @@ __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, cons
     const int gx0 = min(lox, 0) - over - 6, gx1 = max(hix, 0) + over + w + 16 - PITCH; // first / last start of a window row
     const int gy0 = min(loy, 0) - over - 3, gy1 = max(hiy, 0) + over + h + 3;          // first / last row
     auto load_window = [&](int ccx, int ccy, bool mine) {
-        // units u = 2 row + half, dealt to the lanes of the team; a lane's loads are in flight together, half of them
+        // units u = UPR row + half, dealt to the lanes of the team; a lane's loads are in flight together, half of them
         // at a time (registers)
-        constexpr int NU = (2 * TeamGeo<L>::ROWS + L - 1) / L, NH = (NU + 1) / 2;
+        constexpr int UPR = PITCH / UNIT, NU = (UPR * T::ROWS + L - 1) / L, NH = (NU + 1) / 2;
         // (the region is at least PITCH wide for the blocks of a class: w + 26 samples, me_job_class)
         const int nwx = min(max(ccx - rx, gx0), gx1), nwy = ccy - TEAM_RY;
 #pragma unroll
@@ -205,7 +248,7 @@ __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, cons
 #pragma unroll
             for (int k = 0; k < NH; k++)
             {
-                const int u = tl + (k0 + k) * L, row = u >> 1, half = u & 1;
+                const int u = tl + (k0 + k) * L, row = u / UPR, half = u - row * UPR;
                 const int ax = nwx + half * UNIT, ay = min(max(nwy + row, gy0), gy1);
                 // every lane loads (a lane without a unit, or of a team that keeps its window, from a valid address
                 // all the same): behind a branch per unit the loads waited for each other
@@ -224,7 +267,7 @@ __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, cons
 #pragma unroll
             for (int k = 0; k < NH; k++)
             {
-                const int u = tl + (k0 + k) * L, row = u >> 1, half = u & 1;
+                const int u = tl + (k0 + k) * L, row = u / UPR, half = u - row * UPR;
                 if (mine && k0 + k < NU && row < wrows)
                 {
                     __attribute__((address_space(3))) uint32_t *dst = (__attribute__((address_space(3))) uint32_t *)&lds.win[team][row * PITCH + half * UNIT];
@@ -330,30 +373,31 @@ __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, cons
                 typedef int i32x4 __attribute__((ext_vector_type(4)));
                 const i32x4 pv = *(const i32x4 *)&lds.cand[team][4 * g];
                 const int pos[4] = { pv.x, pv.y, pv.z, pv.w };
-                uint32_t rr[4][4];
                 int ta[4], tb[4];
+                ldsa_t r[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                 {
                     const bool act = ((vmask >> (4 * g + j)) & 1u) != 0;
                     const int qx = (int)(int16_t)pos[j], qy = pos[j] >> 16;
-                    const ldsa_t r((const uint8_t *)(act ? lbase + ((qy >> 2) * PITCH + (qx >> 2)) : (lptr_t)&lds.win[team][0]));
+                    r[j] = ldsa_t((const uint8_t *)(act ? lbase + ((qy >> 2) * PITCH + (qx >> 2)) : (lptr_t)&lds.win[team][0]));
                     ta[j] = tab_at(tab, mvpx, qx);
                     tb[j] = tab_at(tab, mvpy, qy);
-#pragma unroll
-                    for (int y = 0; y < 4; y++)
-                        rr[j][y] = ld4g(r + y * PITCH);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                 {
                     uint32_t a = 0;
 #pragma unroll
-                    for (int y = 0; y < 4; y++)
-                        a = __builtin_amdgcn_sad_u8(frow[y], rr[j][y], a);
+                    for (int cx = 0; cx < CW; cx++)
+#pragma unroll
+                        for (int y = 0; y < 4 * CH; y++)
+                            a = __builtin_amdgcn_sad_u8(frow[cx][y], ld4g(r[j] + (y * PITCH + 4 * cx)), a);
                     const int cost = team_sum<L>(has_tile ? (int)a : 0) + (int)(uint16_t)(ta[j] + tb[j]);
                     if ((vmask >> (4 * g + j)) & 1u)
                         key = min(key, (cost << 4) | (4 * g + j));
+                    if (CW * CH > 1) // (one candidate's window reads at a time: all four at once is 64 .. 128 registers)
+                        __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -374,9 +418,9 @@ __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, cons
                 // behind a branch the loads had a wait of their own in front of the pixel loads
                 const int ta = tab_at(tab, mvpx, qx), tb = tab_at(tab, mvpy, qy);
                 if (__ballot(pre) != 0) // the pre-tests (all teams of a wave are there together): from the plane
-                    v = team_tile<gptr_t, 11>(pbase + (toff + (qy >> 2) * stride + (qx >> 2)), stride, qx & 3, qy & 3, frow, ft, metric);
+                    v = team_cell<gptr_t, CH == 1 ? TEAM_AH1 : TEAM_AH2, CW, CH>(pbase + (toff + (qy >> 2) * stride + (qx >> 2)), stride, qx & 3, qy & 3, frow, ft, metric);
                 else
-                    v = team_tile<ldsa_t, 0>((const uint8_t *)(lbase + ((qy >> 2) * PITCH + (qx >> 2))), PITCH, qx & 3, qy & 3, frow, ft, metric);
+                    v = team_cell<ldsa_t, 0, CW, CH>((const uint8_t *)(lbase + ((qy >> 2) * PITCH + (qx >> 2))), PITCH, qx & 3, qy & 3, frow, ft, metric);
                 if (!has_tile)
                     v = 0;
                 seed = (pre && c == 0) ? 0 : (int)(uint16_t)(ta + tb);
@@ -589,15 +633,11 @@ __device__ __forceinline__ void team_chunk(TeamLds<L> &lds, const int *pat, cons
     wave_sync(); // the next chunk rewrites the lists
 }
 
-#ifndef ME_TEAM_WAVES
-#define ME_TEAM_WAVES 3
-#endif
-
-template <int L>
-__device__ __forceinline__ void team_lists(TeamLds<L> &lds, const int *pat, const DeviceTables *tabs, const x265_hip_me_job *jobs, uint32_t *route,
-                                           int parity, int cap, int cls, x265_hip_me_result *out, int out_stride)
+template <typename T>
+__device__ __forceinline__ void team_lists(TeamLds<T> &lds, const int *pat, const DeviceTables *tabs, const x265_hip_me_job *jobs, uint32_t *route,
+                                           int parity, int cap, x265_hip_me_result *out, int out_stride)
 {
-    constexpr int G = 64 / L;
+    constexpr int G = 64 / T::L, cls = T::CLS;
     const int p = blockIdx.x & (ME_PARTS - 1), waves = gridDim.x / ME_PARTS;
     const uint32_t count = min(*route_append(route, parity, cls, p), (uint32_t)cap);
     const uint32_t nchunk = (count + G - 1) / G;
@@ -605,7 +645,7 @@ __device__ __forceinline__ void team_lists(TeamLds<L> &lds, const int *pat, cons
     uint32_t k = blockIdx.x / ME_PARTS;
     while (k < nchunk)
     {
-        team_chunk<L>(lds, pat, tabs, jobs, list, count, k, out, out_stride);
+        team_chunk<T>(lds, pat, tabs, jobs, list, count, k, out, out_stride);
         k = 0;
         if ((threadIdx.x & 63) == 0)
             k = (uint32_t)waves + atomicAdd(route_handout(route, parity, cls, p), 1u);
@@ -613,37 +653,49 @@ __device__ __forceinline__ void team_lists(TeamLds<L> &lds, const int *pat, cons
     }
 }
 
-// gridDim.x is a multiple of ME_PARTS; every wave works through its part of the MC_T16 list, then of the MC_T4 list
-// (one launch for both: the second list fills the end of the first), and leaves when both hand-out counters have
-// passed the ends of the lists
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_TEAM_WAVES))) void me_team_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs,
-                                                                                                    uint32_t *route, int parity, int cap,
-                                                                                                    x265_hip_me_result *out, int out_stride)
+// gridDim.x is a multiple of ME_PARTS; a wave works through its part of the class's list and leaves when the hand-out
+// counter has passed the list's end.  A kernel per class: the classes differ in registers per lane (a cell of 8x8
+// samples and its filtered rows against a single tile), and one kernel for all ran at the occupancy of the largest.
+template <typename T, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void me_team_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs,
+                                                                                            uint32_t *route, int parity, int cap,
+                                                                                            x265_hip_me_result *out, int out_stride)
 {
-    __shared__ union TeamLdsBoth
-    {
-        TeamLds<16> t16;
-        TeamLds<4> t4;
-    } lds; // one list after the other
+    __shared__ TeamLds<T> lds;
     __shared__ int pat[PAT_N];
     if (threadIdx.x < PAT_N)
         pat[threadIdx.x] = k_pat[threadIdx.x];
     wave_sync();
-    team_lists<16>(lds.t16, pat, tabs, jobs, route, parity, cap, MC_T16, out, out_stride);
-    team_lists<4>(lds.t4, pat, tabs, jobs, route, parity, cap, MC_T4, out, out_stride);
+    team_lists<T>(lds, pat, tabs, jobs, route, parity, cap, out, out_stride);
 }
 
+#ifndef ME_T4_WAVES
+#define ME_T4_WAVES 3
+#endif
+#ifndef ME_T8_WAVES
+#define ME_T8_WAVES 2
+#endif
+#ifndef ME_T32_WAVES
+#define ME_T32_WAVES 2
+#endif
+
+template <typename T, int WAVES>
+static void launch_team_class(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, uint32_t *route, int parity, int cap, x265_hip_me_result *out,
+                              int out_stride, hipStream_t st)
+{
+    constexpr int G = 64 / T::L;
+    const int want = (n + ME_PARTS * G - 1) / (ME_PARTS * G), most = 256 * 4 * WAVES / ME_PARTS;
+    const int grid = ME_PARTS * (want < 1 ? 1 : want > most ? most : want);
+    hipLaunchKernelGGL((me_team_kernel<T, WAVES>), dim3(grid), dim3(64), 0, st, tabs, jobs, route, parity, cap, out, out_stride);
+}
+
+// largest blocks first: the shorter calls of the next class fill the end of a launch
 void launch_me_team(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, uint32_t *route, int parity, int cap, x265_hip_me_result *out,
                     int out_stride, hipStream_t st)
 {
-    static const int resident = [] {
-        const char *e = getenv("X265_HIP_ME_TEAM_GRID"); // experiments; a multiple of ME_PARTS
-        const int g = e ? atoi(e) : 0;
-        return g >= ME_PARTS ? g / ME_PARTS * ME_PARTS : 256 * 4 * ME_TEAM_WAVES;
-    }();
-    const int want = (n + ME_PARTS * 4 - 1) / (ME_PARTS * 4), most = resident / ME_PARTS;
-    const int grid = ME_PARTS * (want < 1 ? 1 : want > most ? most : want);
-    hipLaunchKernelGGL(me_team_kernel, dim3(grid), dim3(64), 0, st, tabs, jobs, route, parity, cap, out, out_stride);
+    launch_team_class<TeamT32, ME_T32_WAVES>(tabs, jobs, n, route, parity, cap, out, out_stride, st);
+    launch_team_class<TeamT8, ME_T8_WAVES>(tabs, jobs, n, route, parity, cap, out, out_stride, st);
+    launch_team_class<TeamT4, ME_T4_WAVES>(tabs, jobs, n, route, parity, cap, out, out_stride, st);
 }
 
 } // namespace x265hip
