@@ -230,6 +230,17 @@ int x265_hip_plane_extend_border(x265_hip_ctx *ctx, int plane_id, int width, int
  * correction of reference.cpp:95-98 is applied inside), then the border extension. */
 int x265_hip_plane_weight(x265_hip_ctx *ctx, int src_plane, int dst_plane, int width, int height, int margin_x,
                           int margin_y, int w0, int offset, int log2_denom);
+/* The same two for a range of picture rows, as the reference produces reference planes while a picture is being
+ * reconstructed: MotionReference::applyWeight(rows, numRows) weights and extends the CTU rows that have become
+ * available (source/encoder/reference.cpp:78-121), the frame filter extends each finished row's left and right margins
+ * (primitives.extendRowBorder, source/encoder/framefilter.cpp:221; C: extendCURowColBorder, source/common/
+ * ipfilter.cpp:56-74).  Picture rows row0 .. row0 + rows - 1 are produced with their side margins; a range that
+ * starts at row 0 also fills the rows above the picture, one that ends at the last row the rows below it.  Calling
+ * them for consecutive ranges that cover the picture gives byte for byte what the whole-picture forms give. */
+int x265_hip_plane_extend_border_rows(x265_hip_ctx *ctx, int plane_id, int width, int height, int margin_x, int margin_y, int row0,
+                                      int rows);
+int x265_hip_plane_weight_rows(x265_hip_ctx *ctx, int src_plane, int dst_plane, int width, int height, int margin_x, int margin_y,
+                               int w0, int offset, int log2_denom, int row0, int rows);
 
 /* One lambda-scaled MVD cost row as BitCost::setQP builds it (source/encoder/bitcost.cpp:31-56):
  * tab[32768 + d] = cost of difference d, d in [-32768, 32767].  The table is an input: it is made

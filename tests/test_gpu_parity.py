@@ -312,6 +312,42 @@ def test_plane_weight_and_border(oracle, small_seq):
     ctx.close()
 
 
+def test_plane_rows_as_they_become_available(oracle, small_seq):
+    """the row-range forms (MotionReference::applyWeight(rows, numRows), reference.cpp:78-121; the frame filter's
+    extendRowBorder, framefilter.cpp:221): CTU row by CTU row they must build the plane the whole-picture forms build,
+    and after every step the rows produced so far must already be final"""
+    from x265_amd import lib
+    ctx = lib.Context(0)
+    p = small_seq[1]
+    ctx.plane_upload(0, p.buf, p.stride, p.origin)
+    rows = np.arange(p.rows)[:, None]
+    cols = np.arange(p.stride)[None, :]
+    written = ((cols < p.w + 192) & (rows < p.h + 160))
+    ctu_rows = [(r, min(64, p.h - r)) for r in range(0, p.h, 64)]  # 64, 64, 64, 48
+    for (w0, off, den) in ((70, -3, 6), (37, 10, 5)):
+        want = oracle.weighted_plane(p.buf, p.origin, p.stride, p.w, p.h, w0, off, den).reshape(p.rows, p.stride)
+        ctx.plane_weight(0, 1, p.w, p.h, 1, 0, 0)  # something else in the destination first
+        for r0, n in ctu_rows:
+            ctx.plane_weight_rows(0, 1, p.w, p.h, w0, off, den, r0, n)
+            got = ctx.plane_download(1, p.buf.size).reshape(p.rows, p.stride)
+            done = written & (rows < 80 + r0 + n) if r0 + n < p.h else written
+            assert np.array_equal(got[done], want[done]), (w0, r0)
+    wiped = p.buf.reshape(p.rows, p.stride).copy()
+    inside = (rows >= 80) & (rows < 80 + p.h) & (cols >= 96) & (cols < 96 + p.w)
+    wiped[~inside] = 0x55
+    ctx.plane_upload(2, wiped.reshape(-1), p.stride, p.origin)
+    for r0, n in ctu_rows:
+        ctx.plane_extend_border_rows(2, p.w, p.h, r0, n)
+        got = ctx.plane_download(2, p.buf.size).reshape(p.rows, p.stride)
+        done = written & (rows < 80 + r0 + n) if r0 + n < p.h else written
+        assert np.array_equal(got[done], p.buf.reshape(p.rows, p.stride)[done]), r0
+        if r0 + n < p.h:  # rows not yet available are untouched
+            assert (got[80 + r0 + n:, :96] == 0x55).all()
+    with pytest.raises(lib.X265HipError):
+        ctx.plane_extend_border_rows(2, p.w, p.h, 200, 64)  # past the last row
+    ctx.close()
+
+
 @pytest.mark.parametrize("n", [1, 33, 2500])
 def test_bidir_cost_batch(gpu_ctx, oracle, small_seq, n):
     """x265_hip_bidir_cost_batch: block vs the rounded average of two interpolated predictions"""
@@ -883,6 +919,40 @@ def test_large_block_jobs_and_their_routing(oracle, small_seq, costtabs, one_str
         got = o.download(abi.ME_RESULT, len(jobs))
         assert np.array_equal(got, want), (k, "device", np.nonzero(got != want)[0][:5])
         assert np.array_equal(ctx.me_batch(jobs), want), (k, "host")
+    ctx.close()
+
+
+def test_long_lists_search_32x32_blocks_in_teams(oracle, small_seq, costtabs):
+    """lists of 262,144 calls and more send their 32x32, 32x16, 32x24, 24x32, 32x8 blocks to me_team_kernel's class of
+    8x8 cells (shorter lists to me_rest_kernel, me_launch_both): a short list repeated to that length, DIA and HEX at
+    every sub-pel level, every copy against the oracle"""
+    from x265_amd import abi, lib, synth
+    from x265_amd.hipmem import DeviceBuffer
+    ctx = lib.Context(0)
+    for i, p in enumerate(small_seq):
+        ctx.plane_upload(i, p.buf, p.stride, p.origin)
+    for q, t in costtabs.items():
+        ctx.costtab_upload(q, t)
+    rng = np.random.default_rng(3232)
+    W, H = small_seq[0].w, small_seq[0].h
+    t32 = [i for i in range(1, 25) if 24 <= abi.PARTS[i][0] <= 32 and abi.PARTS[i][1] <= 32 and abi.PARTS[i][0] % 8 == 0 and abi.PARTS[i][1] % 8 == 0]
+    assert sorted(abi.PARTS[i] for i in t32) == [(24, 32), (32, 8), (32, 16), (32, 24), (32, 32)]
+    mixed = t32 * 3 + list(range(1, 25))
+    for method in (abi.DIA, abi.HEX):
+        for subme in range(8):
+            table = [abi.PARTS[0]] + [abi.PARTS[mixed[int(rng.integers(len(mixed)))]] for _ in range(24)]
+            jobs = random_me_jobs(rng, 150, method, subme, W, H, abi.ME_JOB, synth.search_range, table)
+            want = oracle.me_batch(_planes(small_seq), costtabs, jobs)
+            reps = 262144 // len(jobs) + 1
+            d = DeviceBuffer.from_array(np.tile(jobs, reps))
+            o = DeviceBuffer(reps * len(jobs) * abi.ME_RESULT.itemsize)
+            ctx.me_batch_device(d.ptr, reps * len(jobs), o.ptr)
+            ctx.sync()
+            got = o.download(abi.ME_RESULT, reps * len(jobs)).reshape(reps, len(jobs))
+            bad = np.nonzero((got != want[None, :]).any(axis=0))[0]
+            assert len(bad) == 0, f"method {method} subme {subme}: job {jobs[bad[0]]} got {got[:, bad[0]][:4]} want {want[bad[0]]}"
+            d.free()
+            o.free()
     ctx.close()
 
 

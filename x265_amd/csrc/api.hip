@@ -689,6 +689,22 @@ static int border_args(x265_hip_ctx *c, const char *who, int src, int dst, int w
     a.margin_y = my;
     a.weighted = 0;
     a.w0 = a.round = a.shift = a.offset = 0;
+    a.py0 = 0;
+    a.pyn = height + 2 * my;
+    return 0;
+}
+
+// Picture rows row0 .. row0 + rows - 1 become available (a CTU row of a frame encoder, say): the padded rows that
+// depend on them alone -- these rows with their left and right margins, the rows above the picture with row 0, the
+// rows below it with the last row -- as MotionReference::applyWeight (reference.cpp:78-121) and the frame filter's
+// extendRowBorder (framefilter.cpp:221, ipfilter.cpp:56-74) produce them row by row.
+static int border_rows(const char *who, int height, int my, int row0, int rows, PlaneBorderArgs &a)
+{
+    if (row0 < 0 || rows <= 0 || row0 + rows > height)
+        return fail(X265_HIP_EINVAL, "%s: rows %d .. %d outside the picture's %d", who, row0, row0 + rows - 1, height);
+    const int first = row0 == 0 ? 0 : my + row0, last = row0 + rows == height ? height + 2 * my : my + row0 + rows;
+    a.py0 = first;
+    a.pyn = last - first;
     return 0;
 }
 
@@ -706,8 +722,37 @@ int x265_hip_plane_extend_border(x265_hip_ctx *c, int id, int width, int height,
     return X265_HIP_OK;
 }
 
+int x265_hip_plane_extend_border_rows(x265_hip_ctx *c, int id, int width, int height, int mx, int my, int row0, int rows)
+{
+    if (!c || id < 0 || id >= X265_HIP_MAX_PLANES)
+        return fail(X265_HIP_EINVAL, "plane_extend_border_rows: bad plane id %d", id);
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    PlaneBorderArgs a;
+    int r = border_args(c, "plane_extend_border_rows", id, id, width, height, mx, my, a);
+    if (r || (r = border_rows("plane_extend_border_rows", height, my, row0, rows, a)))
+        return r;
+    LAUNCH(launch_plane_border(a, c->stream));
+    return X265_HIP_OK;
+}
+
+static int plane_weight_impl(x265_hip_ctx *c, int src, int dst, int width, int height, int mx, int my, int w0, int offset, int log2_denom,
+                             int row0, int rows);
+
 int x265_hip_plane_weight(x265_hip_ctx *c, int src, int dst, int width, int height, int mx, int my, int w0, int offset,
                           int log2_denom)
+{
+    return plane_weight_impl(c, src, dst, width, height, mx, my, w0, offset, log2_denom, 0, height);
+}
+
+int x265_hip_plane_weight_rows(x265_hip_ctx *c, int src, int dst, int width, int height, int mx, int my, int w0, int offset,
+                               int log2_denom, int row0, int rows)
+{
+    return plane_weight_impl(c, src, dst, width, height, mx, my, w0, offset, log2_denom, row0, rows);
+}
+
+static int plane_weight_impl(x265_hip_ctx *c, int src, int dst, int width, int height, int mx, int my, int w0, int offset, int log2_denom,
+                             int row0, int rows)
 {
     if (!c || src < 0 || src >= X265_HIP_MAX_PLANES || dst < 0 || dst >= X265_HIP_MAX_PLANES || src == dst ||
         log2_denom < 0 || log2_denom > 7)
@@ -726,7 +771,8 @@ int x265_hip_plane_weight(x265_hip_ctx *c, int src, int dst, int width, int heig
     }
     int r = plane_set(c, dst, c->owned_plane[dst], bytes, c->host_tabs.planes[src].stride, c->plane_origin[src]);
     PlaneBorderArgs a;
-    if (r || (r = border_args(c, "plane_weight", src, dst, width, height, mx, my, a)))
+    if (r || (r = border_args(c, "plane_weight", src, dst, width, height, mx, my, a)) ||
+        (r = border_rows("plane_weight", height, my, row0, rows, a)))
         return r;
     // MotionReference::init / applyWeight, reference.cpp:57-61, 95-98
     const int round = log2_denom ? 1 << (log2_denom - 1) : 0;
@@ -2009,6 +2055,8 @@ int prim_weight(const uint8_t *src, uint8_t *dst, intptr_t ss, intptr_t ds, int 
     a.width = width;
     a.height = height;
     a.margin_x = a.margin_y = 0;
+    a.py0 = 0;
+    a.pyn = height;
     a.weighted = 1;
     a.w0 = w0;
     a.round = round;

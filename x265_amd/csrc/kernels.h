@@ -44,6 +44,7 @@ struct PlaneBorderArgs
     int stride;         // both planes
     int width, height, margin_x, margin_y;
     int weighted, w0, round, shift, offset; // weight_pp arguments as applyWeight passes them
+    int py0, pyn; // padded rows py0 .. py0 + pyn - 1 of the height + 2 margin_y are produced (all of them: 0, height + 2 margin_y)
 };
 
 void launch_lowres_init(const LowresArgs &a, hipStream_t st);

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void lowres_init_kernel(LowresArgs a)
 __global__ __launch_bounds__(256) void plane_border_kernel(PlaneBorderArgs a)
 {
     const int px4 = blockIdx.x * 256 + threadIdx.x;
-    const int py = blockIdx.y;
+    const int py = a.py0 + blockIdx.y;
     const int padw = a.width + 2 * a.margin_x;
     if (4 * px4 >= padw)
         return;
@@ -106,8 +106,9 @@ __global__ __launch_bounds__(256) void plane_border_kernel(PlaneBorderArgs a)
 
 void launch_plane_border(const PlaneBorderArgs &a, hipStream_t st)
 {
-    const int padw = a.width + 2 * a.margin_x, padh = a.height + 2 * a.margin_y;
-    hipLaunchKernelGGL(plane_border_kernel, dim3(((padw + 3) / 4 + 255) / 256, padh), dim3(256), 0, st, a);
+    const int padw = a.width + 2 * a.margin_x;
+    if (a.pyn > 0)
+        hipLaunchKernelGGL(plane_border_kernel, dim3(((padw + 3) / 4 + 255) / 256, a.pyn), dim3(256), 0, st, a);
 }
 
 void launch_lowres_init(const LowresArgs &a, hipStream_t st)

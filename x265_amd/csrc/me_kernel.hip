@@ -1580,7 +1580,7 @@ __global__ __launch_bounds__(256) void me_route_kernel(const x265_hip_me_job *jo
     if (i < n)
     {
         cls = me_job_class(jobs[i].pu_w, jobs[i].pu_h, jobs[i].method);
-        if (!team_on && cls >= MC_T4)
+        if ((!team_on && cls >= MC_T4) || (team_on == 2 && cls == MC_T32))
             cls = MC_REST;
     }
     const int p = (i >> 6) & (ME_PARTS - 1);
@@ -2396,6 +2396,10 @@ static int list_grid(int n, int per_wave, int resident)
     return ME_PARTS * (want < 1 ? 1 : want > most ? most : want);
 }
 
+#ifndef ME_T32_MIN_JOBS
+#define ME_T32_MIN_JOBS 262144
+#endif
+
 static void me_launch_both(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, int out_stride, const MeRoute &r)
 {
     if (n <= 0)
@@ -2406,7 +2410,12 @@ static void me_launch_both(const DeviceTables *tabs, const x265_hip_me_job *jobs
         return;
     }
     const int cap = me_route_cap(n), parity = r.parity & 1;
-    static const int team_on = env_int("X265_HIP_ME_TEAM", 1); // experiments: 0 sends the small searches to me_kernel
+    // experiments: 0 sends the small searches to me_rest_kernel, 2 those of MC_T32, 2 those of MC_T32 whatever the length of the list
+    static const int team_env = env_int("X265_HIP_ME_TEAM", 1);
+    // Four 32x32 calls share a wave in me_team_kernel and take as long as the longest of them: worth it when there are
+    // waves enough to fill the chip all the same (a 4K picture's list: 0.956 against 0.971 ms), not for a short list
+    // (a 1080p picture's 128,700 calls: 0.299 against 0.283 ms; profiles/r03_team_order.txt)
+    const int team_on = team_env == 1 && n < ME_T32_MIN_JOBS ? 2 : team_env;
     // The lists first (made beside the searches on a side stream the kernel had to find room among their workgroups and
     // sometimes ended with them: nothing ran side by side), then the big jobs on the side stream and the other jobs on
     // the main one: the small jobs fill what the big ones leave idle (their last round, or most of the chip when
@@ -2425,7 +2434,7 @@ static void me_launch_both(const DeviceTables *tabs, const x265_hip_me_job *jobs
     const int bg = list_grid(n, 1, big_grid);
     hipLaunchKernelGGL(me_big_kernel, dim3(bg), dim3(64), 0, sb, tabs, jobs, r.route, parity, cap, out, out_stride);
     if (team_on)
-        launch_me_team(tabs, jobs, n, r.route, parity, cap, out, out_stride, r.stream);
+        launch_me_team(tabs, jobs, n, r.route, parity, cap, out, out_stride, r.stream, team_on != 2);
     hipLaunchKernelGGL(me_rest_kernel, dim3(list_grid(n, 1, 256 * 4 * ME_REST_WAVES)), dim3(64), 0, r.stream, tabs, jobs, r.route, parity, cap, out, out_stride);
     if (r.side)
     {

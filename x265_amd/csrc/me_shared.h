@@ -52,9 +52,9 @@ __device__ __forceinline__ constexpr uint32_t workload_column(int c)
 //            me_big_kernel (one wave per call, strips of 16 x 4 pixels / stacked tiles, 4 waves per SIMD)
 //   MC_T4    diamond / hexagon searches of blocks up to 8x8, full-resolution reference: me_team_kernel, sixteen calls
 //            per wave in lockstep (a team of 4 lanes per call, one lane per 4x4 tile)
-//   MC_T8    the same for 16x16, 16x8, 8x16, 12x16: eight calls per wave, a team of 8 lanes, one lane per 4x8 strip
+//   MC_T8    the same for 16x16, 16x8, 8x16, 12x16, 8x8 ...: four calls per wave, a team of 16 lanes, one lane per tile
 //   MC_T32   the same for 32x32, 32x16, 32x24, 24x32, 32x8: four calls per wave, a team of 16 lanes, one lane per 8x8 cell
-//   MC_REST  everything else (UMH / STAR / FULL, Lowres references, 32x32 ...): me_rest_kernel, one wave per call
+//   MC_REST  everything else (UMH / STAR / FULL, Lowres references, odd sizes): me_rest_kernel, one wave per call
 // A list per kind is kept in ME_PARTS parts (one counter for a whole grid would serialise: an atomic on one address
 // takes ~12 ns): the jobs of one wave of me_route_kernel (64 consecutive jobs) go to one part, consecutive waves to
 // consecutive parts, and part p is served by the waves p, p + ME_PARTS, ... of the kind's kernel, which all run on one
@@ -111,6 +111,6 @@ __host__ __device__ inline int me_job_class(int w, int h, int method)
 
 // me_team.hip
 void launch_me_team(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, uint32_t *route, int parity, int cap, x265_hip_me_result *out,
-                    int out_stride, hipStream_t st);
+                    int out_stride, hipStream_t st, bool with_t32);
 
 } // namespace x265hip

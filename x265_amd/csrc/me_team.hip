@@ -30,6 +30,7 @@
 // Results are those of me_kernel bit for bit (same candidates, same order, same ties); tests/test_gpu_parity.py and
 // the encoder captures run through this kernel whenever a list has such jobs (me_job_class, me_shared.h).
 #include <stddef.h>
+#include <type_traits>
 
 #include "me_shared.h"
 
@@ -45,7 +46,7 @@ static_assert(sizeof(x265_hip_me_job) == 80 && offsetof(x265_hip_me_job, pu_x) =
 enum TeamState { TS_PRE, TS_DIA, TS_HEX1, TS_HEXN, TS_SQ, TS_POST_WAIT, TS_HPEL, TS_QPEL, TS_DONE };
 
 #ifndef TEAM_AH1
-#define TEAM_AH1 6 // rows in flight in the two-stage filter of the pre-tests (from the plane), single tiles / strips
+#define TEAM_AH1 11 // rows in flight in the two-stage filter of the pre-tests (from the plane), single tiles / strips
 #endif
 #ifndef TEAM_AH2
 #define TEAM_AH2 0
@@ -53,18 +54,29 @@ enum TeamState { TS_PRE, TS_DIA, TS_HEX1, TS_HEXN, TS_SQ, TS_POST_WAIT, TS_HPEL,
 #define TEAM_RY 6 // rows of the window above and below the block at its centre position
 // A class of blocks: L lanes per team, a lane owns a cell of CW x CH 4x4 tiles of the block (its source pixels stay in
 // registers for the whole call); the window of a team is ROWS rows of PITCH bytes, loaded in units of UNIT bytes.
-//   TeamT4   blocks up to 8x8:   4 lanes, cell = one tile            (16 calls per wave)
-//   TeamT8   blocks up to 16x16: 8 lanes, cell = a strip of 4 x 8    ( 8 calls per wave; 15 filtered rows per 8 rows of output
-//                                                                      instead of 2 x 11, ref_strip<2>)
-//   TeamT32  blocks up to 32x32: 16 lanes, cell = 8 x 8 (two strips) ( 4 calls per wave)
+//   TeamT4   blocks up to 8x8:   4 lanes,  cell = one tile            (16 calls per wave)
+//   TeamT8   blocks up to 16x16: 16 lanes, cell = one tile            ( 4 calls per wave).  With TEAM_T8_STRIPS: 8 lanes,
+//            cell = a strip of 4 x 8 (15 filtered rows per 8 rows of output instead of 2 x 11), which needs the registers
+//            of two waves per SIMD and measured slower
+//   TeamT32  blocks up to 32x32: 16 lanes, cell = 8 x 8 (two strips)  ( 4 calls per wave)
 struct TeamT4
 {
     enum { L = 4, CW = 1, CH = 1, PITCH = 24, ROWS = 8 + 2 * TEAM_RY, UNIT = 12, CLS = MC_T4 };
 };
+#ifndef TEAM_T8_STRIPS
+#define TEAM_T8_STRIPS 0 // measured: strips at two waves per SIMD 0.323 ms for the 16x16 calls of a 4K picture, tiles at three 0.294
+#endif
+#if TEAM_T8_STRIPS
 struct TeamT8
 {
     enum { L = 8, CW = 1, CH = 2, PITCH = 32, ROWS = 16 + 2 * TEAM_RY, UNIT = 16, CLS = MC_T8 };
 };
+#else
+struct TeamT8 // (16 lanes, a tile each)
+{
+    enum { L = 16, CW = 1, CH = 1, PITCH = 32, ROWS = 16 + 2 * TEAM_RY, UNIT = 16, CLS = MC_T8 };
+};
+#endif
 struct TeamT32
 {
     enum { L = 16, CW = 2, CH = 2, PITCH = 48, ROWS = 32 + 2 * TEAM_RY, UNIT = 16, CLS = MC_T32 };
@@ -230,7 +242,7 @@ __device__ __forceinline__ void team_chunk(TeamLds<T> &lds, const int *pat, cons
     // margins): a window at the edge of that region is shifted sideways into it and repeats its outermost rows instead
     // of reading outside the plane's buffer; no candidate of the search uses the repeated rows.
     const int wrows = h + 2 * TEAM_RY, rx = (PITCH - w) >> 1;
-    int wx = 0, wy = 0;
+    int wx = 0, wy = 0; // its origin
     bool wok = false; // the window holds something
     const int over = (method == X265_HIP_DIA ? 1 : 3) + (int)((0x22122111u >> wsh) & 15); // k_int_over + (k_qsteps + 3) / 4
     const int gx0 = min(lox, 0) - over - 6, gx1 = max(hix, 0) + over + w + 16 - PITCH; // first / last start of a window row
@@ -291,19 +303,21 @@ __device__ __forceinline__ void team_chunk(TeamLds<T> &lds, const int *pat, cons
     };
 
     // ---- the pre-tests' list (motion.cpp:551-598).  Slots are by kind, so that the passes of the round are of one
-    // kind for all teams: 0 the predictor (no mv rate), 1 its full-pel rounding (if the predictor is fractional), 2 the
-    // zero vector (if the predictor is not zero), 3 .. the candidate vectors that are neither zero nor the predictor,
-    // in list order ("m != bestpre", :584, is resolved when the costs are consumed)
-    uint32_t vmask = has_job ? (1u | (sub ? 2u : 0u) | (nz ? 4u : 0u)) : 0u; // the round's candidates, a bit per slot
+    // kind for all teams: 0 the predictor (no mv rate), 1 its full-pel rounding (if the predictor is fractional), 2 .. the
+    // candidate vectors that are neither zero nor the predictor, in list order ("m != bestpre", :584, is resolved when the
+    // costs are consumed), and last, in slot TQ - 1, the zero vector (if the predictor is not zero): the others mostly
+    // lie near the predictor and share a window, the zero vector needs one of its own
+    constexpr int ZSLOT = 2;
+        uint32_t vmask = has_job ? (1u | (sub ? 2u : 0u) | (nz ? 1u << ZSLOT : 0u)) : 0u; // the round's candidates, a bit per slot
     if (tl == 0)
     {
         lds.cand[team][0] = pack_mv(pmx, pmy);
         lds.cand[team][1] = pack_mv(s16(fpx << 2), s16(fpy << 2));
-        lds.cand[team][2] = 0;
+        lds.cand[team][ZSLOT] = 0;
     }
+    int npre = 3; // first slot behind the candidate vectors
     {
         const uint32_t mw[X265_HIP_MAX_MVC] = { m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, m2.x, m2.y, m2.z, m2.w };
-        int slot = 3;
 #pragma unroll
         for (int i = 0; i < X265_HIP_MAX_MVC; i++)
             if (i < nmvc)
@@ -312,10 +326,10 @@ __device__ __forceinline__ void team_chunk(TeamLds<T> &lds, const int *pat, cons
                 if ((mx | my) && !(mx == pmx && my == pmy))
                 {
                     if (tl == 0)
-                        lds.cand[team][slot] = pack_mv(mx, my);
+                        lds.cand[team][npre] = pack_mv(mx, my);
                     if (has_job)
-                        vmask |= 1u << slot;
-                    slot++;
+                        vmask |= 1u << npre;
+                    npre++;
                 }
             }
     }
@@ -359,12 +373,14 @@ __device__ __forceinline__ void team_chunk(TeamLds<T> &lds, const int *pat, cons
         int key = 0x7fffffff; // min over the round of (cost << 4) | index: the first minimum in visiting order
         const bool pre = st == TS_PRE;
         typedef const __attribute__((address_space(3))) uint8_t *lptr_t;
-        const lptr_t lbase = (lptr_t)&lds.win[team][0] + (ltoff - wy * PITCH - wx); // this lane's tile at the zero vector, were it in the window
+        // BitCost::mvcost (bitcost.h:45)
+        auto mv_rate = [&](int qx, int qy) { return (int)(uint16_t)(tab_at(tab, mvpx, qx) + tab_at(tab, mvpy, qy)); };
         if (__ballot(vmask != 0u && !(st >= TS_DIA && st <= TS_SQ)) == 0)
         {
             // A round of the integer stage for every team that has candidates: full-pel positions, SAD, out of the
             // windows.  Straight-line code over groups of four slots; slots without a candidate read the window's first
             // bytes and are not used.
+            const lptr_t lbase = (lptr_t)&lds.win[team][0] + (ltoff - wy * PITCH - wx); // this lane's cell at the zero vector, were it in the window
 #pragma unroll
             for (int g = 0; g < 2; g++)
             {
@@ -373,31 +389,56 @@ __device__ __forceinline__ void team_chunk(TeamLds<T> &lds, const int *pat, cons
                 typedef int i32x4 __attribute__((ext_vector_type(4)));
                 const i32x4 pv = *(const i32x4 *)&lds.cand[team][4 * g];
                 const int pos[4] = { pv.x, pv.y, pv.z, pv.w };
-                int ta[4], tb[4];
-                ldsa_t r[4];
+                // the rates are loads of device memory: all in flight before the first is used
+                int rate[4];
+                if constexpr (CW * CH > 1)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        rate[j] = mv_rate((int)(int16_t)pos[j], pos[j] >> 16);
+                if constexpr (CW * CH == 1)
+                {
+                    // single tiles: the four candidates' rows are all asked for before the first is used
+                    uint32_t rr[4][4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                    {
+                        const bool act = ((vmask >> (4 * g + j)) & 1u) != 0;
+                        const int qx = (int)(int16_t)pos[j], qy = pos[j] >> 16;
+                        rate[j] = mv_rate(qx, qy);
+                        const ldsa_t r((const uint8_t *)(act ? lbase + ((qy >> 2) * PITCH + (qx >> 2)) : (lptr_t)&lds.win[team][0]));
+#pragma unroll
+                        for (int y = 0; y < 4; y++)
+                            rr[j][y] = ld4g(r + y * PITCH);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                    {
+                        uint32_t a = 0;
+#pragma unroll
+                        for (int y = 0; y < 4; y++)
+                            a = __builtin_amdgcn_sad_u8(frow[0][y], rr[j][y], a);
+                        const int cost = team_sum<L>(has_tile ? (int)a : 0) + rate[j];
+                        if ((vmask >> (4 * g + j)) & 1u)
+                            key = min(key, (cost << 4) | (4 * g + j));
+                    }
+                }
+                else
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                 {
                     const bool act = ((vmask >> (4 * g + j)) & 1u) != 0;
                     const int qx = (int)(int16_t)pos[j], qy = pos[j] >> 16;
-                    r[j] = ldsa_t((const uint8_t *)(act ? lbase + ((qy >> 2) * PITCH + (qx >> 2)) : (lptr_t)&lds.win[team][0]));
-                    ta[j] = tab_at(tab, mvpx, qx);
-                    tb[j] = tab_at(tab, mvpy, qy);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                {
+                    const ldsa_t r((const uint8_t *)(act ? lbase + ((qy >> 2) * PITCH + (qx >> 2)) : (lptr_t)&lds.win[team][0]));
                     uint32_t a = 0;
 #pragma unroll
                     for (int cx = 0; cx < CW; cx++)
 #pragma unroll
                         for (int y = 0; y < 4 * CH; y++)
-                            a = __builtin_amdgcn_sad_u8(frow[cx][y], ld4g(r[j] + (y * PITCH + 4 * cx)), a);
-                    const int cost = team_sum<L>(has_tile ? (int)a : 0) + (int)(uint16_t)(ta[j] + tb[j]);
-                    if ((vmask >> (4 * g + j)) & 1u)
+                            a = __builtin_amdgcn_sad_u8(frow[cx][y], ld4g(r + (y * PITCH + 4 * cx)), a);
+                    const int cost = team_sum<L>(has_tile ? (int)a : 0) + rate[j];
+                    if (act)
                         key = min(key, (cost << 4) | (4 * g + j));
-                    if (CW * CH > 1) // (one candidate's window reads at a time: all four at once is 64 .. 128 registers)
-                        __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0); // (one candidate's window reads at a time: all four at once is 64 .. 128 registers)
                 }
             }
         }
@@ -409,21 +450,23 @@ __device__ __forceinline__ void team_chunk(TeamLds<T> &lds, const int *pat, cons
             const bool act = ((vmask >> c) & 1u) != 0;
             if (__ballot(act) == 0)
                 continue;
+            const bool from_plane = __ballot(pre) != 0; // (all teams of a wave are in the pre-tests together)
             int v = 0, seed = 0;
             if (act)
             {
                 const int pos = lds.cand[team][c];
                 const int qx = (int)(int16_t)pos, qy = pos >> 16;
-                // BitCost::mvcost (bitcost.h:45); the predictor's own test has none (:559).  Loaded whether used or not:
-                // behind a branch the loads had a wait of their own in front of the pixel loads
-                const int ta = tab_at(tab, mvpx, qx), tb = tab_at(tab, mvpy, qy);
-                if (__ballot(pre) != 0) // the pre-tests (all teams of a wave are there together): from the plane
+                const int rate = mv_rate(qx, qy);
+                if (from_plane)
                     v = team_cell<gptr_t, CH == 1 ? TEAM_AH1 : TEAM_AH2, CW, CH>(pbase + (toff + (qy >> 2) * stride + (qx >> 2)), stride, qx & 3, qy & 3, frow, ft, metric);
                 else
+                {
+                    const lptr_t lbase = (lptr_t)&lds.win[team][0] + (ltoff - wy * PITCH - wx);
                     v = team_cell<ldsa_t, 0, CW, CH>((const uint8_t *)(lbase + ((qy >> 2) * PITCH + (qx >> 2))), PITCH, qx & 3, qy & 3, frow, ft, metric);
+                }
                 if (!has_tile)
                     v = 0;
-                seed = (pre && c == 0) ? 0 : (int)(uint16_t)(ta + tb);
+                seed = (pre && c == 0) ? 0 : rate; // the predictor's own test has no rate (:559)
             }
             const int cost = team_sum<L>(v) + seed;
             if (act)
@@ -454,7 +497,7 @@ __device__ __forceinline__ void team_chunk(TeamLds<T> &lds, const int *pat, cons
                 bcost = lds.cost[team][1]; // full-pel start re-measured with its mv rate (:562-567)
             if (nz)
             {
-                const int cz = lds.cost[team][2]; // zero vector (:570-578)
+                const int cz = lds.cost[team][ZSLOT]; // zero vector (:570-578)
                 if (cz < bcost)
                 {
                     bcost = cz;
@@ -653,49 +696,56 @@ __device__ __forceinline__ void team_lists(TeamLds<T> &lds, const int *pat, cons
     }
 }
 
-// gridDim.x is a multiple of ME_PARTS; a wave works through its part of the class's list and leaves when the hand-out
-// counter has passed the list's end.  A kernel per class: the classes differ in registers per lane (a cell of 8x8
-// samples and its filtered rows against a single tile), and one kernel for all ran at the occupancy of the largest.
-template <typename T, int WAVES>
+// gridDim.x is a multiple of ME_PARTS; a wave works through its part of the list of class A, then of class B (one launch
+// for two classes of equal register needs: the shorter calls of the second fill the end of the first), and leaves when
+// the hand-out counters have passed the ends of the lists.  The class of 8x8 cells takes more registers per lane (its
+// source cell and filtered rows) and has a kernel of its own at a lower occupancy.
+template <typename A, typename B, int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void me_team_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs,
                                                                                             uint32_t *route, int parity, int cap,
                                                                                             x265_hip_me_result *out, int out_stride)
 {
-    __shared__ TeamLds<T> lds;
+    __shared__ union TeamLdsBoth
+    {
+        TeamLds<A> a;
+        TeamLds<B> b;
+    } lds; // one list after the other
     __shared__ int pat[PAT_N];
     if (threadIdx.x < PAT_N)
         pat[threadIdx.x] = k_pat[threadIdx.x];
     wave_sync();
-    team_lists<T>(lds, pat, tabs, jobs, route, parity, cap, out, out_stride);
+    team_lists<A>(lds.a, pat, tabs, jobs, route, parity, cap, out, out_stride);
+    if constexpr (!std::is_same<A, B>::value)
+        team_lists<B>(lds.b, pat, tabs, jobs, route, parity, cap, out, out_stride);
 }
 
 #ifndef ME_T4_WAVES
 #define ME_T4_WAVES 3
 #endif
-#ifndef ME_T8_WAVES
-#define ME_T8_WAVES 2
-#endif
 #ifndef ME_T32_WAVES
 #define ME_T32_WAVES 2
 #endif
 
-template <typename T, int WAVES>
-static void launch_team_class(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, uint32_t *route, int parity, int cap, x265_hip_me_result *out,
-                              int out_stride, hipStream_t st)
+template <typename A, typename B, int WAVES>
+static void launch_team_classes(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, uint32_t *route, int parity, int cap, x265_hip_me_result *out,
+                                int out_stride, hipStream_t st)
 {
-    constexpr int G = 64 / T::L;
+    constexpr int G = 64 / (A::L > B::L ? A::L : B::L);
     const int want = (n + ME_PARTS * G - 1) / (ME_PARTS * G), most = 256 * 4 * WAVES / ME_PARTS;
     const int grid = ME_PARTS * (want < 1 ? 1 : want > most ? most : want);
-    hipLaunchKernelGGL((me_team_kernel<T, WAVES>), dim3(grid), dim3(64), 0, st, tabs, jobs, route, parity, cap, out, out_stride);
+    hipLaunchKernelGGL((me_team_kernel<A, B, WAVES>), dim3(grid), dim3(64), 0, st, tabs, jobs, route, parity, cap, out, out_stride);
 }
 
-// largest blocks first: the shorter calls of the next class fill the end of a launch
+// The classes of single tiles first and the class of 8x8 cells behind them (measured on the ME-stage list of a 4K
+// picture, profiles/r03_team_order.txt: 0.956 ms; the 8x8 cells first 1.003, on the side stream behind me_big_kernel
+// 1.005, in me_rest_kernel instead 0.971): me_big_kernel runs beside the first of these kernels, and its waves of 128
+// registers share a SIMD with waves of 168 better than with waves of 224.
 void launch_me_team(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, uint32_t *route, int parity, int cap, x265_hip_me_result *out,
-                    int out_stride, hipStream_t st)
+                    int out_stride, hipStream_t st, bool with_t32)
 {
-    launch_team_class<TeamT32, ME_T32_WAVES>(tabs, jobs, n, route, parity, cap, out, out_stride, st);
-    launch_team_class<TeamT8, ME_T8_WAVES>(tabs, jobs, n, route, parity, cap, out, out_stride, st);
-    launch_team_class<TeamT4, ME_T4_WAVES>(tabs, jobs, n, route, parity, cap, out, out_stride, st);
+    launch_team_classes<TeamT8, TeamT4, ME_T4_WAVES>(tabs, jobs, n, route, parity, cap, out, out_stride, st);
+    if (with_t32)
+        launch_team_classes<TeamT32, TeamT32, ME_T32_WAVES>(tabs, jobs, n, route, parity, cap, out, out_stride, st);
 }
 
 } // namespace x265hip

@@ -40,6 +40,7 @@ EXPORTS = [
     "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device", "x265_hip_ctx_check_records", "x265_hip_refine_sections_device",
     "x265_hip_host_alloc", "x265_hip_host_free", "x265_hip_plane_alloc", "x265_hip_plane_upload_async", "x265_hip_download_async",
     "x265_hip_copy_wait_compute", "x265_hip_compute_wait_copy", "x265_hip_copy_sync",
+    "x265_hip_plane_extend_border_rows", "x265_hip_plane_weight_rows",
 ]
 
 
@@ -226,6 +227,15 @@ class Context:
         _check(load().x265_hip_plane_weight(self._h, C.c_int(src_plane), C.c_int(dst_plane), C.c_int(width),
                                             C.c_int(height), C.c_int(margin_x), C.c_int(margin_y), C.c_int(w0),
                                             C.c_int(offset), C.c_int(log2_denom)))
+
+    def plane_extend_border_rows(self, plane_id, width, height, row0, rows, margin_x=96, margin_y=80):
+        _check(load().x265_hip_plane_extend_border_rows(self._h, C.c_int(plane_id), C.c_int(width), C.c_int(height),
+                                                        C.c_int(margin_x), C.c_int(margin_y), C.c_int(row0), C.c_int(rows)))
+
+    def plane_weight_rows(self, src_plane, dst_plane, width, height, w0, offset, log2_denom, row0, rows, margin_x=96, margin_y=80):
+        _check(load().x265_hip_plane_weight_rows(self._h, C.c_int(src_plane), C.c_int(dst_plane), C.c_int(width),
+                                                 C.c_int(height), C.c_int(margin_x), C.c_int(margin_y), C.c_int(w0),
+                                                 C.c_int(offset), C.c_int(log2_denom), C.c_int(row0), C.c_int(rows)))
 
     def costtab_upload(self, qp, tab):
         tab = np.ascontiguousarray(tab, np.uint16)
