@@ -72,6 +72,7 @@ struct RingSections
 struct RingLds
 {
     int pre[RF_BATCH + 1]; // exclusive prefix of the requests' strip counts
+    int prea[RF_BATCH + 1]; // ... counting only the requests whose side columns are horizontal-only (ring_strip's hz_only)
     int cost[RF_BATCH * X265_HIP_RING_COSTS];
     const uint8_t *fenc[RF_BATCH]; // PU origin in the source plane
     const uint8_t *ref[RF_BATCH];  // PU origin in the reference plane
@@ -85,9 +86,13 @@ __device__ __forceinline__ int rf_s16(int v) { return (int)(int16_t)v; }
 // One strip of NT tiles for one horizontal position: `src` is the reference at row iy(-1) - 3, column ix - 3 of
 // the strip; jneed says which vertical positions this lane wants, tj[j] their tap windows (fraction * 2 + delta).
 // Adds the lane's costs into cost[sq[j]].
+// hz_only (the same for every lane of the pass): each lane wants the middle vertical position alone and that position
+// is a full row (the side columns of a four-point ring around a centre whose y is whole, e.g. the half-pel ring around
+// an integer winner): the strip's own 4 NT rows filtered horizontally are the prediction, luma_hpp's (S + 32) >> 6
+// (ipfilter.cpp:76-115) -- no rows above and below, no vertical pass.  `src` is then the strip's row -3 all the same.
 template <int NT>
 __device__ __forceinline__ void ring_strip(gptr_t src, int stride, int fx, int jneed, const int tj[3], const uint32_t *taps_lds,
-                                           const uint8_t *f, int fstride, int metric, int *cost, const int sq[3])
+                                           const uint8_t *f, int fstride, int metric, int *cost, const int sq[3], bool hz_only)
 {
     constexpr int NP = 2 * NT + 4; // row pairs: rows 0 .. 4 NT + 7
     uint32_t q[NP][4];
@@ -99,6 +104,43 @@ __device__ __forceinline__ void ring_strip(gptr_t src, int stride, int fx, int j
 #pragma unroll
         for (int y = 0; y < 4 * NT; y++, fp += lf)
             frow[y] = ld4g(fp);
+    }
+    if (hz_only)
+    {
+        const uint32_t tlo = k_taps_s8[fx][0], thi = k_taps_s8[fx][1];
+        const long lstride = stride;
+        gptr_t rp = src + 3 * lstride;
+        uint32_t w[4 * NT][3];
+#pragma unroll
+        for (int y = 0; y < 4 * NT; y++, rp += lstride)
+            ld12g(rp, w[y][0], w[y][1], w[y][2]);
+        uint32_t P[4 * NT][2];
+#pragma unroll
+        for (int y = 0; y < 4 * NT; y++)
+        {
+            int o[4];
+            // the taps run over p - 128: S + 32 = o + 64 * 128 + 32; (S + 32) >> 6, clamped to 0 .. 255, as int16 pairs
+            tap8x4<8192 + 32>(w[y][0] ^ 0x80808080u, w[y][1] ^ 0x80808080u, w[y][2] ^ 0x80808080u, tlo, thi, o);
+            const s16x2 lo = { 0, 0 }, hi255 = { 255, 255 };
+            const s16x2 p0 = as_s2(pack_s16(o[0] >> 6, o[1] >> 6)), p1 = as_s2(pack_s16(o[2] >> 6, o[3] >> 6));
+            P[y][0] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(p0, lo), hi255));
+            P[y][1] = as_u32(__builtin_elementwise_min(__builtin_elementwise_max(p1, lo), hi255));
+        }
+        int v = 0;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+        {
+            uint32_t fa[4], fb[4];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+            {
+                fa[y] = __builtin_amdgcn_perm(0, frow[4 * t + y], 0x0c010c00);
+                fb[y] = __builtin_amdgcn_perm(0, frow[4 * t + y], 0x0c030c02);
+            }
+            v += tile_metric_pairs(fa, fb, &P[4 * t], metric);
+        }
+        atomicAdd(&cost[sq[1]], v);
+        return;
     }
     // ---- horizontal pass: rows 2p, 2p + 1 as vertical pairs ---------------------------------------------------------
     if (__ballot(fx != 0) == 0)
@@ -307,6 +349,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RF_WAVES)))
             locate(batch_of(b), base, limit, bsize);
         const bool have = lane < bsize && base + lane < limit;
         int ns = 0; // strips of this lane's request
+        const bool cur_eight = (cur.pattern & X265_HIP_RING_8) != 0;
+        const int cur_cy = cur.qmv_y;
         if (have)
         {
             const PlaneDesc fp = tabs->planes[cur.fenc_plane], rp = tabs->planes[cur.ref_plane];
@@ -320,20 +364,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RF_WAVES)))
                            (((cur.pattern & X265_HIP_RING_8) ? 1 : 0) << 9) | (((cur.pattern & X265_HIP_RING_CENTRE) ? 1 : 0) << 10);
             L.qmv[lane] = (int)(((uint32_t)(uint16_t)cur.qmv_y << 16) | (uint16_t)cur.qmv_x);
         }
-        if (lane < RF_BATCH)
         {
-            // inclusive scan over lanes 0..31: row_shr 1, 2, 4, 8 inside each 16-lane row, then the first row's total
-            int inc = ns;
+            // inclusive scans over lanes 0..31 (lanes 32..63 do the same for the horizontal-only requests): row_shr 1, 2, 4,
+            // 8 inside each 16-lane row, then the row's total to the row behind it
+            const int mine = __shfl(ns, lane & 31), hz = __shfl((int)(have && !(cur_eight) && (cur_cy & 3) == 0), lane & 31);
+            int inc = lane < 32 ? mine : (hz ? mine : 0);
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
             inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
-            const int row0 = __builtin_amdgcn_readlane(inc, 15);
-            if (lane >= 16)
-                inc += row0;
-            L.pre[lane + 1] = inc;
-            if (lane == 0)
-                L.pre[0] = 0;
+            const int row0 = __builtin_amdgcn_readlane(inc, 15), row2 = __builtin_amdgcn_readlane(inc, 47);
+            if ((lane & 31) >= 16)
+                inc += lane < 32 ? row0 : row2;
+            (lane < 32 ? L.pre : L.prea)[(lane & 31) + 1] = inc;
+            if ((lane & 31) == 0)
+                (lane < 32 ? L.pre : L.prea)[0] = 0;
         }
         for (int i = lane; i < RF_BATCH * X265_HIP_RING_COSTS; i += 64)
             L.cost[i] = 0;
@@ -346,16 +391,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RF_WAVES)))
                 cur = reqs[first + lane];
         }
         wave_sync();
-        const int S = L.pre[RF_BATCH]; // strips of the batch; items are (k, strip), k-major
+        // strips of the batch; items are (k, strip): the side columns (k = 0, then k = 2) of the horizontal-only requests,
+        // the side columns of the others, then the middle column of all, so that the lanes of a pass share a kind
+        const int S = L.pre[RF_BATCH], SA = L.prea[RF_BATCH], SB = S - SA;
         for (int i = lane; i < 3 * S; i += 64)
         {
-            const int k = (i >= S) + (i >= 2 * S), si = i - k * S;
-            int r = 0;
+            int k, si, r = 0, t;
+            bool side_hz = false;
+            if (i < 2 * SA)
+            {
+                k = i >= SA ? 2 : 0, si = i - (k >> 1) * SA, side_hz = true;
 #pragma unroll
-            for (int s = 16; s > 0; s >>= 1)
-                if (L.pre[r + s] <= si)
-                    r += s;
-            const int t = si - L.pre[r];
+                for (int s = 16; s > 0; s >>= 1)
+                    if (L.prea[r + s] <= si)
+                        r += s;
+                t = si - L.prea[r];
+            }
+            else if (i < 2 * S)
+            {
+                k = i - 2 * SA >= SB ? 2 : 0, si = i - 2 * SA - (k >> 1) * SB;
+#pragma unroll
+                for (int s = 16; s > 0; s >>= 1)
+                    if (L.pre[r + s] - L.prea[r + s] <= si)
+                        r += s;
+                t = si - (L.pre[r] - L.prea[r]);
+            }
+            else
+            {
+                k = 1, si = i - 2 * S;
+#pragma unroll
+                for (int s = 16; s > 0; s >>= 1)
+                    if (L.pre[r + s] <= si)
+                        r += s;
+                t = si - L.pre[r];
+            }
             const int info = L.info[r], ntx = info & 31, tall = (info >> 5) & 1, metric = (info >> 6) & 1, step = (info >> 7) & 3;
             const int eight = (info >> 9) & 1, centre = (info >> 10) & 1;
             const int ty = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)ntx)), tx = t - ty * ntx; // exact: t < 256, ntx <= 16
@@ -376,10 +445,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RF_WAVES)))
             const int rows = 4 << tall;
             const gptr_t src = as_global(L.ref[r]) + (long)(rows * ty + iy0 - 3) * rstride + 4 * tx + (qx >> 2) - 3;
             const uint8_t *f = L.fenc[r] + (long)(rows * ty) * fstride + 4 * tx;
+            // (every lane of the pass, idle ones aside: a pass at the border of two kinds takes the general path)
+            const bool hz_only = __ballot(!side_hz) == 0;
+            const gptr_t src_hz = as_global(L.ref[r]) + (long)(rows * ty + (cy >> 2) - 3) * rstride + 4 * tx + (qx >> 2) - 3;
             if (tall)
-                ring_strip<2>(src, rstride, qx & 3, jneed, tj, taps_lds, f, fstride, metric, L.cost, sq);
+                ring_strip<2>(hz_only ? src_hz : src, rstride, qx & 3, jneed, tj, taps_lds, f, fstride, metric, L.cost, sq, hz_only);
             else
-                ring_strip<1>(src, rstride, qx & 3, jneed, tj, taps_lds, f, fstride, metric, L.cost, sq);
+                ring_strip<1>(hz_only ? src_hz : src, rstride, qx & 3, jneed, tj, taps_lds, f, fstride, metric, L.cost, sq, hz_only);
         }
         wave_sync();
         // ---- results: nine per request, INT_MAX where the pattern has no candidate ---------------------------------
