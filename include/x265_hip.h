@@ -81,8 +81,17 @@ int x265_hip_ctx_sync(x265_hip_ctx *ctx);
  * by this call, or with X265_HIP_CHECK_RECORDS=1 in the environment when the context is created -- every *_device
  * call first waits for the context's stream, copies the records back to the host and puts them through the checks of
  * the host-array form; a bad record then returns X265_HIP_EINVAL / X265_HIP_ERANGE with a message and nothing is
- * launched.  It costs a synchronisation and a copy per call: not for production runs.  No counterpart in the reference. */
-int x265_hip_ctx_check_records(x265_hip_ctx *ctx, int on);
+ * launched.  It costs a synchronisation and a copy per call: not for production runs.  No counterpart in the reference.
+ *
+ * Mode 2 (X265_HIP_CHECK_RECORDS=2) is the guard on the device: x265_hip_me_batch_device checks every job in the
+ * kernel that sorts its list (one thread per record, the same checks, against the plane directory in device memory);
+ * nothing waits and nothing is copied back.  A job that fails is searched by no kernel and gets the result
+ * (cost -1, mv 0 0); the call itself returns X265_HIP_OK.  The refusals are counted on the device:
+ * x265_hip_ctx_guard_status waits for the stream and returns (and clears) their number and the lowest index of one in
+ * its list; x265_hip_ctx_sync in this mode returns X265_HIP_ERANGE with a message if there were any since the last
+ * look.  The other *_device entry points have no guard and keep mode 1's copy-back in mode 2. */
+int x265_hip_ctx_check_records(x265_hip_ctx *ctx, int mode);
+int x265_hip_ctx_guard_status(x265_hip_ctx *ctx, uint32_t *refused, uint32_t *first_index);
 
 /* ---- (1) primitive level ---------------------------------------------------------------------- */
 

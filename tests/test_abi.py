@@ -89,14 +89,15 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     kernels spill nothing (cost_kernel at six waves spilled 14 dwords, 100 MB of scratch writes per 1080p launch,
     and was 8 % slower than at five waves without spills); refine_kernel at four waves (113 registers) spills nothing;
     me_rest_kernel (the same search inside a list loop, six waves per SIMD) may spill a dozen dwords; me_team_kernel
-    (three waves per SIMD) spills nothing."""
+    (three waves per SIMD for the tile classes) may spill eight in the set-up of a chunk of calls (fifteen scratch
+    instructions in all, none inside the rounds of a search)."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     src = os.path.join(ROOT, "x265_amd", "csrc")
-    allowed = {"me_kernel": 32, "me_rest_kernel": 64}
+    allowed = {"me_kernel": 32, "me_rest_kernel": 64, "me_team_kernel": 32}
     seen = set()
     kernels = ("me_kernel", "me_rest_kernel", "me_big_kernel", "me_team_kernel", "cost_kernel", "dist_kernel", "predict_kernel", "fullsearch2_kernel",
                "refine_kernel")

@@ -878,6 +878,87 @@ def test_record_check_mode_refuses_bad_device_records(gpu_ctx, small_seq):
         gpu_ctx.check_records(False)
 
 
+def test_record_guard_on_the_device_skips_bad_jobs(gpu_ctx, oracle, small_seq, costtabs):
+    """x265_hip_ctx_check_records mode 2: me_route_kernel checks every job of a device-resident list (one thread per
+    record, nothing copied back); bad records of every kind are searched by no kernel and come back as (cost -1, mv 0),
+    the others give the usual results, the refusals are counted on the device; and the guard draws the line where the
+    host-array entry point's check draws it"""
+    from x265_amd import abi, lib, synth
+    from x265_amd.hipmem import DeviceBuffer
+    W, H = small_seq[0].w, small_seq[0].h
+    rng = np.random.default_rng(99)
+    jobs = np.concatenate([random_me_jobs(rng, 400, m, int(rng.integers(0, 8)), W, H, abi.ME_JOB, synth.search_range, abi.PARTS) for m in range(4)])
+    rng.shuffle(jobs)
+    want = oracle.me_batch(_planes(small_seq), costtabs, jobs)
+    bad = jobs.copy()
+    spoil = {
+        5: lambda j: j.__setitem__("ref_plane", 511),          # not uploaded
+        64: lambda j: j.__setitem__("fenc_plane", 65000),      # no such plane
+        65: lambda j: j.__setitem__("pu_w", 20),               # not a partition
+        300: lambda j: j.__setitem__("subme", 9),
+        301: lambda j: j.__setitem__("num_mvc", abi.MAX_MVC + 1),
+        700: lambda j: j.__setitem__("qp", 81),                # no table for it
+        701: lambda j: j.__setitem__("mvmin_x", j["mvmax_x"] + 1),
+        1023: lambda j: j.__setitem__("mvmax_y", 30000),       # reaches far below the plane
+        1024: lambda j: j.__setitem__("mvmin_y", -30000),   # ... far above it
+        1500: lambda j: j.__setitem__("pu_y", H + 400),        # the source block itself lies outside
+        1599: lambda j: j.__setitem__("method", 9),
+    }
+    accepted = []
+    for i, f in spoil.items():
+        f(bad[i])
+        try:  # the host-array form refuses each of them
+            gpu_ctx.me_batch(bad[i:i + 1])
+            accepted.append(i)
+        except lib.X265HipError:
+            pass
+    assert not accepted
+    d_jobs, d_out = DeviceBuffer.from_array(bad), DeviceBuffer(8 * len(bad))
+    gpu_ctx.check_records(2)
+    try:
+        assert gpu_ctx.guard_status() == (0, 0xFFFFFFFF)
+        gpu_ctx.me_batch_device(d_jobs.ptr, len(bad), d_out.ptr)
+        with pytest.raises(lib.X265HipError, match=rf"refused {len(spoil)} .* index 5 "):
+            gpu_ctx.sync()
+        gpu_ctx.sync()  # reported once
+        got = d_out.download(abi.ME_RESULT)
+        ok = np.ones(len(bad), bool)
+        ok[list(spoil)] = False
+        assert np.array_equal(got[ok], want[ok])
+        assert (got["cost"][~ok] == -1).all() and (got["mvx"][~ok] == 0).all() and (got["mvy"][~ok] == 0).all()
+        # two launches, then one look
+        gpu_ctx.me_batch_device(d_jobs.ptr, len(bad), d_out.ptr)
+        gpu_ctx.me_batch_device(d_jobs.ptr + 64 * abi.ME_JOB.itemsize, len(bad) - 64, d_out.ptr)
+        assert gpu_ctx.guard_status() == (2 * len(spoil) - 1, 0)  # (job 5 is not in the second list, job 64 heads it)
+        assert gpu_ctx.guard_status() == (0, 0xFFFFFFFF)
+        # a good list
+        d_good = DeviceBuffer.from_array(jobs)
+        gpu_ctx.me_batch_device(d_good.ptr, len(jobs), d_out.ptr)
+        gpu_ctx.sync()
+        assert np.array_equal(d_out.download(abi.ME_RESULT), want)
+        # the line: a block near the lower right corner whose window grows past the plane's margins step by step
+        edge = np.repeat(jobs[:1], 160)
+        edge["pu_w"], edge["pu_h"], edge["pu_x"], edge["pu_y"] = 16, 16, W - 16, H - 16
+        edge["method"], edge["subme"], edge["qmvp_x"], edge["qmvp_y"], edge["num_mvc"] = abi.HEX, 2, 0, 0, 0
+        edge["mvmin_x"], edge["mvmin_y"] = -4, -4
+        edge["mvmax_x"] = np.arange(160) // 2 + 20
+        edge["mvmax_y"] = (np.arange(160) + 1) // 2 + 20
+        host_ok = np.ones(160, bool)
+        for i in range(160):
+            try:
+                gpu_ctx.me_batch(edge[i:i + 1])
+            except lib.X265HipError:
+                host_ok[i] = False
+        assert host_ok[0] and not host_ok[-1]
+        d_edge = DeviceBuffer.from_array(edge)
+        gpu_ctx.me_batch_device(d_edge.ptr, 160, d_out.ptr)
+        n_ref, first = gpu_ctx.guard_status()
+        got = d_out.download(abi.ME_RESULT, 160)
+        assert np.array_equal(got["cost"] != -1, host_ok) and n_ref == int((~host_ok).sum()) and first == int(np.argmin(host_ok))
+    finally:
+        gpu_ctx.check_records(False)
+
+
 @pytest.mark.parametrize("one_stream", [False, True])
 def test_large_block_jobs_and_their_routing(oracle, small_seq, costtabs, one_stream, monkeypatch):
     """blocks of 128 tiles and more are listed on the device and searched by me_big_kernel beside me_kernel (on a second

@@ -83,7 +83,8 @@ struct x265_hip_ctx
     int route_parity = 0; // counter set of the next motionEstimate launch (me_kernel.hip)
     int noalloc_slot = -1; // this context's part of the GPU's `scratch` array (taken at the first noalloc call)
     int noalloc_parity = 0;
-    bool check_records = false; // record-check mode of the device-array entry points
+    int check_records = 0; // record-check mode of the device-array entry points: 0 off, 1 copy-back, 2 device guard
+    uint32_t *guard_words = nullptr; // the guard's two status words (device)
     void *owned_plane[X265_HIP_MAX_PLANES] = {};
     size_t plane_bytes[X265_HIP_MAX_PLANES] = {};
     int plane_origin[X265_HIP_MAX_PLANES] = {};
@@ -94,6 +95,8 @@ struct x265_hip_ctx
     Buf look;          // x265_hip_lookahead_batch: row counters (64 bytes per search) behind one status word
     Buf prim_a, prim_b; // staging of the primitive thunks
 };
+
+static const uint32_t k_guard_clear[2] = { 0u, 0xffffffffu };
 
 // ---- scratch of the entry point that allocates nothing (x265_hip_cost_batch_device_noalloc) --------------
 // The cost kernels hand their batches out through counters in device memory.  Contexts keep theirs in a buffer
@@ -194,11 +197,11 @@ int ensure(x265_hip_ctx *c, Buf &b, size_t bytes, bool pinned = true)
 
 // `launches`: whether kernels will run (a call without jobs must not take a counter set: the set is cleared for the
 // launch after next by the launch that uses it)
-MeRoute me_route(x265_hip_ctx *c, bool launches, bool any_routed = true)
+MeRoute me_route(x265_hip_ctx *c, bool launches, bool any_routed = true, bool guarded = false)
 {
     if (!launches || !any_routed)
-        return MeRoute{ nullptr, 0, c->stream, nullptr, nullptr, nullptr };
-    return MeRoute{ (uint32_t *)c->route.d, c->route_parity++, c->stream, c->side, c->ev_fork, c->ev_join };
+        return MeRoute{ nullptr, 0, c->stream, nullptr, nullptr, nullptr, nullptr };
+    return MeRoute{ (uint32_t *)c->route.d, c->route_parity++, c->stream, c->side, c->ev_fork, c->ev_join, guarded ? c->guard_words : nullptr };
 }
 
 template <typename Job>
@@ -310,12 +313,18 @@ int x265_hip_ctx_create(int device, x265_hip_ctx **out)
         e = hipMalloc((void **)&c->batch_counter, X265HIP_COST_COUNTER_BYTES);
     if (e == hipSuccess)
         e = hipMemset(c->batch_counter, 0, X265HIP_COST_COUNTER_BYTES);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&c->guard_words, 2 * sizeof(uint32_t));
+    if (e == hipSuccess)
+        e = hipMemcpy(c->guard_words, k_guard_clear, sizeof(k_guard_clear), hipMemcpyHostToDevice);
     if (e != hipSuccess)
     {
         x265_hip_ctx_destroy(c);
         return fail(X265_HIP_ERUNTIME, "context setup: %s", hipGetErrorString(e));
     }
-    c->check_records = getenv("X265_HIP_CHECK_RECORDS") && atoi(getenv("X265_HIP_CHECK_RECORDS")) != 0;
+    c->check_records = getenv("X265_HIP_CHECK_RECORDS") ? atoi(getenv("X265_HIP_CHECK_RECORDS")) : 0;
+    if (c->check_records < 0 || c->check_records > 2)
+        c->check_records = 1;
     if (fullsearch2_setup() != 0)
     {
         x265_hip_ctx_destroy(c);
@@ -355,6 +364,8 @@ void x265_hip_ctx_destroy(x265_hip_ctx *c)
         (void)hipFree(c->dev_tabs);
     if (c->batch_counter)
         (void)hipFree(c->batch_counter);
+    if (c->guard_words)
+        (void)hipFree(c->guard_words);
     if (c->ev_fork)
         (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join)
@@ -378,8 +389,35 @@ int x265_hip_ctx_check_records(x265_hip_ctx *c, int on)
 {
     if (!c)
         return fail(X265_HIP_EINVAL, "null context");
+    if (on < 0 || on > 2)
+        return fail(X265_HIP_EINVAL, "check_records: mode %d (0 off, 1 copy-back, 2 device guard)", on);
     std::lock_guard<std::mutex> g(c->mu);
-    c->check_records = on != 0;
+    c->check_records = on;
+    return X265_HIP_OK;
+}
+
+// the guard's words, read and cleared (the stream is idle)
+static int guard_take(x265_hip_ctx *c, uint32_t w[2])
+{
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy(w, c->guard_words, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (w[0])
+        HIP_TRY(hipMemcpy(c->guard_words, k_guard_clear, sizeof(k_guard_clear), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int x265_hip_ctx_guard_status(x265_hip_ctx *c, uint32_t *refused, uint32_t *first_index)
+{
+    if (!c || !refused || !first_index)
+        return fail(X265_HIP_EINVAL, "guard_status: null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint32_t w[2];
+    int r = guard_take(c, w);
+    if (r)
+        return r;
+    *refused = w[0];
+    *first_index = w[1];
     return X265_HIP_OK;
 }
 
@@ -388,6 +426,18 @@ int x265_hip_ctx_sync(x265_hip_ctx *c)
     if (!c)
         return fail(X265_HIP_EINVAL, "null context");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->check_records == 2)
+    {
+        // what the guard refused since the words were last read: reported once, here
+        std::lock_guard<std::mutex> g(c->mu);
+        uint32_t w[2];
+        int r = guard_take(c, w);
+        if (r)
+            return r;
+        if (w[0])
+            return fail(X265_HIP_ERANGE, "the record guard refused %u motionEstimate job(s), the first at index %u of its list: their results are (cost -1, mv 0)",
+                        w[0], w[1]);
+    }
     return X265_HIP_OK;
 }
 
@@ -404,6 +454,7 @@ static void plane_clear(x265_hip_ctx *c, int id)
     c->host_tabs.planes[id].stride = 0;
     c->plane_bytes[id] = 0;
     c->plane_origin[id] = 0;
+    c->host_tabs.span_first[id] = c->host_tabs.span_end[id] = 0;
     c->tabs_dirty = true;
 }
 
@@ -415,6 +466,8 @@ static int plane_set(x265_hip_ctx *c, int id, const void *dev, size_t bytes, int
     c->host_tabs.planes[id].stride = stride;
     c->plane_bytes[id] = bytes;
     c->plane_origin[id] = origin;
+    c->host_tabs.span_first[id] = -(long)origin;
+    c->host_tabs.span_end[id] = (long)bytes - origin;
     c->tabs_dirty = true;
     return X265_HIP_OK;
 }
@@ -1151,9 +1204,9 @@ static int validate_lookahead(const x265_hip_ctx *c, const x265_hip_lookahead_jo
 // a bad record then gives an error code and a message instead of a GPU memory fault.
 extern "C++" {
 template <typename T, typename F>
-static int checked_records(x265_hip_ctx *c, const void *d_recs, int n, F validate)
+static int checked_records(x265_hip_ctx *c, const void *d_recs, int n, F validate, bool has_guard = false)
 {
-    if (!c->check_records || n <= 0)
+    if (!c->check_records || n <= 0 || (c->check_records == 2 && has_guard))
         return 0;
     std::vector<T> host((size_t)n);
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1173,14 +1226,14 @@ int x265_hip_me_batch_device(x265_hip_ctx *c, const void *d_jobs, int n, void *d
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     {
-        int vr = checked_records<x265_hip_me_job>(c, d_jobs, n, [&](const x265_hip_me_job *h) { return check_jobs(c, h, n); });
+        int vr = checked_records<x265_hip_me_job>(c, d_jobs, n, [&](const x265_hip_me_job *h) { return check_jobs(c, h, n); }, true);
         if (vr)
             return vr;
     }
     int r = push_tabs(c);
     if (r || (r = ensure_route(c, n)))
         return r;
-    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)d_jobs, n, (x265_hip_me_result *)d_results, me_route(c, n > 0)));
+    LAUNCH(launch_me(c->dev_tabs, (const x265_hip_me_job *)d_jobs, n, (x265_hip_me_result *)d_results, me_route(c, n > 0, true, c->check_records == 2)));
     return X265_HIP_OK;
 }
 

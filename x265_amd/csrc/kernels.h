@@ -77,6 +77,9 @@ struct MeRoute
     int parity;
     hipStream_t stream, side;
     hipEvent_t fork, join;
+    // record guard (x265_hip_ctx_check_records mode 2): two words, [0] counts the refused records of the launches since
+    // the words were last read, [1] is the lowest index of one; null: records are taken on trust
+    uint32_t *guard;
 };
 size_t me_route_words(int n);
 size_t me_route_counter_words();

@@ -30,6 +30,9 @@ struct DeviceTables
 {
     PlaneDesc planes[X265_HIP_MAX_PLANES];
     const uint16_t *costtab[X265_HIP_MAX_QP]; // 65536 entries each, centre at +32768
+    // the bytes of a plane's buffer relative to its origin, [first, end): what me_route_kernel's record guard checks a
+    // job's reach against (api.hip's check_reach / check_inside on the device)
+    long span_first[X265_HIP_MAX_PLANES], span_end[X265_HIP_MAX_PLANES];
 };
 
 __device__ __constant__ const int8_t k_taps[4][8] = {

@@ -1570,7 +1570,68 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_REST_WAVE
 // The lists of a routed launch (me_shared.h).  A wave's 64 consecutive jobs go to one part, each kind with one atomic
 // per wave; list order inside a part follows job order inside a wave.  Block 0 also clears the counter set of the next
 // launch: that set was last used by the launch before this one, which is over (launches of a context are ordered).
-__global__ __launch_bounds__(256) void me_route_kernel(const x265_hip_me_job *jobs, int n, uint32_t *route, int parity, int cap, int team_on)
+//
+// The record guard (`guard` not null; x265_hip_ctx_check_records mode 2): a thread puts its record through the checks
+// the host-array entry point makes of it (check_job in api.hip: plane ids, partition, method / subme / candidate count,
+// cost table, and that every sample the search may touch, filter margins included, lies inside the planes' buffers).  A
+// record that fails is put on no list (no kernel ever reads it), gets the result (cost -1, mv 0) and is counted in
+// guard[0]; guard[1] keeps the lowest index of one.  Nothing is copied back to the host.
+__device__ __forceinline__ bool guard_partition(int w, int h) // x265_hip_partition_from_sizes >= 0 (primitives.h:38-46)
+{
+    const int a = w > h ? w : h, b = w > h ? h : w; // the table is symmetric in (w, h)
+    switch (a)
+    {
+    case 4: return b == 4;
+    case 8: return b == 8 || b == 4;
+    case 16: return b == 16 || b == 8 || b == 12 || b == 4;
+    case 32: return b == 32 || b == 16 || b == 24 || b == 8;
+    case 64: return b == 64 || b == 32 || b == 48 || b == 16;
+    default: return false;
+    }
+}
+
+__device__ bool guard_me_job(const DeviceTables *tabs, const x265_hip_me_job &j)
+{
+    const int method = j.method & ~X265_HIP_LOWRES_REF;
+    if (j.fenc_plane >= X265_HIP_MAX_PLANES || j.ref_plane >= X265_HIP_MAX_PLANES)
+        return false;
+    const PlaneDesc fp = tabs->planes[j.fenc_plane], rp = tabs->planes[j.ref_plane];
+    if (!fp.origin || !rp.origin || !guard_partition(j.pu_w, j.pu_h))
+        return false;
+    if (method > X265_HIP_FULL || j.subme > 7 || j.num_mvc > X265_HIP_MAX_MVC)
+        return false;
+    if (j.method & X265_HIP_LOWRES_REF)
+    {
+        if (j.pu_w != 8 || j.pu_h != 8 || j.ref_plane + 3 >= X265_HIP_MAX_PLANES)
+            return false;
+        for (int k = 1; k < 4; k++)
+            if (!tabs->planes[j.ref_plane + k].origin || tabs->planes[j.ref_plane + k].stride != rp.stride ||
+                tabs->span_first[j.ref_plane + k] != tabs->span_first[j.ref_plane] || tabs->span_end[j.ref_plane + k] != tabs->span_end[j.ref_plane])
+                return false;
+    }
+    if (j.qp >= X265_HIP_MAX_QP || !tabs->costtab[j.qp])
+        return false;
+    if (j.mvmin_x > j.mvmax_x || j.mvmin_y > j.mvmax_y)
+        return false;
+    // reach, as check_job: the window and the zero vector, the steps a search may take outside them, the sub-pel
+    // stage's moves; then the filters' 3 before / 4 behind and the loads' overhang (check_reach)
+    const int int_over = method == X265_HIP_DIA ? 1 : method == X265_HIP_HEX ? 3 : method == X265_HIP_UMH ? 4 : 0;
+    const int qsteps = (j.method & X265_HIP_LOWRES_REF) ? 3 : (int)((0x65365332u >> (4 * j.subme)) & 15); // {2,3,3,5,6,3,5,6}
+    const long over = int_over + (qsteps + 3) / 4;
+    const long lox = min((long)j.mvmin_x, 0L) - over, hix = max((long)j.mvmax_x, 0L) + over;
+    const long loy = min((long)j.mvmin_y, 0L) - over, hiy = max((long)j.mvmax_y, 0L) + over;
+    {
+        const long first = (long)j.pu_y * fp.stride + j.pu_x, last = (long)(j.pu_y + j.pu_h - 1) * fp.stride + j.pu_x + j.pu_w;
+        if (first < tabs->span_first[j.fenc_plane] || last > tabs->span_end[j.fenc_plane] || j.pu_x + j.pu_w > fp.stride)
+            return false;
+    }
+    const long x0 = j.pu_x + lox, y0 = j.pu_y + loy, x1 = j.pu_x + hix + j.pu_w, y1 = j.pu_y + hiy + j.pu_h;
+    const long first = (y0 - 3) * rp.stride + (x0 - 3 - 3), last = (y1 + 4 - 1) * rp.stride + (x1 + 4 + 12);
+    return first >= tabs->span_first[j.ref_plane] && last <= tabs->span_end[j.ref_plane] + 16;
+}
+
+__global__ __launch_bounds__(256) void me_route_kernel(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, uint32_t *route, int parity, int cap,
+                                                       int team_on, uint32_t *guard, x265_hip_me_result *out, int out_stride)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x == 0)
@@ -1579,9 +1640,20 @@ __global__ __launch_bounds__(256) void me_route_kernel(const x265_hip_me_job *jo
     int cls = -1;
     if (i < n)
     {
-        cls = me_job_class(jobs[i].pu_w, jobs[i].pu_h, jobs[i].method);
-        if ((!team_on && cls >= MC_T4) || (team_on == 2 && cls == MC_T32))
-            cls = MC_REST;
+        if (guard && !guard_me_job(tabs, jobs[i]))
+        {
+            atomicAdd(&guard[0], 1u);
+            atomicMin(&guard[1], (uint32_t)i);
+            x265_hip_me_result *o = (x265_hip_me_result *)((char *)out + (size_t)i * out_stride);
+            o->cost = -1;
+            o->mvx = o->mvy = 0;
+        }
+        else
+        {
+            cls = me_job_class(jobs[i].pu_w, jobs[i].pu_h, jobs[i].method);
+            if ((!team_on && cls >= MC_T4) || (team_on == 2 && cls == MC_T32))
+                cls = MC_REST;
+        }
     }
     const int p = (i >> 6) & (ME_PARTS - 1);
 #pragma unroll
@@ -2420,7 +2492,7 @@ static void me_launch_both(const DeviceTables *tabs, const x265_hip_me_job *jobs
     // sometimes ended with them: nothing ran side by side), then the big jobs on the side stream and the other jobs on
     // the main one: the small jobs fill what the big ones leave idle (their last round, or most of the chip when
     // there are few of them).
-    hipLaunchKernelGGL(me_route_kernel, dim3((n + 255) / 256), dim3(256), 0, r.stream, jobs, n, r.route, parity, cap, team_on);
+    hipLaunchKernelGGL(me_route_kernel, dim3((n + 255) / 256), dim3(256), 0, r.stream, tabs, jobs, n, r.route, parity, cap, team_on, r.guard, out, out_stride);
     hipStream_t sb = r.side ? r.side : r.stream;
     if (r.side)
     {

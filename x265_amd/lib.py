@@ -37,7 +37,7 @@ EXPORTS = [
     "x265_hip_dist_batch", "x265_hip_dist_batch_device", "x265_hip_predict_batch", "x265_hip_predict_batch_device",
     "x265_hip_cost_batch_device_noalloc", "x265_hip_refine_batch", "x265_hip_refine_batch_device",
     "x265_hip_inter_search_batch", "x265_hip_inter_search_batch_device",
-    "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device", "x265_hip_ctx_check_records", "x265_hip_refine_sections_device",
+    "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device", "x265_hip_ctx_check_records", "x265_hip_ctx_guard_status", "x265_hip_refine_sections_device",
     "x265_hip_host_alloc", "x265_hip_host_free", "x265_hip_plane_alloc", "x265_hip_plane_upload_async", "x265_hip_download_async",
     "x265_hip_copy_wait_compute", "x265_hip_compute_wait_copy", "x265_hip_copy_sync",
     "x265_hip_plane_extend_border_rows", "x265_hip_plane_weight_rows",
@@ -266,8 +266,15 @@ class Context:
         _check(load().x265_hip_refine_sections_device(self._h, C.c_void_p(d_reqs), _p(sec), C.c_int(len(sec)), C.c_void_p(d_costs9)))
 
     def check_records(self, on=True):
-        """record-check mode of the *_device entry points (debugging aid)"""
-        _check(load().x265_hip_ctx_check_records(self._h, C.c_int(1 if on else 0)))
+        """record-check mode of the *_device entry points (debugging aid): False / 0 off, True / 1 copy the records back
+        and check them on the host, 2 the guard on the device (x265_hip_me_batch_device)"""
+        _check(load().x265_hip_ctx_check_records(self._h, C.c_int(int(on))))
+
+    def guard_status(self):
+        """(refused records since the last look, lowest index of one in its list): waits for the stream"""
+        n, first = C.c_uint32(0), C.c_uint32(0)
+        _check(load().x265_hip_ctx_guard_status(self._h, C.byref(n), C.byref(first)))
+        return n.value, first.value
 
     def lookahead_batch(self, jobs, width_in_cu, height_in_cu):
         """(n, height_in_cu, width_in_cu) results: the whole-frame searches of the lookahead"""
