@@ -113,6 +113,8 @@ typedef void (*x265_hip_weightp_pp_t)(uint8_t *src, uint8_t *dst, intptr_t srcSt
                                       int height, int w0, int round, int shift, int offset);
 typedef void (*x265_hip_downscale_t)(uint8_t *src0, uint8_t *dstf, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc,
                                      intptr_t src_stride, intptr_t dst_stride, int width, int height);
+/* primitives.h:159 */
+typedef void (*x265_hip_extendCURowBorder_t)(uint8_t *txt, intptr_t stride, int width, int height, int marginX);
 
 /* primitives.h:167, 169-171, 180 */
 typedef void (*x265_hip_filter_ps_t)(uint8_t *src, intptr_t srcStride, int16_t *dst, intptr_t dstStride, int coeffIdx);
@@ -146,6 +148,9 @@ typedef struct x265_hip_primitives
     x265_hip_filter_hv_pp_t luma_hvpp[X265_HIP_NUM_LUMA_PARTITIONS];   /* primitives.h:227; C: ipfilter.cpp:362-369 */
     x265_hip_filter_p2s_t   luma_p2s;                                  /* primitives.h:228; C: ipfilter.cpp:37-54, 510 */
     x265_hip_addAvg_t       luma_addAvg[X265_HIP_NUM_LUMA_PARTITIONS]; /* primitives.h:235; C: pixel.cpp:819-839 */
+    /* the margins of the rows a frame thread has finished (MotionReference::applyWeight, reference.cpp:99; the frame
+     * filter, framefilter.cpp:221-223) */
+    x265_hip_extendCURowBorder_t extendRowBorder;                      /* primitives.h:259; C: ipfilter.cpp:56-74, 516 */
 } x265_hip_primitives;
 
 /* Replaces the assignments Setup_C_PixelPrimitives / Setup_C_IPFilterPrimitives make for these

@@ -20,6 +20,8 @@
  *   X265_USE_HIP_ME=1      every MotionEstimate::motionEstimate call, the lookahead's included -> x265_hip_me_batch
  *   X265_USE_HIP_MC=1      the luma block of every TComPrediction::motionCompensation call -> x265_hip_predict_batch
  *   X265_USE_HIP_PLANES=1  Lowres::init -> x265_hip_lowres_init, MotionReference::applyWeight -> x265_hip_plane_weight
+ *   X265_USE_HIP_PLANES=2  ... and every applyWeight call that adds CU rows -> x265_hip_plane_weight_rows for those rows
+ *                          (what frame threads > 1 do while the reference picture is still being reconstructed)
  *   X265_USE_HIP_LOOKAHEAD=1|2  the lookahead's motion search a whole frame at a time: the first lowres motionEstimate call
  *                          of a frame cost estimate's list (CU (W-1, H-1), slicetype.cpp:1458-1499) runs
  *                          x265_hip_lookahead_batch for the (picture, reference) pair, and this and every later call of
@@ -472,9 +474,9 @@ int look_answer(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, con
  * by x265_hip_lowres_init, and every weighted reference plane MotionReference::applyWeight completes
  * (reference.cpp:78-121) by x265_hip_plane_weight. */
 namespace {
-bool g_hip_planes = false;
+int g_hip_planes = 0; /* 1: whole planes when complete, 2: rows as applyWeight adds them */
 x265_hip_ctx *g_ctx_planes = nullptr;
-long g_li_planes = 0, g_li_mismatch = 0, g_aw_planes = 0, g_aw_mismatch = 0, g_aw_partial = 0;
+long g_li_planes = 0, g_li_mismatch = 0, g_aw_planes = 0, g_aw_mismatch = 0, g_aw_partial = 0, g_aw_batches = 0, g_aw_batch_mismatch = 0;
 std::vector<uint8_t> g_pl_buf;
 
 /* rows -MY .. h + MY - 1, columns -MX .. w + MX - 1 of a padded buffer: what the reference writes */
@@ -536,6 +538,41 @@ void wrap_aw(MotionReference *self, int rows, int numRows)
 {
     const int before = self->m_numWeightedRows;
     real_aw(self, rows, numRows);
+    if (g_hip_planes == 2)
+    {
+        const int after = self->m_numWeightedRows;
+        if (!self->isWeighted || after == before)
+            return;
+        std::lock_guard<std::mutex> g(g_mu);
+        if (after == numRows && before < numRows - 1)
+        {
+            g_aw_partial++; /* (see below) */
+            return;
+        }
+        TComPicYuv *pic = self->m_reconPic;
+        const int stride = pic->getStride(), prow = (g_height + 63) / 64 * 64;
+        const size_t bytes = (size_t)stride * (prow + 2 * MY);
+        const int row0 = before * 64, nrows = after == numRows ? g_height - row0 : (after - before) * 64;
+        /* (the whole buffer goes up, rows that are still being reconstructed included: only rows row0 .. are read) */
+        if (x265_hip_plane_upload(g_ctx_planes, 8, pic->getLumaAddr() - (intptr_t)MY * stride - MX, bytes, stride, MY * stride + MX) != X265_HIP_OK ||
+            x265_hip_plane_weight_rows(g_ctx_planes, 8, 9, g_width, g_height, MX, MY, self->weight, self->offset, self->shift, row0, nrows) != X265_HIP_OK)
+            planes_fail("plane_weight_rows");
+        g_pl_buf.resize(bytes);
+        if (x265_hip_plane_download(g_ctx_planes, 9, g_pl_buf.data(), bytes) != X265_HIP_OK)
+            planes_fail("plane_download");
+        /* what this call of the reference wrote: the rows with their side margins, the rows above the picture with
+         * the first batch, the rows below it with the last (reference.cpp:95-119) */
+        const int y0 = before == 0 ? 0 : MY + row0, y1 = after == numRows ? g_height + 2 * MY : MY + row0 + nrows;
+        bool diff = false;
+        for (int y = y0; y < y1; y++)
+        {
+            diff |= memcmp(self->m_weightBuffer + (size_t)y * stride, g_pl_buf.data() + (size_t)y * stride, g_width + 2 * MX) != 0;
+            memcpy(self->m_weightBuffer + (size_t)y * stride, g_pl_buf.data() + (size_t)y * stride, g_width + 2 * MX);
+        }
+        g_aw_batches++;
+        g_aw_batch_mismatch += diff;
+        return;
+    }
     if (!g_hip_planes || !self->isWeighted || self->m_numWeightedRows != numRows || before == numRows)
         return; /* only the call that completes the plane */
     std::lock_guard<std::mutex> g(g_mu);
@@ -881,7 +918,7 @@ int main(int argc, char **argv)
             fprintf(stderr, "x265_hip_ctx_create: %s\n", x265_hip_last_error());
             return 1;
         }
-        g_hip_planes = true;
+        g_hip_planes = atoi(getenv("X265_USE_HIP_PLANES")) == 2 ? 2 : 1;
         fprintf(stderr, "enc_capture: lookahead planes and weighted reference planes made by x265_hip_lowres_init / x265_hip_plane_weight\n");
     }
     if (getenv("X265_USE_HIP_MC"))
@@ -987,6 +1024,9 @@ int main(int argc, char **argv)
     if (g_hip_planes)
         fprintf(stderr, "enc_capture: %ld lookahead planes made on the GPU, %ld differed; %ld weighted reference planes made on the GPU, %ld differed (%ld the reference left incomplete)\n",
                 g_li_planes, g_li_mismatch, g_aw_planes, g_aw_mismatch, g_aw_partial);
+    if (g_hip_planes == 2)
+        fprintf(stderr, "enc_capture: %ld batches of weighted reference rows made on the GPU as applyWeight added them, %ld differed\n", g_aw_batches,
+                g_aw_batch_mismatch);
     if (g_hip_mc)
         fprintf(stderr, "enc_capture: %ld motionCompensation luma blocks predicted on the GPU (%ld weighted, %ld bi-directional), %ld differed from the reference's own pixels, %ld left alone\n",
                 g_mc_calls, g_mc_weighted, g_mc_bi, g_mc_mismatch, g_mc_skipped);

@@ -169,6 +169,10 @@ class Checker:
         self._f("weight_pp")(_ptr(src, soff), _ptr(dst, doff), C.c_ssize_t(sstride), C.c_ssize_t(dstride), C.c_int(width),
                              C.c_int(height), C.c_int(w0), C.c_int(rnd), C.c_int(shift), C.c_int(offset))
 
+    def extend_row_border(self, buf, off, stride, width, height, margin_x):
+        """extendCURowColBorder (ipfilter.cpp:56-74): extendPicBorder without rows above and below"""
+        self._f("extend_pic_border")(_ptr(buf, off), C.c_ssize_t(stride), C.c_int(width), C.c_int(height), C.c_int(margin_x), C.c_int(0))
+
     def frame_init_lowres(self, src, soff, dsts, doff, sstride, dstride, width, height):
         self._f("frame_init_lowres")(_ptr(src, soff), _ptr(dsts[0], doff), _ptr(dsts[1], doff), _ptr(dsts[2], doff),
                                      _ptr(dsts[3], doff), C.c_ssize_t(sstride), C.c_ssize_t(dstride), C.c_int(width),

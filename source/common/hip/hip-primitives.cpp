@@ -54,6 +54,8 @@ void Setup_HIP_Primitives(EncoderPrimitives &p, x265_param *param, int device)
     p.luma_p2s = (filter_p2s_t)t.luma_p2s;
     p.weight_pp = (weightp_pp_t)t.weight_pp;
     p.frame_init_lowres_core = (downscale_t)t.frame_init_lowres_core;
+    /* the margins of finished rows (primitives.h:259; reference.cpp:99, framefilter.cpp:221-223) */
+    p.extendRowBorder = (extendCURowBorder_t)t.extendRowBorder;
 }
 }
 

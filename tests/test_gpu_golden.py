@@ -293,13 +293,19 @@ def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
     hashes = []
     # C primitives; HIP table; motionEstimate via x265_hip_me_batch; motionCompensation (luma) via x265_hip_predict_batch
     # lookahead / weighted planes via x265_hip_lowres_init / x265_hip_plane_weight
-    for mode in (None, "X265_USE_HIP", "X265_USE_HIP_ME", "X265_USE_HIP_MC", "X265_USE_HIP_PLANES"):
+    # ... and the weighted planes row by row as MotionReference::applyWeight adds them (x265_hip_plane_weight_rows)
+    for mode in (None, "X265_USE_HIP", "X265_USE_HIP_ME", "X265_USE_HIP_MC", "X265_USE_HIP_PLANES", "X265_USE_HIP_PLANES=2"):
         env = dict(os.environ)
         if mode:
-            env[mode] = "1"
+            env[mode.split("=")[0]] = mode.split("=")[1] if "=" in mode else "1"
         r = subprocess.run([exe, str(clip), str(W), str(H), str(N), str(tmp_path), "0", "0", "0", "2", "1"], env=env,
                            capture_output=True, text=True, timeout=100)
         assert r.returncode == 0, r.stderr
+        if mode == "X265_USE_HIP_PLANES=2":
+            m = re.search(r"(\d+) batches of weighted reference rows made on the GPU as applyWeight added them, (\d+) differed", r.stderr)
+            assert m and int(m.group(1)) > 4 and int(m.group(2)) == 0, r.stderr
+            hashes.append(re.search(r"%d pictures in .* bitstream hash ([0-9a-f]+)" % N, r.stderr).group(1))
+            continue
         assert ("HIP primitive table installed" in r.stderr) == (mode == "X265_USE_HIP")
         if mode == "X265_USE_HIP_ME":
             m = re.search(r"(\d+) motionEstimate calls answered on the GPU, (\d+) differed", r.stderr)
@@ -312,5 +318,18 @@ def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
         if mode == "X265_USE_HIP_MC":
             m = re.search(r"(\d+) motionCompensation luma blocks predicted on the GPU \((\d+) weighted, (\d+) bi-directional\), (\d+) differed", r.stderr)
             assert m and int(m.group(1)) > 100 and int(m.group(2)) > 0 and int(m.group(4)) == 0, r.stderr
+        hashes.append(re.search(r"%d pictures in .* bitstream hash ([0-9a-f]+)" % N, r.stderr).group(1))
+    assert len(set(hashes)) == 1, hashes
+    # three frame threads: MotionReference::applyWeight weights a reference's CU rows while the picture is still being
+    # reconstructed; each batch of rows is made again by x265_hip_plane_weight_rows (with the table's extendRowBorder
+    # installed as well: the frame filter and applyWeight extend their rows through it)
+    hashes = []
+    for modes in ({}, {"X265_USE_HIP_PLANES": "2"}, {"X265_USE_HIP_PLANES": "2", "X265_USE_HIP": "1"}):
+        r = subprocess.run([exe, str(clip), str(W), str(H), str(N), str(tmp_path), "0", "0", "0", "3", "3"], env=dict(os.environ, **modes),
+                           capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stderr
+        if modes:
+            m = re.search(r"(\d+) batches of weighted reference rows made on the GPU as applyWeight added them, (\d+) differed", r.stderr)
+            assert m and int(m.group(1)) > 4 and int(m.group(2)) == 0, r.stderr
         hashes.append(re.search(r"%d pictures in .* bitstream hash ([0-9a-f]+)" % N, r.stderr).group(1))
     assert len(set(hashes)) == 1, hashes

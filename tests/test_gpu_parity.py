@@ -383,6 +383,13 @@ def test_primitive_table_plane_entries(oracle):
         t.weight_pp(addr(a, 7), addr(d1, 11), 150, 160, w, h, w0, rnd, sh, off)
         oracle.weight_pp(a, 7, d2, 11, 150, 160, w, h, w0, rnd, sh, off)
         assert np.array_equal(d1, d2), (w, h)
+    # extendRowBorder (primitives.h:259): a CTU row of luma and of chroma with the encoder's margins, and odd shapes
+    for (w, h, mx, stride, off) in ((416, 64, 80, 576, 80 + 3 * 576), (208, 32, 40, 288, 40), (33, 5, 7, 61, 9), (4, 1, 1, 6, 1), (90, 17, 96, 300, 400)):
+        d1 = rng.integers(0, 256, 200 * 200, dtype=np.uint8)
+        d2 = d1.copy()
+        t.extendRowBorder(addr(d1, off), stride, w, h, mx)
+        oracle.extend_row_border(d2, off, stride, w, h, mx)
+        assert np.array_equal(d1, d2), (w, h, mx)
     for (w, h) in ((48, 40), (17, 9), (80, 24), (4, 4)):
         o1 = [np.full(200 * 200, 0x5A, np.uint8) for _ in range(4)]
         o2 = [np.full(200 * 200, 0x5A, np.uint8) for _ in range(4)]

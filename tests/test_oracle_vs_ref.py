@@ -122,6 +122,12 @@ def test_pixelavg_weight_lowres_primitives(oracle, ref):
         oracle.weight_pp(a, 7, d1, 11, 150, 160, w, h, w0, rnd, sh, off)
         ref.weight_pp(a, 7, d2, 11, 150, 160, w, h, w0, rnd, sh, off)
         assert np.array_equal(d1, d2), (w, h)
+    for (w, h, mx, stride, off) in ((416, 64, 80, 576, 80 + 3 * 576), (33, 5, 7, 61, 9), (4, 1, 1, 6, 1)):  # extendRowBorder
+        d1 = rng.integers(0, 256, 200 * 200, dtype=np.uint8)
+        d2 = d1.copy()
+        oracle.extend_row_border(d1, off, stride, w, h, mx)
+        ref.extend_row_border(d2, off, stride, w, h, mx)
+        assert np.array_equal(d1, d2), (w, h, mx)
     for (w, h) in ((48, 40), (17, 9), (80, 24)):
         o1 = [np.full(200 * 200, 0x5A, np.uint8) for _ in range(4)]
         o2 = [np.full(200 * 200, 0x5A, np.uint8) for _ in range(4)]

@@ -2123,6 +2123,43 @@ int prim_weight(const uint8_t *src, uint8_t *dst, intptr_t ss, intptr_t ds, int 
     return 0;
 }
 
+// extendCURowColBorder (ipfilter.cpp:56-74): the rows' first and last samples into their left and right margins
+int prim_extend_rows(uint8_t *txt, intptr_t stride, int width, int height, int mx)
+{
+    x265_hip_ctx *c = prim_ctx();
+    if (!c)
+        return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
+    if (width <= 0 || height <= 0 || mx <= 0)
+        return 0;
+    const int pitch = (width + 2 * mx + 3) & ~3; // staged rows start at their left margin, 4-byte aligned
+    const size_t blk = (size_t)pitch * height;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = ensure(c, c->prim_a, blk + 64)) || (r = stage_rows(c, c->prim_a, mx, txt, stride, width, height, pitch)))
+        return r;
+    PlaneBorderArgs a = {};
+    a.src = (const uint8_t *)c->prim_a.d + mx;
+    a.dst = (uint8_t *)c->prim_a.d + mx;
+    a.stride = pitch;
+    a.width = width;
+    a.height = height;
+    a.margin_x = mx;
+    a.margin_y = 0;
+    a.py0 = 0;
+    a.pyn = height;
+    LAUNCH(launch_plane_border(a, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->prim_a.h, c->prim_a.d, blk, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int y = 0; y < height; y++)
+    {
+        const uint8_t *row = (const uint8_t *)c->prim_a.h + (size_t)y * pitch;
+        memcpy(txt + (long)y * stride - mx, row, mx);
+        memcpy(txt + (long)y * stride + width, row + mx + width, mx);
+    }
+    return 0;
+}
+
 int prim_lowres(const uint8_t *src0, uint8_t *const dst[4], intptr_t ss, intptr_t ds, int width, int height)
 {
     x265_hip_ctx *c = prim_ctx();
@@ -2172,6 +2209,12 @@ void t_weight(uint8_t *src, uint8_t *dst, intptr_t ss, intptr_t ds, int width, i
 {
     if (prim_weight(src, dst, ss, ds, width, height, w0, round, shift, offset))
         prim_fatal("weight_pp");
+}
+
+void t_extend(uint8_t *txt, intptr_t stride, int width, int height, int mx)
+{
+    if (prim_extend_rows(txt, stride, width, height, mx))
+        prim_fatal("extendRowBorder");
 }
 
 void t_lowres(uint8_t *src0, uint8_t *dstf, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc, intptr_t ss, intptr_t ds, int width,
@@ -2226,6 +2269,7 @@ int x265_hip_setup_primitives(x265_hip_primitives *table, int device)
     table->luma_p2s = t_p2s;
     table->weight_pp = t_weight;
     table->frame_init_lowres_core = t_lowres;
+    table->extendRowBorder = t_extend;
     return X265_HIP_OK;
 }
 

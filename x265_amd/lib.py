@@ -87,6 +87,7 @@ class Primitives(C.Structure):
     _p2s = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_int, C.c_int)
     _aavg = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_ssize_t)
     _hps = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int)
+    _ext = C.CFUNCTYPE(None, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int)
     _fields_ = [
         ("sad", _cmp * NUM_PARTS), ("sad_x3", _x3 * NUM_PARTS), ("sad_x4", _x4 * NUM_PARTS),
         ("satd", _cmp * NUM_PARTS), ("luma_hpp", _pp * NUM_PARTS), ("luma_hps", _hps * NUM_PARTS),
@@ -94,7 +95,7 @@ class Primitives(C.Structure):
         ("pixelavg_pp", _avg * NUM_PARTS), ("weight_pp", _wpp), ("frame_init_lowres_core", _down),
         ("sa8d_inter", _cmp * NUM_PARTS), ("sse_pp", _cmp * NUM_PARTS),
         ("luma_vps", _ps * NUM_PARTS), ("luma_vss", _ps * NUM_PARTS), ("luma_hvpp", _hv * NUM_PARTS), ("luma_p2s", _p2s),
-        ("luma_addAvg", _aavg * NUM_PARTS),
+        ("luma_addAvg", _aavg * NUM_PARTS), ("extendRowBorder", _ext),
     ]
 
 
