@@ -49,6 +49,8 @@
 #include "bitcost.h"
 #include "TLibCommon/TComPic.h"
 #include "TLibCommon/TComDataCU.h"
+#include "TLibEncoder/TEncSearch.h"
+#include "rdcost.h"
 #ifdef WITH_HIP
 #include "TLibCommon/TComPrediction.h"
 #endif
@@ -74,6 +76,13 @@ int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const M
 #define FM_SYM "_ZN4x26510TComDataCU11fillMvpCandEjjiiPNS_8AMVPInfoEPNS_2MVE"
 int real_fm(TComDataCU *self, uint32_t partIdx, uint32_t partAddr, int picList, int refIdx, AMVPInfo *info, MV *mvc) asm("__real_" FM_SYM);
 int wrap_fm(TComDataCU *self, uint32_t partIdx, uint32_t partAddr, int picList, int refIdx, AMVPInfo *info, MV *mvc) asm("__wrap_" FM_SYM);
+
+/* TEncSearch::predInterSearch itself (called from TEncCu.cpp / compress.cpp): what it left in the CU for every prediction
+ * unit -- merge or not, direction, vectors, references, AMVP indices after xCheckBestMVP and the bidirectional stage
+ * (TEncSearch.cpp:2343-2347, 2360-2499) -- is written to pu.bin beside the motionEstimate calls the unit made. */
+#define PI_SYM "_ZN4x26510TEncSearch15predInterSearchEPNS_10TComDataCUEPNS_7TComYuvEbb"
+bool real_pi(TEncSearch *self, TComDataCU *cu, TComYuv *predYuv, bool bMergeOnly, bool bChroma) asm("__real_" PI_SYM);
+bool wrap_pi(TEncSearch *self, TComDataCU *cu, TComYuv *predYuv, bool bMergeOnly, bool bChroma) asm("__wrap_" PI_SYM);
 
 #ifdef WITH_HIP
 #define MC_SYM "_ZN4x26514TComPrediction18motionCompensationEPNS_10TComDataCUEPNS_7TComYuvEiibb"
@@ -119,9 +128,32 @@ struct AmvpRec /* amvp.bin: one per CallRec, in the same order (num_amvp 0 for t
 };
 #pragma pack(pop)
 static_assert(sizeof(AmvpRec) == 20, "layout read by gen_golden.py");
+#pragma pack(push, 1)
+struct PuRec /* pu.bin: one per prediction unit that searched (read by oracle/gen_golden.py) */
+{
+    int32_t call[8];     /* indices into calls.bin of its motionEstimate calls, in order: list 0's references, then list 1's */
+    uint8_t call_list[8], call_ref[8];
+    uint8_t n_calls, is_p, part_size, part_idx, num_ref[2], bipred_restriction, complete; /* complete: every call is in calls.bin */
+    uint8_t list_sel_bits[3]; /* xGetBlkBits for this unit (TEncSearch.cpp:2301) */
+    uint8_t merge_flag, inter_dir, pad[3]; /* as predInterSearch left them */
+    uint32_t lambda_sad;      /* RDCost::m_lambdaSAD */
+    int16_t mv[4];            /* list 0 x y, list 1 x y */
+    int8_t ref[2], mvp_idx[2];
+};
+#pragma pack(pop)
+static_assert(sizeof(PuRec) == 80, "layout read by gen_golden.py");
+std::vector<PuRec> g_pus;
+struct PuCall
+{
+    int index, list, ref, part;
+};
+thread_local bool t_pu_active = false;
+thread_local std::vector<PuCall> t_pu_calls;
+
 struct AmvpNote
 {
     bool valid;
+    int list, ref, part;
     int cu_x, cu_y, num;
     MV cand[2];
     const pixel *recon;
@@ -720,6 +752,7 @@ int wrap_fm(TComDataCU *self, uint32_t partIdx, uint32_t partAddr, int picList, 
     const int n = real_fm(self, partIdx, partAddr, picList, refIdx, info, mvc);
     AmvpNote &a = t_amvp;
     a.valid = true;
+    a.list = picList, a.ref = refIdx, a.part = (int)partIdx;
     a.cu_x = (int)self->getCUPelX();
     a.cu_y = (int)self->getCUPelY();
     a.num = info->m_num < 2 ? info->m_num : 2;
@@ -798,9 +831,17 @@ int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const M
 #endif
     const bool low = ref->isLowres;
     if (!low && g_seen_full++ < g_first_full)
+    {
+        if (t_pu_active && t_amvp.valid)
+            t_pu_calls.push_back(PuCall{ -1, t_amvp.list, t_amvp.ref, t_amvp.part });
         return cost;
+    }
     if ((low ? g_n_low >= g_max_low : g_n_full >= g_max_full) || numc > 12)
+    {
+        if (!low && t_pu_active && t_amvp.valid)
+            t_pu_calls.push_back(PuCall{ -1, t_amvp.list, t_amvp.ref, t_amvp.part });
         return cost;
+    }
     CallRec r;
     memset(&r, 0, sizeof(r));
     const int stride = (int)self->fencLumaStride;
@@ -836,6 +877,8 @@ int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const M
     r.cost = cost;
     r.mvx = out.x, r.mvy = out.y;
     g_calls.push_back(r);
+    if (!low && t_pu_active && t_amvp.valid)
+        t_pu_calls.push_back(PuCall{ (int)g_calls.size() - 1, t_amvp.list, t_amvp.ref, t_amvp.part });
     AmvpRec ar;
     memset(&ar, 0, sizeof(ar));
     if (!low && t_amvp.valid)
@@ -849,6 +892,70 @@ int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const M
     }
     g_amvp.push_back(ar);
     return cost;
+}
+
+bool wrap_pi(TEncSearch *self, TComDataCU *cu, TComYuv *predYuv, bool bMergeOnly, bool bChroma)
+{
+    t_pu_active = true;
+    t_pu_calls.clear();
+    const bool ok = real_pi(self, cu, predYuv, bMergeOnly, bChroma);
+    t_pu_active = false;
+    if (t_pu_calls.empty())
+        return ok;
+    const PartSize partSize = cu->getPartitionSize(0);
+    const int numPart = cu->getNumPartInter();
+    const bool isP = cu->getSlice()->isInterP();
+    const int *numRefIdx = cu->getSlice()->getNumRefIdx();
+    uint32_t lastMode = 0; /* TEncSearch.cpp:2242; set where a unit ends up uni- or bi-directional (:2449-2499) */
+    std::lock_guard<std::mutex> g(g_mu);
+    for (int part = 0; part < numPart; part++)
+    {
+        uint32_t partAddr;
+        int w, h;
+        cu->getPartIndexAndSize(part, partAddr, w, h);
+        const bool merged = cu->getMergeFlag(partAddr);
+        const int dir = cu->getInterDir(partAddr);
+        PuRec p;
+        memset(&p, 0, sizeof(p));
+        p.complete = 1;
+        for (const PuCall &c : t_pu_calls)
+            if (c.part == part && p.n_calls < 8)
+            {
+                p.call[p.n_calls] = c.index;
+                p.call_list[p.n_calls] = (uint8_t)c.list;
+                p.call_ref[p.n_calls] = (uint8_t)c.ref;
+                p.n_calls++;
+                if (c.index < 0)
+                    p.complete = 0;
+            }
+        if (p.n_calls)
+        {
+            uint32_t bits[3];
+            self->xGetBlkBits(partSize, isP, part, lastMode, bits);
+            p.is_p = isP;
+            p.part_size = (uint8_t)partSize;
+            p.part_idx = (uint8_t)part;
+            p.num_ref[0] = (uint8_t)numRefIdx[0];
+            p.num_ref[1] = (uint8_t)(isP ? 0 : numRefIdx[1]);
+            p.bipred_restriction = cu->isBipredRestriction();
+            for (int k = 0; k < 3; k++)
+                p.list_sel_bits[k] = (uint8_t)bits[k];
+            p.merge_flag = merged;
+            p.inter_dir = (uint8_t)dir;
+            p.lambda_sad = (uint32_t)self->m_rdCost->m_lambdaSAD;
+            for (int l = 0; l < 2; l++)
+            {
+                const MV mv = cu->getCUMvField(l)->getMv(partAddr);
+                p.mv[2 * l] = mv.x, p.mv[2 * l + 1] = mv.y;
+                p.ref[l] = (int8_t)cu->getCUMvField(l)->getRefIdx(partAddr);
+                p.mvp_idx[l] = (int8_t)cu->getMVPIdx(l, partAddr);
+            }
+            g_pus.push_back(p);
+        }
+        if (!merged && p.n_calls)
+            lastMode = dir == 3 ? 2 : dir == 2 ? 1 : 0;
+    }
+    return ok;
 }
 
 int main(int argc, char **argv)
@@ -1017,6 +1124,9 @@ int main(int argc, char **argv)
     fclose(out);
     out = fopen((dir + "/amvp.bin").c_str(), "wb");
     fwrite(g_amvp.data(), sizeof(AmvpRec), g_amvp.size(), out);
+    fclose(out);
+    out = fopen((dir + "/pu.bin").c_str(), "wb");
+    fwrite(g_pus.data(), sizeof(PuRec), g_pus.size(), out);
     fclose(out);
     fprintf(stderr, "enc_capture: %d pictures in %.2f s, bitstream hash %016llx\n", got,
             (ts1.tv_sec - ts0.tv_sec) + (ts1.tv_nsec - ts0.tv_nsec) * 1e-9, (unsigned long long)hash);

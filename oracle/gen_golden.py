@@ -10,6 +10,8 @@ been run.  The fixtures hold inputs and the reference's outputs (data, no refere
   bitcost.npz CRC32 and probe entries of BitCost::setQP's table for qp 0..69
   lowres.npz  CRC32s of the 12 lookahead planes (frame_init_lowres_core + extendPicBorder) of the same pictures and
               motionEstimate call records against them (ref->isLowres)
+  encoder_pu.npz  the prediction units of a reference encoder run: their iterations, xGetBlkBits / lambda, and what
+              predInterSearch left in the CU (direction, vectors, AMVP indices) -- see gen_encoder_pu
   me.npz      motionEstimate call records (inputs) and (cost, qmv) results on a small synthetic
               sequence for every search method and sub-pel level, plus two per-CTU full searches
 
@@ -254,6 +256,72 @@ def gen_encoder():
                                                                               int(calls["lowres"].sum()), len(planes)))
 
 
+CAPTURE_PU = np.dtype([("call", "<i4", (8,)), ("call_list", "u1", (8,)), ("call_ref", "u1", (8,)), ("n_calls", "u1"), ("is_p", "u1"),
+                       ("part_size", "u1"), ("part_idx", "u1"), ("num_ref", "u1", (2,)), ("bipred_restriction", "u1"), ("complete", "u1"),
+                       ("list_sel_bits", "u1", (3,)), ("merge_flag", "u1"), ("inter_dir", "u1"), ("pad", "u1", (3,)), ("lambda_sad", "<u4"),
+                       ("mv", "<i2", (4,)), ("ref", "i1", (2,)), ("mvp_idx", "i1", (2,))])
+assert CAPTURE_PU.itemsize == 80  # PuRec of oracle/enc_capture.cpp
+
+
+def gen_encoder_pu():
+    """What predInterSearch left in the CU for every prediction unit (oracle/enc_capture.cpp, pu.bin): the same encoder
+    run as gen_encoder with the first 3600 full-resolution calls kept -- the first P picture and the B pictures behind
+    it -- and, per unit whose calls are all among them, the x265_hip_inter_pu record (xGetBlkBits, lambda, reference
+    counts) with the encoder's own outcome: direction, vectors, references and AMVP indices after xCheckBestMVP and the
+    bidirectional stage.  The planes are this run's own snapshots."""
+    import subprocess
+    cap = os.path.join(HERE, "_ref", "capture_pu")
+    exe = os.path.join(HERE, "_ref", "enc_capture")
+    os.makedirs(cap, exist_ok=True)
+    W, H, N = 416, 240, 40
+    seq = synth.Sequence(W, H, seed=7, n_patches=3)
+    with open(os.path.join(cap, "in.yuv"), "wb") as f:
+        for i in range(N):
+            f.write(seq.frame(i).astype(np.uint8).tobytes())
+            f.write(bytes([128]) * (W * H // 2))
+    subprocess.check_call([exe, os.path.join(cap, "in.yuv"), str(W), str(H), str(N), cap, "3600", "0"])
+    calls = np.fromfile(os.path.join(cap, "calls.bin"), dtype=CAPTURE_CALL)
+    amvp = np.fromfile(os.path.join(cap, "amvp.bin"), dtype=CAPTURE_AMVP)
+    pus = np.fromfile(os.path.join(cap, "pu.bin"), dtype=CAPTURE_PU)
+    pus = pus[(pus["complete"] == 1) & (pus["n_calls"] == pus["num_ref"].sum(axis=1))]
+    raw = open(os.path.join(cap, "planes.bin"), "rb").read()
+    planes, pos = [], 0
+    while pos < len(raw):
+        pid, stride, origin, nbytes = (int(v) for v in np.frombuffer(raw, dtype="<i4", count=4, offset=pos))
+        planes.append((np.frombuffer(raw, dtype=np.uint8, count=nbytes, offset=pos + 16).copy(), origin, stride))
+        pos += 16 + nbytes
+    # the units' iterations as one job list, unit after unit (list 0's references, then list 1's)
+    order = np.concatenate([p["call"][:p["n_calls"]] for p in pus])
+    for p in pus:
+        n0 = int(p["num_ref"][0])
+        assert list(p["call_list"][:p["n_calls"]]) == [0] * n0 + [1] * (int(p["n_calls"]) - n0)
+        assert list(p["call_ref"][:n0]) == list(range(n0))
+    ij = np.zeros(len(order), pyoracle.INTER_JOB)
+    for k in ("fenc_plane", "ref_plane", "pu_x", "pu_y", "pu_w", "pu_h", "method", "subme", "merange", "num_mvc", "qp", "mvc"):
+        ij[k] = calls[k][order]
+    for k in ("pred_plane", "cu_x", "cu_y", "amvp", "num_amvp"):
+        ij[k] = amvp[k][order]
+    ij["ref_lag"] = H
+    res = np.zeros(len(order), pyoracle.ME_RESULT)
+    for k in ("cost", "mvx", "mvy"):
+        res[k] = calls[k][order]
+    rec = np.zeros(len(pus), pyoracle.INTER_PU)
+    rec["first_job"] = np.concatenate([[0], np.cumsum(pus["n_calls"])[:-1]])
+    rec["num_ref"], rec["list_sel_bits"], rec["lambda_sad"] = pus["num_ref"], pus["list_sel_bits"], pus["lambda_sad"]
+    rec["no_bidir"] = (pus["is_p"] != 0) | (pus["bipred_restriction"] != 0)
+    final = np.zeros(len(pus), np.dtype([("merge_flag", "u1"), ("inter_dir", "u1"), ("mv", "<i2", (4,)), ("ref", "i1", (2,)), ("mvp_idx", "i1", (2,))]))
+    for k in final.dtype.names:
+        final[k] = pus[k]
+    used = sorted(set(ij["fenc_plane"]) | set(ij["ref_plane"]) | set(ij["pred_plane"]))
+    assert used == list(range(len(used)))
+    planes = planes[:len(used)]
+    geo = np.array([(len(b), o, s) for (b, o, s) in planes], np.int32)
+    np.savez_compressed(os.path.join(OUT, "encoder_pu.npz"), inter_jobs=ij, me_results=res, pus=rec, final=final, plane_geo=geo,
+                        plane_bytes=np.concatenate([b for (b, _, _) in planes]), pic_size=np.array([W, H], np.int32))
+    print("encoder_pu: %d units (%d of B pictures, %d bidirectional), %d iterations, %d planes" % (
+        len(pus), int((pus["is_p"] == 0).sum()), int((pus["inter_dir"] == 3).sum()), len(order), len(planes)))
+
+
 def main():
     if not pyoracle.have_ref():
         sys.exit("oracle/_ref/libx265ref.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -266,6 +334,7 @@ def main():
     gen_dist(R)
     gen_pred(R)
     gen_encoder()
+    gen_encoder_pu()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
@@ -273,5 +342,7 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "encoder":
         gen_encoder()
+    elif len(sys.argv) > 1 and sys.argv[1] == "encoder_pu":
+        gen_encoder_pu()
     else:
         main()

@@ -76,6 +76,15 @@ INTER_RESULT = np.dtype([
     ("mvp_idx", "u1"), ("pad", "u1", (3,)),
 ])
 assert INTER_RESULT.itemsize == 32
+INTER_PU = np.dtype([("first_job", "<i4"), ("num_ref", "u1", (2,)), ("list_sel_bits", "u1", (3,)), ("no_bidir", "u1"), ("pad", "u1", (2,)),
+                     ("lambda_sad", "<u4")])
+assert INTER_PU.itemsize == 16
+INTER_SIDE = np.dtype([("cost", "<u4"), ("bits", "<i4"), ("mvx", "<i2"), ("mvy", "<i2"), ("mvp_x", "<i2"), ("mvp_y", "<i2"), ("ref", "i1"),
+                       ("mvp_idx", "i1"), ("pad", "u1", (2,))])
+assert INTER_SIDE.itemsize == 20
+INTER_PU_RESULT = np.dtype([("list", INTER_SIDE, (2,)), ("bidir", INTER_SIDE, (2,)), ("bidir_cost", "<u4"), ("bidir_bits", "<i4"),
+                            ("inter_dir", "u1"), ("zero_tried", "u1"), ("pad", "u1", (2,))])
+assert INTER_PU_RESULT.itemsize == 92
 
 
 LOOKAHEAD_JOB = np.dtype([
@@ -237,6 +246,26 @@ class Checker:
             keep.append(t)
             tabs[qp] = t.ctypes.data
         self._f("inter_search_batch")(self._planes(planes), tabs, _ptr(jobs), C.c_int(len(jobs)), C.c_int(pic_w), C.c_int(pic_h), _ptr(out))
+        return out
+
+    def mv_bits(self, x, y, px, py):
+        """BitCost::bitcost of vector (x, y) against predictor (px, py)"""
+        return int(self._f("mv_bits", C.c_int)(C.c_int(x), C.c_int(y), C.c_int(px), C.c_int(py)))
+
+    def inter_decide_batch(self, planes, costtabs, jobs, results, pus, pic_w, pic_h):
+        """predInterSearch behind its iterations (oracle only): bits, xCheckBestMVP, the bidirectional candidate, the choice"""
+        jobs = np.ascontiguousarray(jobs, dtype=INTER_JOB)
+        results = np.ascontiguousarray(results, dtype=INTER_RESULT)
+        pus = np.ascontiguousarray(pus, dtype=INTER_PU)
+        out = np.zeros(len(pus), INTER_PU_RESULT)
+        tabs = (C.c_void_p * 256)()
+        keep = []
+        for qp, t in costtabs.items():
+            t = np.ascontiguousarray(t, np.uint16)
+            keep.append(t)
+            tabs[qp] = t.ctypes.data
+        self._f("inter_decide_batch")(self._planes(planes), tabs, _ptr(jobs), _ptr(results), _ptr(pus), C.c_int(len(pus)), C.c_int(pic_w),
+                                      C.c_int(pic_h), _ptr(out))
         return out
 
     def lookahead_batch(self, planes, costtabs, jobs, width_in_cu, height_in_cu, nthreads=1):

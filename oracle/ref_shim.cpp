@@ -134,6 +134,16 @@ void x265r_bitcost_table(int qp, uint16_t *out)
     out[0] = out[1];
 }
 
+/* BitCost::bitcost (bitcost.h:48-52) with the predictor set by setMVP, as predInterSearch and xCheckBestMVP use it */
+int x265r_mv_bits(int x, int y, int px, int py)
+{
+    init();
+    CostPeek p;
+    p.centre(30); /* (CalculateLogs: the bit sizes do not depend on the QP) */
+    p.setMVP(MV(px, py));
+    return p.bitcost(MV(x, y));
+}
+
 static void run_me(MotionEstimate &me, const x265o_plane *planes, const x265o_me_job *j, x265o_me_result *r)
 {
     const x265o_plane &f = planes[j->fenc_plane];

@@ -467,6 +467,7 @@ static inline int in_range(int x, int y, mv_t lo, mv_t hi)
 }
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
 
 /* tables                                                ref: motion.cpp:129-149 */
 static const int8_t k_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
@@ -1589,6 +1590,166 @@ void x265o_inter_search_batch(const x265o_plane *planes, const uint16_t *const *
         r->mvmin_x = m.mvmin_x, r->mvmin_y = m.mvmin_y, r->mvmax_x = m.mvmax_x, r->mvmax_y = m.mvmax_y;
         r->mvp_x = m.qmvp_x, r->mvp_y = m.qmvp_y;
         r->mvp_idx = (uint8_t)pick;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* predInterSearch behind its iterations: bits, xCheckBestMVP, the bidirectional candidate, the choice */
+
+/* ref: BitCost::CalculateLogs, encoder/bitcost.cpp:68-80: s_bitsizes[0] = 0.718f, [i] = log(i + 1) * (2 / ln 2) + 1.718f
+ * (the logarithm in double, as in x265o_bitcost_table) */
+static float g_bitsizes[32769];
+static void bitsizes_init(void)
+{
+    static int done = 0;
+    if (done)
+        return;
+    const float two_over_ln2 = (float)(2.0f / log((double)2.0f));
+    g_bitsizes[0] = 0.718f;
+    for (int i = 1; i <= 32768; i++)
+        g_bitsizes[i] = (float)(log((double)(float)(i + 1)) * two_over_ln2 + 1.718f);
+    done = 1;
+}
+
+/* ref: BitCost::bitcost, encoder/bitcost.h:48-52 (differences beyond the table's 16383 quarter samples, which the
+ * reference reads out of bounds, take its last entry here) */
+int x265o_mv_bits(int x, int y, int px, int py)
+{
+    bitsizes_init();
+    int ix = (abs(x - px) << 1) + (x < px), iy = (abs(y - py) << 1) + (y < py);
+    if (ix > 32768)
+        ix = 32768;
+    if (iy > 32768)
+        iy = 32768;
+    volatile float sum = g_bitsizes[ix] + g_bitsizes[iy];
+    volatile float r = sum + 0.5f;
+    return (uint16_t)r;
+}
+
+/* ref: RDCost::getCost, encoder/rdcost.h:112-115 */
+static uint32_t rd_cost_of_bits(uint32_t bits, uint32_t lambda_sad) { return (uint32_t)(((uint64_t)bits * lambda_sad + 128) >> 8); }
+
+/* ref: TEncSearch::xCheckBestMVP, TEncSearch.cpp:2565-2598 (AMVP_MAX_NUM_CANDS = 2, MVP_IDX_BITS = 1) */
+void x265o_check_best_mvp(const int16_t cand[4], int mvx, int mvy, int *mvp_idx, uint32_t *bits, uint32_t *cost, uint32_t lambda_sad)
+{
+    const int cur = *mvp_idx;
+    const int orig = x265o_mv_bits(mvx, mvy, cand[2 * cur], cand[2 * cur + 1]) + 1;
+    int best_bits = orig, best = cur;
+    for (int i = 0; i < 2; i++)
+    {
+        if (i == cur)
+            continue;
+        int b = x265o_mv_bits(mvx, mvy, cand[2 * i], cand[2 * i + 1]) + 1;
+        if (b < best_bits)
+        {
+            best_bits = b;
+            best = i;
+        }
+    }
+    if (best != cur)
+    {
+        const uint32_t before = *bits;
+        *mvp_idx = best;
+        *bits = before - orig + best_bits;
+        *cost = (*cost - rd_cost_of_bits(before, lambda_sad)) + rd_cost_of_bits(*bits, lambda_sad);
+    }
+}
+
+void x265o_inter_decide_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_inter_job *jobs,
+                              const x265o_inter_result *res, const x265o_inter_pu *pus, int npu, int pic_w, int pic_h,
+                              x265o_inter_pu_result *out)
+{
+    for (int u = 0; u < npu; u++)
+    {
+        const x265o_inter_pu *p = &pus[u];
+        x265o_inter_pu_result *o = &out[u];
+        memset(o, 0, sizeof(*o));
+        o->list[0].cost = o->list[1].cost = o->bidir_cost = UINT32_MAX;
+        const x265o_inter_job *jl[2] = { 0, 0 }; /* the job of each list's best reference */
+        int k = p->first_job;
+        /* ref: TEncSearch.cpp:2303-2358 */
+        for (int l = 0; l < 2; l++)
+            for (int ref = 0; ref < p->num_ref[l]; ref++, k++)
+            {
+                const x265o_inter_job *q = &jobs[k];
+                const x265o_inter_result *r = &res[k];
+                uint32_t bits = p->list_sel_bits[l] + 1 + (uint32_t)(ref + (ref < p->num_ref[l] - 1)); /* MVP_IDX_BITS, getTUBits */
+                bits += (uint32_t)x265o_mv_bits(r->mvx, r->mvy, r->mvp_x, r->mvp_y);
+                const int mvc = (uint16_t)(tab_at(costtabs[q->qp], r->mvp_x, r->mvx) + tab_at(costtabs[q->qp], r->mvp_y, r->mvy));
+                uint32_t cost = (uint32_t)(r->cost - mvc) + rd_cost_of_bits(bits, p->lambda_sad);
+                int idx = r->mvp_idx;
+                x265o_check_best_mvp(q->amvp, r->mvx, r->mvy, &idx, &bits, &cost, p->lambda_sad);
+                if (cost < o->list[l].cost)
+                {
+                    x265o_inter_side *s = &o->list[l];
+                    s->cost = cost, s->bits = (int32_t)bits;
+                    s->mvx = r->mvx, s->mvy = r->mvy;
+                    s->mvp_x = q->amvp[2 * idx], s->mvp_y = q->amvp[2 * idx + 1];
+                    s->ref = (int8_t)ref, s->mvp_idx = (int8_t)idx;
+                    jl[l] = q;
+                }
+            }
+        /* ref: TEncSearch.cpp:2360-2439 */
+        if (!p->no_bidir && o->list[0].cost != UINT32_MAX && o->list[1].cost != UINT32_MAX)
+        {
+            const x265o_inter_job *q0 = jl[0], *q1 = jl[1];
+            const int sel = p->list_sel_bits[2] - (p->list_sel_bits[0] + p->list_sel_bits[1]);
+            o->bidir[0] = o->list[0];
+            o->bidir[1] = o->list[1];
+            int satd = x265o_bidir_cost(&planes[q0->fenc_plane], &planes[q0->pred_plane], &planes[q1->pred_plane], q0->pu_x, q0->pu_y, q0->pu_w,
+                                        q0->pu_h, o->list[0].mvx, o->list[0].mvy, o->list[1].mvx, o->list[1].mvy, X265O_SATD);
+            o->bidir_bits = o->list[0].bits + o->list[1].bits + sel;
+            o->bidir_cost = (uint32_t)satd + rd_cost_of_bits((uint32_t)o->bidir_bits, p->lambda_sad);
+            int try_zero = (o->list[0].mvx | o->list[0].mvy | o->list[1].mvx | o->list[1].mvy) != 0;
+            if (try_zero)
+            {
+                /* xSetSearchRange around the zero vector with merange = the larger picture side (:2600-2617) */
+                const int d = s16(imax(pic_w, pic_h) << 2);
+                int px = 0, py = 0;
+                clip_mv(&px, &py, q0->cu_x, q0->cu_y, pic_w, pic_h);
+                int lox = s16(px - d), loy = s16(py - d), hix = s16(px + d), hiy = s16(py + d);
+                clip_mv(&lox, &loy, q0->cu_x, q0->cu_y, pic_w, pic_h);
+                clip_mv(&hix, &hiy, q0->cu_x, q0->cu_y, pic_w, pic_h);
+                int minx = lox >> 2, maxx = hix >> 2, miny = imin(loy >> 2, q0->ref_lag), maxy = imin(hiy >> 2, q0->ref_lag);
+                maxy = s16(maxy + 2);
+                minx = s16(minx << 2), miny = s16(miny << 2), maxx = s16(maxx << 2), maxy = s16(maxy << 2);
+                for (int l = 0; l < 2; l++)
+                    try_zero &= o->list[l].mvp_x >= minx && o->list[l].mvp_x <= maxx && o->list[l].mvp_y >= miny && o->list[l].mvp_y <= maxy;
+            }
+            o->zero_tried = (uint8_t)try_zero;
+            if (try_zero)
+            {
+                /* the coincident blocks of the two searched planes (m_mref[l][ref]->fpelPlane) */
+                satd = x265o_bidir_cost(&planes[q0->fenc_plane], &planes[q0->ref_plane], &planes[q1->ref_plane], q0->pu_x, q0->pu_y, q0->pu_w, q0->pu_h,
+                                        0, 0, 0, 0, X265O_SATD);
+                uint32_t bits[2], cost;
+                int idx[2];
+                for (int l = 0; l < 2; l++)
+                {
+                    const x265o_inter_side *s = &o->list[l];
+                    idx[l] = s->mvp_idx;
+                    bits[l] = (uint32_t)(s->bits - x265o_mv_bits(s->mvx, s->mvy, s->mvp_x, s->mvp_y) + x265o_mv_bits(0, 0, s->mvp_x, s->mvp_y));
+                }
+                cost = (uint32_t)satd + rd_cost_of_bits(bits[0], p->lambda_sad) + rd_cost_of_bits(bits[1], p->lambda_sad);
+                x265o_check_best_mvp(q0->amvp, 0, 0, &idx[0], &bits[0], &cost, p->lambda_sad);
+                x265o_check_best_mvp(q1->amvp, 0, 0, &idx[1], &bits[1], &cost, p->lambda_sad);
+                if (cost < o->bidir_cost)
+                {
+                    const x265o_inter_job *qq[2] = { q0, q1 };
+                    for (int l = 0; l < 2; l++)
+                    {
+                        o->bidir[l].mvx = o->bidir[l].mvy = 0;
+                        o->bidir[l].mvp_x = qq[l]->amvp[2 * idx[l]], o->bidir[l].mvp_y = qq[l]->amvp[2 * idx[l] + 1];
+                        o->bidir[l].mvp_idx = (int8_t)idx[l];
+                        o->bidir[l].bits = (int32_t)bits[l];
+                    }
+                    o->bidir_cost = cost;
+                    o->bidir_bits = (int32_t)(bits[0] + bits[1]) + sel;
+                }
+            }
+        }
+        /* ref: TEncSearch.cpp:2449-2499 without the merge candidate */
+        o->inter_dir = (o->bidir_cost < o->list[0].cost && o->bidir_cost < o->list[1].cost) ? 3 : (o->list[0].cost <= o->list[1].cost ? 1 : 2);
     }
 }
 

@@ -141,6 +141,44 @@ typedef struct x265o_inter_result
 void x265o_inter_search_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_inter_job *jobs, int n,
                               int pic_w, int pic_h, x265o_inter_result *out);
 
+/* What predInterSearch does with a prediction unit's iterations (TEncSearch.cpp:2342-2358, 2360-2439, 2449-2499):
+ * bits and cost of every iteration with xCheckBestMVP's second look at the AMVP index (:2565-2598), the best reference per
+ * list, the bidirectional candidate with its zero-vector variant, and the choice between the three.  Same layout as
+ * x265_hip_inter_pu / x265_hip_inter_side / x265_hip_inter_pu_result. */
+typedef struct x265o_inter_pu
+{
+    int32_t first_job;        /* its iterations: jobs first_job .., list 0's references in order, then list 1's */
+    uint8_t num_ref[2];       /* numRefIdx[l]; num_ref[1] = 0 in a P slice */
+    uint8_t list_sel_bits[3]; /* xGetBlkBits */
+    uint8_t no_bidir;         /* a P slice, or TComDataCU::isBipredRestriction */
+    uint8_t pad[2];
+    uint32_t lambda_sad;      /* RDCost::m_lambdaSAD */
+} x265o_inter_pu;
+typedef struct x265o_inter_side
+{
+    uint32_t cost; /* UINT32_MAX: none */
+    int32_t bits;
+    int16_t mvx, mvy, mvp_x, mvp_y;
+    int8_t ref, mvp_idx;
+    uint8_t pad[2];
+} x265o_inter_side;
+typedef struct x265o_inter_pu_result
+{
+    x265o_inter_side list[2];  /* the best iteration of each list */
+    x265o_inter_side bidir[2]; /* the two halves of the bidirectional candidate (cost, bits: as list[] or the zero-vector form's) */
+    uint32_t bidir_cost;       /* UINT32_MAX: not tried */
+    int32_t bidir_bits;
+    uint8_t inter_dir;         /* the cheapest of the three: 1 list 0, 2 list 1, 3 both (merge is the caller's to compare) */
+    uint8_t zero_tried, pad[2];
+} x265o_inter_pu_result;
+/* BitCost::bitcost (bitcost.h:48-52) of vector (x, y) against predictor (px, py), quarter-pel */
+int x265o_mv_bits(int x, int y, int px, int py);
+/* xCheckBestMVP (TEncSearch.cpp:2565-2598): cand = m_mvCand[0..1] as x y pairs */
+void x265o_check_best_mvp(const int16_t cand[4], int mvx, int mvy, int *mvp_idx, uint32_t *bits, uint32_t *cost, uint32_t lambda_sad);
+void x265o_inter_decide_batch(const x265o_plane *planes, const uint16_t *const *costtabs, const x265o_inter_job *jobs,
+                              const x265o_inter_result *res, const x265o_inter_pu *pus, int npu, int pic_w, int pic_h,
+                              x265o_inter_pu_result *out);
+
 /* the motion search of a whole lookahead frame cost estimate, one (picture, reference) pair per job: EstimateRow::
  * estimateCUCost's list loop (encoder/slicetype.cpp:1540-1584) over every 8x8 CU; same layout as x265_hip_lookahead_job */
 typedef struct x265o_lookahead_job

@@ -237,6 +237,55 @@ def test_inter_search_iterations_match_the_reference_encoder(oracle):
     check_inter(out, mej, res)
 
 
+def pu_fixture():
+    """encoder_pu.npz: the prediction units of a reference encoder run (oracle/gen_golden.py gen_encoder_pu): planes, the
+    units' iterations as x265_hip_inter_job records with motionEstimate's own results, the x265_hip_inter_pu records,
+    and what predInterSearch left in the CU for each unit"""
+    g = np.load(os.path.join(GOLD, "encoder_pu.npz"))
+    planes, pos = [], 0
+    for nbytes, origin, stride in g["plane_geo"]:
+        planes.append((g["plane_bytes"][pos:pos + nbytes], int(origin), int(stride)))
+        pos += nbytes
+    return planes, g["inter_jobs"], g["me_results"], g["pus"], g["final"], int(g["pic_size"][0]), int(g["pic_size"][1])
+
+
+def check_pu_decisions(out, pus, final):
+    """direction, vectors, references and AMVP indices of every unit as the encoder's (no unit of the run merged: the
+    medium preset's units are all 2Nx2N, which have no merge candidate here, TEncSearch.cpp:2264)"""
+    assert not final["merge_flag"].any()
+    assert np.array_equal(out["inter_dir"], final["inter_dir"])
+    n = {1: 0, 2: 0, 3: 0}
+    for o, f in zip(out, final):
+        d = int(f["inter_dir"])
+        n[d] += 1
+        for l in (0, 1):
+            if not d & (1 << l):
+                continue
+            s = o["bidir"][l] if d == 3 else o["list"][l]
+            assert (s["mvx"], s["mvy"]) == tuple(f["mv"][2 * l:2 * l + 2]), (o, f)
+            assert s["mvp_idx"] == f["mvp_idx"][l] and o["list"][l]["ref"] == f["ref"][l], (o, f)
+    return n
+
+
+def test_pu_decisions_match_the_reference_encoder(oracle):
+    """x265o_inter_decide_batch against what TEncSearch::predInterSearch left in the CU: 1981 prediction units of the
+    first P picture and the B pictures behind it; xCheckBestMVP changes the AMVP index of some, the bidirectional
+    candidate wins some, and its zero-vector form is tried"""
+    from oracle import pyoracle
+    planes, ij, mres, pus, final, W, H = pu_fixture()
+    ij, pus = ij.view(pyoracle.INTER_JOB), pus.view(pyoracle.INTER_PU)
+    tabs = {int(q): oracle.bitcost_table(int(q)) for q in np.unique(ij["qp"])}
+    res = oracle.inter_search_batch(planes, tabs, ij, W, H)
+    for k in ("cost", "mvx", "mvy"):
+        assert np.array_equal(res[k], mres[k]), k
+    out = oracle.inter_decide_batch(planes, tabs, ij, res, pus, W, H)
+    n = check_pu_decisions(out, pus, final)
+    assert len(pus) == 1981 and n[3] > 100 and n[2] > 100 and out["zero_tried"].sum() > 50
+    # xCheckBestMVP moved the index away from the candidate the SAD pick chose
+    first = res["mvp_idx"][pus["first_job"]]
+    assert (out["list"]["mvp_idx"][:, 0] != first)[pus["num_ref"][:, 0] == 1].sum() > 10
+
+
 def lookahead_fixture():
     """the frame cost estimates encoder_me.npz holds completely: (planes, lookahead jobs, width and height in CUs, what
     the reference encoder's own motionEstimate calls returned for every CU, shaped (n, H, W))"""

@@ -223,3 +223,14 @@ def test_bidir_cost_mc_average_and_all_metrics(oracle, ref, small_seq):
     bad = np.nonzero(a != b)[0]
     assert len(bad) == 0, (reqs[bad[0]], a[bad[0]], b[bad[0]])
     assert (reqs["metric"] & 0x40).any() and (reqs["metric"] & 3 == 2).any()
+
+
+def test_mv_bits_match_the_reference(oracle, ref):
+    """BitCost::bitcost restated (x265o_mv_bits) against the reference's own, over differences of every size and sign"""
+    rng = np.random.default_rng(48)
+    for _ in range(4000):
+        s = int(rng.choice([3, 40, 400, 4000, 16000]))
+        x, y, px, py = (int(v) for v in rng.integers(-s, s + 1, 4))
+        if abs(x - px) > 16383 or abs(y - py) > 16383:
+            continue
+        assert oracle.mv_bits(x, y, px, py) == ref.mv_bits(x, y, px, py), (x, y, px, py)
