@@ -509,6 +509,58 @@ int x265_hip_inter_search_batch(x265_hip_ctx *ctx, const x265_hip_inter_job *job
 int x265_hip_inter_search_batch_device(x265_hip_ctx *ctx, const void *d_jobs, int n, int pic_width, int pic_height,
                                        void *d_results);
 
+/* The rest of predInterSearch for a prediction unit, behind its iterations (reference
+ * source/Lib/TLibEncoder/TEncSearch.cpp:2342-2358, 2360-2439, 2449-2499), on the device from the iterations' results:
+ *   4. bits and cost of every iteration -- list selection (xGetBlkBits) + MVP_IDX_BITS + getTUBits(ref) +
+ *      BitCost::bitcost(outmv), cost = (motionEstimate's cost - mvcost(outmv)) + RDCost::getCost(bits) -- with
+ *      xCheckBestMVP's second look at the AMVP index (:2565-2598), and the first cheapest reference of each list;
+ *   5. the bidirectional candidate (B slices without TComDataCU::isBipredRestriction, both lists searched): SATD of the
+ *      block against pixelavg_pp of the two predictions, and its zero-vector form where both predictors pass the range
+ *      check of :2400-2412, each half through xCheckBestMVP;
+ *   6. the cheapest of list 0, list 1 and both (:2449-2499; the merge candidate's cost is the caller's to compare).
+ * BitCost's float table of bit sizes (bitcost.cpp:68-80) is made inside the library the way the reference makes it
+ * and lives in device memory beside the cost tables.  What stays with the caller: fillMvpCand, xGetBlkBits' three
+ * numbers (they depend on the partition and on the previous unit's mode), lambda, merge estimation, and writing the
+ * outcome into the CU. */
+typedef struct x265_hip_inter_pu
+{
+    int32_t first_job;        /* its iterations are jobs first_job .. of the job list: list 0's references 0 .., then list 1's */
+    uint8_t num_ref[2];       /* numRefIdx[l] (at most 16 each, one at least in all); num_ref[1] = 0 in a P slice */
+    uint8_t list_sel_bits[3]; /* xGetBlkBits (TEncSearch.cpp:2301, 2507-2563) */
+    uint8_t no_bidir;         /* a P slice, or TComDataCU::isBipredRestriction */
+    uint8_t pad[2];
+    uint32_t lambda_sad;      /* RDCost::m_lambdaSAD (rdcost.h:50-54) */
+} x265_hip_inter_pu;
+
+typedef struct x265_hip_inter_side /* MotionData of predInterSearch */
+{
+    uint32_t cost; /* UINT32_MAX: none */
+    int32_t bits;
+    int16_t mvx, mvy, mvp_x, mvp_y;
+    int8_t ref, mvp_idx;
+    uint8_t pad[2];
+} x265_hip_inter_side;
+
+typedef struct x265_hip_inter_pu_result
+{
+    x265_hip_inter_side list[2];  /* list[l] of the reference: the best iteration of each list */
+    x265_hip_inter_side bidir[2]; /* bidir[l]: vectors, predictors and AMVP indices of the bidirectional candidate */
+    uint32_t bidir_cost;          /* UINT32_MAX: no such candidate */
+    int32_t bidir_bits;
+    uint8_t inter_dir;            /* 1 list 0, 2 list 1, 3 both */
+    uint8_t zero_tried;           /* the zero-vector form was measured */
+    uint8_t pending, pad;         /* (internal; 0 in results) */
+} x265_hip_inter_pu_result;
+
+/* Steps 1-3 for every job (x265_hip_inter_search_batch), then steps 4-6 for every unit, chained on the context's stream
+ * without a host round trip.  job_results (njobs records) may be NULL in the host-array form.  The `_device` form keeps
+ * internal arrays in device memory, grown on demand; any_bidir = 0 promises that every unit has no_bidir set (a P
+ * picture) and skips the bidirectional kernels. */
+int x265_hip_inter_decide_batch(x265_hip_ctx *ctx, const x265_hip_inter_job *jobs, int njobs, const x265_hip_inter_pu *pus, int npu,
+                                int pic_width, int pic_height, x265_hip_inter_result *job_results, x265_hip_inter_pu_result *results);
+int x265_hip_inter_decide_batch_device(x265_hip_ctx *ctx, const void *d_jobs, int njobs, const void *d_pus, int npu, int pic_width,
+                                       int pic_height, void *d_job_results, void *d_results, int any_bidir);
+
 /* Exhaustive integer-pel search of every square PU (64,32,16,8: 85 per CTU) of the listed 64x64
  * CTUs over [mvmin, mvmax], SAD + mvcost, first minimum in raster order -- the integer stage of
  * motionEstimate with X265_FULL_SEARCH (motion.cpp:997-1032) started from bcost = INT_MAX, with

@@ -174,6 +174,54 @@ def test_inter_search_stage_reproduces_the_reference_encoder():
     ctx.close()
 
 
+def test_pu_decisions_reproduce_the_reference_encoder(oracle):
+    """x265_hip_inter_decide_batch on the prediction units captured inside the reference encoder (encoder_pu.npz): what
+    predInterSearch left in the CU for each of them -- direction, vectors, references, AMVP indices after xCheckBestMVP
+    and the bidirectional stage -- and every field of the result as the oracle's; through the host-array and the
+    device-array entry point, and a P-only list with the bidirectional kernels skipped"""
+    from test_oracle_golden import check_pu_decisions, pu_fixture
+    from x265_amd import abi, lib
+    from x265_amd.hipmem import DeviceBuffer
+    planes, ij, mres, pus, final, W, H = pu_fixture()
+    ij, pus = ij.view(abi.INTER_JOB), pus.view(abi.INTER_PU)
+    ctx = lib.Context(0)
+    for i, (buf, origin, stride) in enumerate(planes):
+        ctx.plane_upload(i, buf, stride, origin)
+    tabs = {}
+    for q in np.unique(ij["qp"]):
+        ctx.set_qp(int(q))
+        tabs[int(q)] = lib.costtab_build(int(q))
+    res, out = ctx.inter_decide_batch(ij, pus, W, H)
+    for k in ("cost", "mvx", "mvy"):
+        assert np.array_equal(res[k], mres[k]), k
+    n = check_pu_decisions(out, pus, final)
+    assert n[3] > 100 and out["zero_tried"].sum() > 50
+    want = oracle.inter_decide_batch(planes, tabs, ij, oracle.inter_search_batch(planes, tabs, ij, W, H), pus, W, H)
+    assert out.tobytes() == want.tobytes()
+    # device arrays
+    d_j, d_p = DeviceBuffer.from_array(ij), DeviceBuffer.from_array(pus)
+    d_r, d_o = DeviceBuffer(len(ij) * abi.INTER_RESULT.itemsize), DeviceBuffer(len(pus) * abi.INTER_PU_RESULT.itemsize)
+    ctx.inter_decide_batch_device(d_j.ptr, len(ij), d_p.ptr, len(pus), W, H, d_r.ptr, d_o.ptr)
+    ctx.sync()
+    assert d_o.download(abi.INTER_PU_RESULT).tobytes() == want.tobytes()
+    # the units of the P picture alone, without the bidirectional kernels
+    sel = np.nonzero(pus["no_bidir"] == 1)[0]
+    assert len(sel) > 500
+    pj = np.concatenate([ij[int(p["first_job"]):int(p["first_job"]) + int(p["num_ref"].sum())] for p in pus[sel]])
+    pp = pus[sel].copy()
+    pp["first_job"] = np.concatenate([[0], np.cumsum(pp["num_ref"].sum(axis=1))[:-1]])
+    d_j, d_p = DeviceBuffer.from_array(pj), DeviceBuffer.from_array(pp)
+    ctx.inter_decide_batch_device(d_j.ptr, len(pj), d_p.ptr, len(pp), W, H, d_r.ptr, d_o.ptr, any_bidir=False)
+    ctx.sync()
+    assert d_o.download(abi.INTER_PU_RESULT, len(pp)).tobytes() == want[sel].tobytes()
+    with pytest.raises(lib.X265HipError, match="iterations"):
+        bad = pus.copy()
+        bad["first_job"][7] = len(ij) - 1
+        bad["num_ref"][7] = (2, 1)
+        ctx.inter_decide_batch(ij, bad, W, H)
+    ctx.close()
+
+
 def test_lookahead_frames_reproduce_the_reference_encoder():
     """x265_hip_lookahead_batch on the lookahead pictures captured inside the reference encoder: the three frame cost
     estimates the capture holds completely (390 CUs each), every CU's cost and vector as the encoder's own"""

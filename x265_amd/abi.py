@@ -106,6 +106,16 @@ INTER_RESULT = np.dtype([
     ("mvp_idx", "u1"), ("pad", "u1", (3,)),
 ])
 assert INTER_RESULT.itemsize == 32
+# x265_hip_inter_pu / x265_hip_inter_side / x265_hip_inter_pu_result: predInterSearch behind its iterations
+INTER_PU = np.dtype([("first_job", "<i4"), ("num_ref", "u1", (2,)), ("list_sel_bits", "u1", (3,)), ("no_bidir", "u1"), ("pad", "u1", (2,)),
+                     ("lambda_sad", "<u4")])
+assert INTER_PU.itemsize == 16
+INTER_SIDE = np.dtype([("cost", "<u4"), ("bits", "<i4"), ("mvx", "<i2"), ("mvy", "<i2"), ("mvp_x", "<i2"), ("mvp_y", "<i2"), ("ref", "i1"),
+                       ("mvp_idx", "i1"), ("pad", "u1", (2,))])
+assert INTER_SIDE.itemsize == 20
+INTER_PU_RESULT = np.dtype([("list", INTER_SIDE, (2,)), ("bidir", INTER_SIDE, (2,)), ("bidir_cost", "<u4"), ("bidir_bits", "<i4"),
+                            ("inter_dir", "u1"), ("zero_tried", "u1"), ("pending", "u1"), ("pad", "u1")])
+assert INTER_PU_RESULT.itemsize == 92
 
 REFINE_SECTION = np.dtype([("count", "<i4"), ("pu_w", "u1"), ("pu_h", "u1"), ("pad", "u1", (2,))])
 assert REFINE_SECTION.itemsize == 8

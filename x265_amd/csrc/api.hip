@@ -92,6 +92,8 @@ struct x265_hip_ctx
     Buf in, out;       // staging of the host-array batch calls
     Buf mejobs;        // motionEstimate jobs made on the device by x265_hip_inter_search_batch (device side only is used)
     Buf route;         // motionEstimate launches: the list of large-block jobs me_route_kernel makes for me_big_kernel (device side only)
+    Buf bidir;         // x265_hip_inter_decide_batch: two bidir requests and two costs per unit (device side only)
+    float *bitsizes = nullptr; // BitCost::s_bitsizes (device)
     Buf look;          // x265_hip_lookahead_batch: row counters (64 bytes per search) behind one status word
     Buf prim_a, prim_b; // staging of the primitive thunks
 };
@@ -314,6 +316,20 @@ int x265_hip_ctx_create(int device, x265_hip_ctx **out)
     if (e == hipSuccess)
         e = hipMemset(c->batch_counter, 0, X265HIP_COST_COUNTER_BYTES);
     if (e == hipSuccess)
+        e = hipMalloc((void **)&c->bitsizes, 32769 * sizeof(float));
+    if (e == hipSuccess)
+    {
+        // BitCost::CalculateLogs (bitcost.cpp:68-80), in the reference's own precision: see x265_hip_costtab_build
+        std::vector<float> bs(32769);
+        const float scale = (float)(2.0f / log((double)2.0f));
+        bs[0] = 0.718f;
+        for (int i = 1; i <= 32768; i++)
+            bs[i] = (float)(log((double)(float)(i + 1)) * scale + 1.718f);
+        e = hipMemcpy(c->bitsizes, bs.data(), bs.size() * sizeof(float), hipMemcpyHostToDevice);
+        c->host_tabs.bitsizes = c->bitsizes;
+        c->tabs_dirty = true;
+    }
+    if (e == hipSuccess)
         e = hipMalloc((void **)&c->guard_words, 2 * sizeof(uint32_t));
     if (e == hipSuccess)
         e = hipMemcpy(c->guard_words, k_guard_clear, sizeof(k_guard_clear), hipMemcpyHostToDevice);
@@ -352,7 +368,7 @@ void x265_hip_ctx_destroy(x265_hip_ctx *c)
     for (int i = 0; i < X265_HIP_MAX_QP; i++)
         if (c->owned_tab[i])
             (void)hipFree(c->owned_tab[i]);
-    Buf *bufs[7] = { &c->in, &c->out, &c->prim_a, &c->prim_b, &c->mejobs, &c->look, &c->route };
+    Buf *bufs[8] = { &c->in, &c->out, &c->prim_a, &c->prim_b, &c->mejobs, &c->look, &c->route, &c->bidir };
     for (Buf *b : bufs)
     {
         if (b->d)
@@ -366,6 +382,8 @@ void x265_hip_ctx_destroy(x265_hip_ctx *c)
         (void)hipFree(c->batch_counter);
     if (c->guard_words)
         (void)hipFree(c->guard_words);
+    if (c->bitsizes)
+        (void)hipFree(c->bitsizes);
     if (c->ev_fork)
         (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join)
@@ -1308,6 +1326,117 @@ int x265_hip_inter_search_batch(x265_hip_ctx *c, const x265_hip_inter_job *jobs,
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(results, c->out.h, ob);
+    return X265_HIP_OK;
+}
+
+// ---- predInterSearch behind its iterations: bits, xCheckBestMVP, the bidirectional candidate, the choice ------------
+
+static int validate_inter_pus(const x265_hip_ctx *c, const x265_hip_inter_job *jobs, int njobs, const x265_hip_inter_pu *pus, int npu)
+{
+    for (int u = 0; u < npu; u++)
+    {
+        const x265_hip_inter_pu &p = pus[u];
+        const int n = p.num_ref[0] + p.num_ref[1];
+        if (p.num_ref[0] > 16 || p.num_ref[1] > 16 || n < 1 || p.first_job < 0 || (long)p.first_job + n > njobs)
+            return fail(X265_HIP_EINVAL, "inter_pu[%d]: iterations %d .. %d of %d jobs (%d + %d references)", u, p.first_job, p.first_job + n - 1, njobs,
+                        p.num_ref[0], p.num_ref[1]);
+        const x265_hip_inter_job &a = jobs[p.first_job];
+        for (int k = 0; k < n; k++)
+        {
+            const x265_hip_inter_job &q = jobs[p.first_job + k];
+            if (q.fenc_plane != a.fenc_plane || q.pu_x != a.pu_x || q.pu_y != a.pu_y || q.pu_w != a.pu_w || q.pu_h != a.pu_h)
+                return fail(X265_HIP_EINVAL, "inter_pu[%d]: its iterations are not of one block", u);
+            // the bidirectional candidate predicts from the reconstructed planes at the vectors the searches found in the
+            // searched planes: the two must be laid out alike for the searches' checks to cover it
+            if (c->host_tabs.planes[q.pred_plane].stride != c->host_tabs.planes[q.ref_plane].stride ||
+                c->plane_bytes[q.pred_plane] != c->plane_bytes[q.ref_plane] || c->plane_origin[q.pred_plane] != c->plane_origin[q.ref_plane])
+                return fail(X265_HIP_EINVAL, "inter_pu[%d]: planes %d and %d of iteration %d differ in layout", u, q.pred_plane, q.ref_plane, k);
+        }
+    }
+    return 0;
+}
+
+// (the caller holds the lock, has validated, and has pushed the tables)
+static int inter_decide_launch(x265_hip_ctx *c, const x265_hip_inter_job *d_jobs, int njobs, const x265_hip_inter_pu *d_pus, int npu, int pic_w, int pic_h,
+                               x265_hip_inter_result *d_job_results, x265_hip_inter_pu_result *d_results, bool any_bidir, bool any_routed)
+{
+    int r;
+    const size_t req_bytes = ((size_t)2 * npu * sizeof(x265_hip_bidir_req) + 255) & ~(size_t)255;
+    if (c->mejobs.cap < (size_t)njobs * sizeof(x265_hip_me_job) || c->bidir.cap < req_bytes + (size_t)2 * npu * sizeof(int32_t))
+        HIP_TRY(hipStreamSynchronize(c->stream)); // an earlier launch may still read a buffer that is about to be replaced
+    if ((r = ensure(c, c->mejobs, (size_t)njobs * sizeof(x265_hip_me_job), false)) || (r = ensure_route(c, njobs)) ||
+        (r = ensure(c, c->bidir, req_bytes + (size_t)2 * npu * sizeof(int32_t), false)))
+        return r;
+    x265_hip_bidir_req *bireq = (x265_hip_bidir_req *)c->bidir.d;
+    int32_t *satd = (int32_t *)((char *)c->bidir.d + req_bytes);
+    LAUNCH(launch_inter_search(c->dev_tabs, d_jobs, njobs, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d, d_job_results, me_route(c, njobs > 0, any_routed)));
+    LAUNCH(launch_inter_decide_lists(c->dev_tabs, d_jobs, d_job_results, d_pus, npu, pic_w, pic_h, d_results, bireq, c->stream));
+    if (any_bidir)
+    {
+        LAUNCH(launch_bidir_cost(c->dev_tabs, bireq, 2 * npu, satd, c->batch_counter, c->batch_parity ^= 1, c->stream));
+        LAUNCH(launch_inter_decide_bidir(c->dev_tabs, d_jobs, d_pus, npu, satd, d_results, c->stream));
+    }
+    return X265_HIP_OK;
+}
+
+int x265_hip_inter_decide_batch_device(x265_hip_ctx *c, const void *d_jobs, int njobs, const void *d_pus, int npu, int pic_w, int pic_h,
+                                       void *d_job_results, void *d_results, int any_bidir)
+{
+    if (!c || njobs < 0 || npu < 0 || pic_w <= 0 || pic_h <= 0 || (npu && (!d_jobs || !d_pus || !d_job_results || !d_results || njobs <= 0)))
+        return fail(X265_HIP_EINVAL, "inter_decide_batch_device: bad argument");
+    if (npu == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->check_records)
+    {
+        std::vector<x265_hip_inter_job> hj((size_t)njobs);
+        std::vector<x265_hip_inter_pu> hp((size_t)npu);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(hj.data(), d_jobs, hj.size() * sizeof(hj[0]), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hp.data(), d_pus, hp.size() * sizeof(hp[0]), hipMemcpyDeviceToHost));
+        int vr = validate_inter(c, hj.data(), njobs, pic_w, pic_h);
+        if (vr || (vr = validate_inter_pus(c, hj.data(), njobs, hp.data(), npu)))
+            return vr;
+    }
+    int r = push_tabs(c);
+    if (r)
+        return r;
+    return inter_decide_launch(c, (const x265_hip_inter_job *)d_jobs, njobs, (const x265_hip_inter_pu *)d_pus, npu, pic_w, pic_h,
+                               (x265_hip_inter_result *)d_job_results, (x265_hip_inter_pu_result *)d_results, any_bidir != 0, true);
+}
+
+int x265_hip_inter_decide_batch(x265_hip_ctx *c, const x265_hip_inter_job *jobs, int njobs, const x265_hip_inter_pu *pus, int npu, int pic_w, int pic_h,
+                                x265_hip_inter_result *job_results, x265_hip_inter_pu_result *results)
+{
+    if (!c || njobs < 0 || npu < 0 || pic_w <= 0 || pic_h <= 0 || (npu && (!jobs || !pus || !results || njobs <= 0)))
+        return fail(X265_HIP_EINVAL, "inter_decide_batch: bad argument");
+    if (npu == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int r = validate_inter(c, jobs, njobs, pic_w, pic_h);
+    if (r || (r = validate_inter_pus(c, jobs, njobs, pus, npu)))
+        return r;
+    bool any_bidir = false;
+    for (int u = 0; u < npu; u++)
+        any_bidir |= !pus[u].no_bidir;
+    // staging: jobs then units in `in`, iteration results then unit results in `out`
+    const size_t jb = ((size_t)njobs * sizeof(*jobs) + 255) & ~(size_t)255, pb = (size_t)npu * sizeof(*pus);
+    const size_t rb = ((size_t)njobs * sizeof(x265_hip_inter_result) + 255) & ~(size_t)255, ob = (size_t)npu * sizeof(*results);
+    if ((r = push_tabs(c)) || (r = ensure(c, c->in, jb + pb)) || (r = ensure(c, c->out, rb + ob)))
+        return r;
+    HIP_TRY(hipMemcpyAsync(c->in.d, jobs, (size_t)njobs * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync((char *)c->in.d + jb, pus, pb, hipMemcpyHostToDevice, c->stream));
+    r = inter_decide_launch(c, (const x265_hip_inter_job *)c->in.d, njobs, (const x265_hip_inter_pu *)((char *)c->in.d + jb), npu, pic_w, pic_h,
+                            (x265_hip_inter_result *)c->out.d, (x265_hip_inter_pu_result *)((char *)c->out.d + rb), any_bidir, any_routed_job(jobs, njobs));
+    if (r)
+        return r;
+    HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, rb + ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (job_results)
+        memcpy(job_results, c->out.h, (size_t)njobs * sizeof(*job_results));
+    memcpy(results, (char *)c->out.h + rb, ob);
     return X265_HIP_OK;
 }
 

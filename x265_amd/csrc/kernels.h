@@ -90,6 +90,12 @@ void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x26
 // the steps of predInterSearch in front of motionEstimate, then me_kernel on the jobs they produce (`mejobs`: n records of scratch)
 void launch_inter_search(const DeviceTables *tabs, const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h, x265_hip_me_job *mejobs,
                          x265_hip_inter_result *out, const MeRoute &r);
+// inter_decide.hip: predInterSearch behind its iterations (`bireq`: 2 npu requests for launch_bidir_cost, whose 2 npu
+// costs are `satd`)
+void launch_inter_decide_lists(const DeviceTables *tabs, const x265_hip_inter_job *jobs, const x265_hip_inter_result *res, const x265_hip_inter_pu *pus, int npu,
+                               int pic_w, int pic_h, x265_hip_inter_pu_result *out, x265_hip_bidir_req *bireq, hipStream_t st);
+void launch_inter_decide_bidir(const DeviceTables *tabs, const x265_hip_inter_job *jobs, const x265_hip_inter_pu *pus, int npu, const int32_t *satd,
+                               x265_hip_inter_pu_result *out, hipStream_t st);
 // `counters`: X265HIP_COST_COUNTER_BYTES of zeroed device memory owned by the context (two alternating sets of
 // batch counters); `parity` flips with every launch that shares them, and such launches are ordered on one stream
 #define X265HIP_COST_COUNTER_BYTES (2 * 64 * 64)

@@ -33,6 +33,7 @@ struct DeviceTables
     // the bytes of a plane's buffer relative to its origin, [first, end): what me_route_kernel's record guard checks a
     // job's reach against (api.hip's check_reach / check_inside on the device)
     long span_first[X265_HIP_MAX_PLANES], span_end[X265_HIP_MAX_PLANES];
+    const float *bitsizes; // BitCost::s_bitsizes, 32769 entries (bitcost.cpp:68-80): inter_decide.hip
 };
 
 __device__ __constant__ const int8_t k_taps[4][8] = {

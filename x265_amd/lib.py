@@ -37,7 +37,8 @@ EXPORTS = [
     "x265_hip_dist_batch", "x265_hip_dist_batch_device", "x265_hip_predict_batch", "x265_hip_predict_batch_device",
     "x265_hip_cost_batch_device_noalloc", "x265_hip_refine_batch", "x265_hip_refine_batch_device",
     "x265_hip_inter_search_batch", "x265_hip_inter_search_batch_device",
-    "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device", "x265_hip_ctx_check_records", "x265_hip_ctx_guard_status", "x265_hip_refine_sections_device",
+    "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device", "x265_hip_ctx_check_records", "x265_hip_ctx_guard_status", "x265_hip_inter_decide_batch", "x265_hip_inter_decide_batch_device",
+    "x265_hip_refine_sections_device",
     "x265_hip_host_alloc", "x265_hip_host_free", "x265_hip_plane_alloc", "x265_hip_plane_upload_async", "x265_hip_download_async",
     "x265_hip_copy_wait_compute", "x265_hip_compute_wait_copy", "x265_hip_copy_sync",
     "x265_hip_plane_extend_border_rows", "x265_hip_plane_weight_rows",
@@ -257,6 +258,21 @@ class Context:
         out = np.zeros(len(jobs), INTER_RESULT)
         _check(load().x265_hip_inter_search_batch(self._h, _p(jobs), C.c_int(len(jobs)), C.c_int(pic_width), C.c_int(pic_height), _p(out)))
         return out
+
+    def inter_decide_batch(self, jobs, pus, pic_width, pic_height):
+        """(iteration results, unit results): x265_hip_inter_search_batch for the jobs, then bits / xCheckBestMVP / the
+        bidirectional candidate / the choice for every prediction unit"""
+        from .abi import INTER_PU, INTER_PU_RESULT
+        jobs, pus = np.ascontiguousarray(jobs, INTER_JOB), np.ascontiguousarray(pus, INTER_PU)
+        res, out = np.zeros(len(jobs), INTER_RESULT), np.zeros(len(pus), INTER_PU_RESULT)
+        _check(load().x265_hip_inter_decide_batch(self._h, _p(jobs), C.c_int(len(jobs)), _p(pus), C.c_int(len(pus)), C.c_int(pic_width),
+                                                  C.c_int(pic_height), _p(res), _p(out)))
+        return res, out
+
+    def inter_decide_batch_device(self, d_jobs, njobs, d_pus, npu, pic_width, pic_height, d_job_results, d_results, any_bidir=True):
+        _check(load().x265_hip_inter_decide_batch_device(self._h, C.c_void_p(d_jobs), C.c_int(njobs), C.c_void_p(d_pus), C.c_int(npu),
+                                                         C.c_int(pic_width), C.c_int(pic_height), C.c_void_p(d_job_results),
+                                                         C.c_void_p(d_results), C.c_int(1 if any_bidir else 0)))
 
     def refine_sections_device(self, d_reqs, sections, d_costs9):
         """sections: [(count, pu_w, pu_h), ...] (at most abi.MAX_SECTIONS runs of one PU size each, in list order)"""
