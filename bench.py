@@ -403,7 +403,7 @@ def main():
             path = os.path.join(ROOT, "profiles", name)
             return json.load(open(path)) if os.path.exists(path) else {}
 
-        traffic = profile_json("r02_traffic.json")
+        traffic = profile_json("r03_traffic.json") or profile_json("r02_traffic.json")
         K = args.steps
         cands = sum(p.n_satd for p in acc_sp)
         ops = sum(p.satd_ops for p in acc_sp)
@@ -468,7 +468,7 @@ def main():
                 "frac": me_model["lane_ops"] / (ms * 1e-3) / VALU_PEAK,
                 "issue_ceiling": {"peak": VALU_ISSUE_4CYC / 1e12, "frac": me_model["lane_ops"] / (ms * 1e-3) / VALU_ISSUE_4CYC},
                 "model": {k: me_model[k] for k in ("sad_ops", "satd_ops", "interp_ops", "sad_candidates", "subpel_candidates", "calls")},
-                "traffic": (sum(traffic.get(k + "_4k", 0) for k in ("me_kernel", "me_big_kernel", "me_route_kernel")) or None)}
+                "traffic": (sum(traffic.get(k + "_4k", 0) for k in ("me_kernel", "me_big_kernel", "me_route_kernel", "me_team_kernel", "me_rest_kernel")) or None)}
         if seq_leg:
             line["sequence"] = seq_leg
         if hd:

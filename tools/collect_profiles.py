@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def ours(name):
@@ -18,7 +18,12 @@ def ours(name):
 
 
 def short(name):
-    return name.split("(")[0].replace("x265hip::", "")
+    """kernel name without namespace, return type, template arguments and parameters (the instantiations of
+    me_team_kernel are one kernel here)"""
+    n = name.split("(")[0].replace("x265hip::", "")
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0]
 
 
 def find(pattern):
@@ -99,9 +104,9 @@ bt = list(csv.DictReader(open(find("stats/**/*kernel_trace.csv"))))
 bt.sort(key=lambda r: int(r["Dispatch_Id"]))
 # a motionEstimate launch is three kernels (me_route_kernel and me_big_kernel on the side stream beside me_kernel): one leg,
 # timed by the union of their intervals
-ME_FAMILY = {"me_route_kernel": "me_kernel", "me_big_kernel": "me_kernel"}
-seqk = [(ME_FAMILY.get(short(r["Kernel_Name"]), short(r["Kernel_Name"])), int(r["Start_Timestamp"]) * 1e-6, int(r["End_Timestamp"]) * 1e-6)
-        for r in bt if ours(r["Kernel_Name"])]
+ME_FAMILY = {"me_route_kernel": "me_kernel", "me_big_kernel": "me_kernel", "me_team_kernel": "me_kernel", "me_rest_kernel": "me_kernel"}
+seqk = [(ME_FAMILY.get(short(r["Kernel_Name"]), short(r["Kernel_Name"])), int(r["Start_Timestamp"]) * 1e-6, int(r["End_Timestamp"]) * 1e-6,
+         short(r["Kernel_Name"])) for r in bt if ours(r["Kernel_Name"])]
 
 
 def busy_ms(intervals):
@@ -118,22 +123,32 @@ def busy_ms(intervals):
 
 line = json.loads(open(os.path.join(SRC, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
 K = line["steps"]
-order = ["refine_kernel", "cost_kernel", "me_kernel", "fullsearch2_kernel"]
+# leg order of bench.py's three_legs: rings of 8, single requests, motionEstimate, full search, the subme-2 rings (two
+# refine_kernel launches per step); the streamed sequence (motionEstimate launches) follows
+order = [("refine_kernel", "refine_kernel", 1), ("cost_kernel", "cost_kernel", 1), ("me_kernel", "me_kernel", 5), ("fullsearch2_kernel", "fullsearch2_kernel", 1),
+         ("refine_kernel_subme2", "refine_kernel", 2)]
 legs, pos = {}, 0
-for i, k in enumerate(order):
-    nxt = order[i + 1] if i + 1 < len(order) else "refine_kernel"
+for i, (leg_name, k, per) in enumerate(order):
+    nxt = order[i + 1][1] if i + 1 < len(order) else "me_kernel"
     start = pos
     while pos < len(seqk) and seqk[pos][0] == k:
         pos += 1
-    block = [(s_, e_) for _, s_, e_ in seqk[start:pos]]
-    per = 3 if k == "me_kernel" else 1
-    timed = block[-K * per:]
-    legs[k] = {"kernels_in_leg": len(block), "timed_kernels": len(timed), "kernels_per_step": per, "trace_ms_per_step": busy_ms(timed) / K}
-    assert seqk[pos][0] == nxt, (k, seqk[pos][0])
+    block = [(s_, e_) for _, s_, e_, _ in seqk[start:pos]]
+    if k == "me_kernel":
+        # a launch is me_route_kernel and the three or four kernels behind it (the class of 8x8 cells only for long
+        # lists): the timed steps start at the K-th last me_route_kernel
+        routes = [i_ for i_, q in enumerate(seqk[start:pos]) if q[3] == "me_route_kernel"]
+        timed = block[routes[-K]:]
+        per = len(timed) / K
+    else:
+        timed = block[-K * per:]
+    legs[leg_name] = {"kernels_in_leg": len(block), "timed_kernels": len(timed), "kernels_per_step": per, "trace_ms_per_step": busy_ms(timed) / K}
+    assert seqk[pos][0] == nxt, (leg_name, seqk[pos][0])
 legs["refine_kernel"]["bench_kernel_ms"] = line["roofline"]["kernel_ms"]
 legs["cost_kernel"]["bench_kernel_ms"] = line["satd_single_requests"]["roofline"]["kernel_ms"]
 legs["me_kernel"]["bench_kernel_ms"] = line["me_stage"]["kernel_ms_per_frame"]
 legs["fullsearch2_kernel"]["bench_kernel_ms"] = line["fullsearch"]["roofline"]["kernel_ms"]
+legs["refine_kernel_subme2"]["bench_kernel_ms"] = line["satd_rings_subme2"]["roofline"]["kernel_ms"]
 for k in legs:
     legs[k]["ratio_events_over_trace"] = legs[k]["bench_kernel_ms"] / legs[k]["trace_ms_per_step"]
 json.dump({"note": "4K legs of `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline`: kernel time per step from the "
