@@ -406,6 +406,9 @@ int x265_hip_lookahead_batch(x265_hip_ctx *ctx, const x265_hip_lookahead_job *jo
  * result whose cost is INT32_MAX means the launch gave up waiting (never observed; the host-array form reports it). */
 int x265_hip_lookahead_batch_device(x265_hip_ctx *ctx, const void *d_jobs, int njobs, int width_in_cu, int height_in_cu,
                                     void *d_results);
+/* The status word of the context's last lookahead launch: 0, or nonzero if a row of it gave up waiting for the row
+ * below it (its CUs then hold cost INT32_MAX).  Waits for the context's stream.  The host-array form checks it itself. */
+int x265_hip_lookahead_status(x265_hip_ctx *ctx, int *status);
 
 /* One ring of the sub-pel refinement of MotionEstimate::motionEstimate (motion.cpp:1047-1119) per request: the costs
  * subpelCompare(ref, centre + square1[i] * step, cmp) (motion.cpp:1126-1164; square1 at :71-73) for i = 1 .. 4 or 1 .. 8,

@@ -265,6 +265,12 @@ def test_lookahead_whole_frame_search(oracle, small_seq, costtabs):
     one_cu = ctx.lookahead_batch(lj[:1], 1, 1)
     assert np.array_equal(one_cu, oracle.lookahead_batch(low, {12: oracle.bitcost_table(12)}, lj[:1], 1, 1).view(one_cu.dtype))
     assert ctx.lookahead_batch(lj[:0], W, H).shape == (0, H, W)
+    # the device-array form, whose caller reads the launch's status word through x265_hip_lookahead_status
+    from x265_amd.hipmem import DeviceBuffer
+    d_lj, d_res = DeviceBuffer.from_array(lj), DeviceBuffer(8 * len(lj) * W * H)
+    ctx.lookahead_batch_device(d_lj.ptr, len(lj), W, H, d_res.ptr)
+    assert ctx.lookahead_status() == 0
+    assert np.array_equal(d_res.download(abi.ME_RESULT).reshape(len(lj), H, W), got)
     # refused: a picture larger than the planes, a reference without its three half-pel planes, no cost table
     with pytest.raises(lib.X265HipError, match="outside"):
         ctx.lookahead_batch(lj[:1], W + 30, H)

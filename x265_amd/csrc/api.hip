@@ -1480,6 +1480,19 @@ int x265_hip_lookahead_batch_device(x265_hip_ctx *c, const void *d_jobs, int njo
     return lookahead_launch(c, d_jobs, njobs, w_cu, h_cu, d_results);
 }
 
+int x265_hip_lookahead_status(x265_hip_ctx *c, int *status)
+{
+    if (!c || !status)
+        return fail(X265_HIP_EINVAL, "lookahead_status: null argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *status = 0;
+    if (c->look.d)
+        HIP_TRY(hipMemcpy(status, c->look.d, sizeof(int), hipMemcpyDeviceToHost));
+    return X265_HIP_OK;
+}
+
 int x265_hip_lookahead_batch(x265_hip_ctx *c, const x265_hip_lookahead_job *jobs, int njobs, int w_cu, int h_cu, x265_hip_me_result *results)
 {
     int r = lookahead_args(c, njobs, w_cu, h_cu, jobs, results, "lookahead_batch");
@@ -1871,18 +1884,29 @@ std::mutex g_prim_init_mu;
 // The table's entries are called concurrently by every pool thread of the encoder (one MotionEstimate per CTU row,
 // SURVEY.md 8(b) "Threading").  Each calling thread gets a context of its own (stream, staging buffers) the first time
 // it calls an entry, so calls from different threads neither wait for each other's mutex nor share a stream; the
-// contexts live until the process ends.
+// context of a thread is destroyed when the thread ends (an encoder's pool threads are created and joined per encoder
+// instance).
+struct PrimCtxHolder
+{
+    x265_hip_ctx *c = nullptr;
+    ~PrimCtxHolder()
+    {
+        if (c)
+            x265_hip_ctx_destroy(c);
+    }
+};
+
 x265_hip_ctx *prim_ctx()
 {
-    static thread_local x265_hip_ctx *t_ctx = nullptr;
-    if (t_ctx)
-        return t_ctx;
+    static thread_local PrimCtxHolder t_ctx;
+    if (t_ctx.c)
+        return t_ctx.c;
     if (!g_prim_ctx)
         return nullptr;
     x265_hip_ctx *c = nullptr;
     if (x265_hip_ctx_create(g_prim_device, &c) != X265_HIP_OK)
         return nullptr;
-    return t_ctx = c;
+    return t_ctx.c = c;
 }
 
 struct HostPlane
@@ -1894,10 +1918,11 @@ struct HostPlane
 std::vector<HostPlane> g_host_planes;
 std::shared_mutex g_host_planes_mu;
 
-// device address serving host address p (+- the bytes a primitive may touch), or null
+// device address serving host address p (+- the bytes a primitive may touch), or null.  The caller holds
+// g_host_planes_mu shared from here until its kernel has finished: x265_hip_unregister_host_plane takes the lock
+// exclusively before it frees a copy, so no primitive is between resolve and the end of its launch at that point.
 const uint8_t *resolve(const uint8_t *p, long before, long after)
 {
-    std::shared_lock<std::shared_mutex> g(g_host_planes_mu);
     for (const HostPlane &hp : g_host_planes)
         if (p - before >= hp.base && p + after <= hp.base + hp.bytes)
             return hp.dev + (p - hp.base);
@@ -1929,6 +1954,7 @@ int prim_cmp(int part, int metric, const uint8_t *fenc, intptr_t fstride, const 
         return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
     const int w = k_part_w[part], h = k_part_h[part];
     std::lock_guard<std::mutex> g(c->mu);
+    std::shared_lock<std::shared_mutex> planes(g_host_planes_mu);
     HIP_TRY(hipSetDevice(c->device));
     const size_t blk = (size_t)w * h;
     int r;
@@ -1999,6 +2025,7 @@ int prim_filter_wh(int w, int rows, int kind, const void *src, intptr_t sstride,
     const int pre_c = horiz ? 3 : 0, post_c = horiz ? 4 : 0, pre_r = vert ? 3 : 0, post_r = vert ? 4 : 0;
     const int sw = w + pre_c + post_c, sr = rows + pre_r + post_r;
     std::lock_guard<std::mutex> g(c->mu);
+    std::shared_lock<std::shared_mutex> planes(g_host_planes_mu);
     HIP_TRY(hipSetDevice(c->device));
     int r;
     const size_t sbytes = (size_t)sw * sr * ses, dbytes = (size_t)w * rows * des;
@@ -2428,6 +2455,8 @@ int x265_hip_unregister_host_plane(const uint8_t *host_base)
         return fail(X265_HIP_ENODEV, "x265_hip_setup_primitives has not succeeded");
     uint8_t *dev = nullptr;
     {
+        // exclusive: every primitive that resolved an address inside the copy has finished its kernel (they hold the lock
+        // shared until then), and none can find the copy afterwards
         std::unique_lock<std::shared_mutex> g(g_host_planes_mu);
         for (size_t i = 0; i < g_host_planes.size(); i++)
             if (g_host_planes[i].base == host_base)
@@ -2441,7 +2470,6 @@ int x265_hip_unregister_host_plane(const uint8_t *host_base)
         return fail(X265_HIP_EINVAL, "unregister_host_plane: not registered");
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipFree(dev));
     return X265_HIP_OK;
 }

@@ -37,7 +37,7 @@ EXPORTS = [
     "x265_hip_dist_batch", "x265_hip_dist_batch_device", "x265_hip_predict_batch", "x265_hip_predict_batch_device",
     "x265_hip_cost_batch_device_noalloc", "x265_hip_refine_batch", "x265_hip_refine_batch_device",
     "x265_hip_inter_search_batch", "x265_hip_inter_search_batch_device",
-    "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device", "x265_hip_ctx_check_records", "x265_hip_ctx_guard_status", "x265_hip_inter_decide_batch", "x265_hip_inter_decide_batch_device",
+    "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device", "x265_hip_lookahead_status", "x265_hip_ctx_check_records", "x265_hip_ctx_guard_status", "x265_hip_inter_decide_batch", "x265_hip_inter_decide_batch_device",
     "x265_hip_refine_sections_device",
     "x265_hip_host_alloc", "x265_hip_host_free", "x265_hip_plane_alloc", "x265_hip_plane_upload_async", "x265_hip_download_async",
     "x265_hip_copy_wait_compute", "x265_hip_compute_wait_copy", "x265_hip_copy_sync",
@@ -292,6 +292,12 @@ class Context:
         n, first = C.c_uint32(0), C.c_uint32(0)
         _check(load().x265_hip_ctx_guard_status(self._h, C.byref(n), C.byref(first)))
         return n.value, first.value
+
+    def lookahead_status(self):
+        """status word of the last lookahead launch (0: every row finished); waits for the stream"""
+        v = C.c_int(0)
+        _check(load().x265_hip_lookahead_status(self._h, C.byref(v)))
+        return v.value
 
     def lookahead_batch(self, jobs, width_in_cu, height_in_cu):
         """(n, height_in_cu, width_in_cu) results: the whole-frame searches of the lookahead"""
