@@ -127,7 +127,17 @@ K = line["steps"]
 # refine_kernel launches per step); the streamed sequence (motionEstimate launches) follows
 order = [("refine_kernel", "refine_kernel", 1), ("cost_kernel", "cost_kernel", 1), ("me_kernel", "me_kernel", 5), ("fullsearch2_kernel", "fullsearch2_kernel", 1),
          ("refine_kernel_subme2", "refine_kernel", 2)]
-legs, pos = {}, 0
+# maximal runs of one kernel family; the legs are the first five consecutive runs of the expected families that are long
+# enough to hold K timed steps (the set-up in front of them -- the integer searches and first rings that centre the
+# subme-2 rings -- is a few launches of the same kernels)
+runs, i0 = [], 0
+for i_ in range(1, len(seqk) + 1):
+    if i_ == len(seqk) or seqk[i_][0] != seqk[i0][0]:
+        runs.append((seqk[i0][0], i0, i_))
+        i0 = i_
+first_run = next(r_ for r_ in range(len(runs) - len(order) + 1)
+                 if all(runs[r_ + q][0] == order[q][1] and runs[r_ + q][2] - runs[r_ + q][1] >= K * min(order[q][2], 4) for q in range(len(order))))
+legs, pos = {}, runs[first_run][1]
 for i, (leg_name, k, per) in enumerate(order):
     nxt = order[i + 1][1] if i + 1 < len(order) else "me_kernel"
     start = pos
