@@ -175,3 +175,39 @@ def random_lowres_bidir_reqs(rng, n, lw, ll, dtype, fenc_plane=4, ref_planes=(0,
             r[kx] = int(np.clip(rng.integers(-70, 70), lox, hix)) if rng.integers(5) else 0
             r[ky] = int(np.clip(rng.integers(-70, 70), loy, hiy)) if rng.integers(5) else 0
     return reqs
+
+
+def random_inter_units(rng, n_units, W, H, job_dtype, pu_dtype, parts, qps=(20, 45)):
+    """prediction units for x265_hip_inter_decide_batch: (jobs, units); a unit's iterations are jobs of one block, one to
+    three references in list 0 and none to two in list 1"""
+    sel_rows = [(3, 3, 5), (1, 3, 5), (0, 0, 3), (5, 7, 7), (7, 5, 7), (6, 6, 6), (0, 2, 3), (5, 5, 7), (3, 0, 0)]
+    jobs, pus = [], []
+    for u in range(n_units):
+        w, h = parts[int(rng.integers(1, 25))]
+        cu = max(w, h) if max(w, h) in (8, 16, 32, 64) else 64
+        cx = int(rng.integers(0, (W - cu) // 8 + 1)) * 8
+        cy = int(rng.integers(0, (H - cu) // 8 + 1)) * 8
+        px, py = cx + int(rng.integers(0, (cu - w) // 4 + 1)) * 4, cy + int(rng.integers(0, (cu - h) // 4 + 1)) * 4
+        n0, n1 = int(rng.integers(1, 4)), int(rng.integers(0, 3))
+        p = np.zeros(1, pu_dtype)[0]
+        p["first_job"], p["num_ref"] = len(jobs), (n0, n1)
+        p["list_sel_bits"] = sel_rows[int(rng.integers(len(sel_rows)))]
+        p["no_bidir"] = int(n1 == 0 or rng.integers(4) == 0)
+        p["lambda_sad"] = int(rng.choice([64, 1024, 4771, 9000, 40000]))
+        pus.append(p)
+        method, subme, qp = int(rng.integers(0, 2)), int(rng.integers(0, 8)), int(rng.integers(qps[0], qps[1]))
+        for k in range(n0 + n1):
+            j = np.zeros(1, job_dtype)[0]
+            j["fenc_plane"], j["ref_plane"] = 1, int(rng.choice([0, 2]))
+            j["pred_plane"] = j["ref_plane"] if rng.integers(3) else int(rng.choice([0, 2]))
+            j["cu_x"], j["cu_y"], j["pu_x"], j["pu_y"], j["pu_w"], j["pu_h"] = cx, cy, px, py, w, h
+            j["method"], j["subme"], j["qp"] = method, subme, qp
+            j["merange"], j["ref_lag"] = int(rng.choice([4, 8, 16])), H if rng.integers(3) else 16
+            j["num_amvp"] = 1 + int(rng.integers(0, 4) > 0)
+            kind = int(rng.integers(4))
+            base = (0, 0) if kind == 0 else (int(rng.integers(-40, 40)), int(rng.integers(-40, 40))) if kind < 3 else \
+                (int(rng.integers(-2500, 2500)), int(rng.integers(-1500, 1500)))
+            j["amvp"][0], j["amvp"][1] = base
+            j["amvp"][2], j["amvp"][3] = (base[0] + int(rng.integers(-12, 13)), base[1] + int(rng.integers(-12, 13))) if rng.integers(4) else (0, 0)
+            jobs.append(j)
+    return np.array(jobs, job_dtype), np.array(pus, pu_dtype)

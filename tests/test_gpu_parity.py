@@ -858,39 +858,10 @@ def test_inter_decide_stage_vs_oracle(gpu_ctx, small_seq, costtabs, oracle):
     xCheckBestMVP moves the index), units with the bidirectional candidate switched off, every xGetBlkBits row, small and
     large lambdas; every byte of the result records"""
     from x265_amd import abi
+    from conftest import random_inter_units
     rng = np.random.default_rng(2360)
     W, H = 416, 240
-    sel_rows = [(3, 3, 5), (1, 3, 5), (0, 0, 3), (5, 7, 7), (7, 5, 7), (6, 6, 6), (0, 2, 3), (5, 5, 7), (3, 0, 0)]
-    jobs, pus = [], []
-    for u in range(900):
-        w, h = abi.PARTS[int(rng.integers(1, 25))]
-        cu = max(w, h) if max(w, h) in (8, 16, 32, 64) else 64
-        cx = int(rng.integers(0, (W - cu) // 8 + 1)) * 8
-        cy = int(rng.integers(0, (H - cu) // 8 + 1)) * 8
-        px, py = cx + int(rng.integers(0, (cu - w) // 4 + 1)) * 4, cy + int(rng.integers(0, (cu - h) // 4 + 1)) * 4
-        n0, n1 = int(rng.integers(1, 4)), int(rng.integers(0, 3))
-        p = np.zeros(1, abi.INTER_PU)[0]
-        p["first_job"], p["num_ref"] = len(jobs), (n0, n1)
-        p["list_sel_bits"] = sel_rows[int(rng.integers(len(sel_rows)))]
-        p["no_bidir"] = int(n1 == 0 or rng.integers(4) == 0)
-        p["lambda_sad"] = int(rng.choice([64, 1024, 4771, 9000, 40000]))
-        pus.append(p)
-        method, subme, qp = int(rng.integers(0, 2)), int(rng.integers(0, 8)), int(rng.integers(20, 45))
-        for k in range(n0 + n1):
-            j = np.zeros(1, abi.INTER_JOB)[0]
-            j["fenc_plane"], j["ref_plane"] = 1, int(rng.choice([0, 2]))
-            j["pred_plane"] = j["ref_plane"] if rng.integers(3) else int(rng.choice([0, 2]))
-            j["cu_x"], j["cu_y"], j["pu_x"], j["pu_y"], j["pu_w"], j["pu_h"] = cx, cy, px, py, w, h
-            j["method"], j["subme"], j["qp"] = method, subme, qp
-            j["merange"], j["ref_lag"] = int(rng.choice([4, 8, 16])), H if rng.integers(3) else 16
-            j["num_amvp"] = 1 + int(rng.integers(0, 4) > 0)
-            kind = int(rng.integers(4))
-            base = (0, 0) if kind == 0 else (int(rng.integers(-40, 40)), int(rng.integers(-40, 40))) if kind < 3 else \
-                (int(rng.integers(-2500, 2500)), int(rng.integers(-1500, 1500)))
-            j["amvp"][0], j["amvp"][1] = base
-            j["amvp"][2], j["amvp"][3] = (base[0] + int(rng.integers(-12, 13)), base[1] + int(rng.integers(-12, 13))) if rng.integers(4) else (0, 0)
-            jobs.append(j)
-    jobs, pus = np.array(jobs, abi.INTER_JOB), np.array(pus, abi.INTER_PU)
+    jobs, pus = random_inter_units(rng, 900, W, H, abi.INTER_JOB, abi.INTER_PU, abi.PARTS)
     res, got = gpu_ctx.inter_decide_batch(jobs, pus, W, H)
     planes = [p.as_tuple() for p in small_seq]
     wres = oracle.inter_search_batch(planes, costtabs, jobs, W, H)

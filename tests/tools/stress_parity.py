@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
-from conftest import random_bidir_reqs, random_cost_reqs, random_lowres_jobs, random_me_jobs, random_pred_reqs
+from conftest import random_bidir_reqs, random_cost_reqs, random_inter_units, random_lowres_jobs, random_me_jobs, random_pred_reqs
 from oracle import pyoracle
 from x265_amd import abi, lib, synth
 
@@ -198,6 +198,29 @@ for j in ij:
 got = ctx.inter_search_batch(ij, W, H)
 want = O.inter_search_batch(pl, tabs, ij, W, H)
 report("inter_search_batch", got, want.view(got.dtype), ij)
+
+# the rest of predInterSearch per prediction unit (round 3): bits, xCheckBestMVP, the bidirectional candidate, the choice
+uj, up = random_inter_units(rng, max(1, N // 4), W, H, abi.INTER_JOB, abi.INTER_PU, abi.PARTS, qps=(0, 52))
+res, got = ctx.inter_decide_batch(uj, up, W, H)
+wres = O.inter_search_batch(pl, tabs, uj, W, H)
+want = O.inter_decide_batch(pl, tabs, uj, wres, up, W, H)
+report("inter_decide_batch (iterations)", res, wres.view(res.dtype), uj)
+report("inter_decide_batch (units)", np.array([g.tobytes() for g in got]), np.array([w_.tobytes() for w_ in want]), up)
+
+# one long diamond / hexagon list (round 3: lists of 262,144 calls and more search their 32-wide blocks in teams of 8x8
+# cells as well), through the device-array entry point with the record guard on
+from x265_amd.hipmem import DeviceBuffer
+jobs = np.concatenate([random_me_jobs(rng, max(300000, N) // 16, m, sm, W, H, abi.ME_JOB, synth.search_range, abi.PARTS, meranges=(4, 8, 16, 57))
+                       for m in (0, 1) for sm in range(8)])
+jobs["qp"] = rng.integers(0, 52, len(jobs))
+t0 = time.time()
+want = O.me_batch(pl, tabs, jobs, nthreads=16)
+d_j, d_o = DeviceBuffer.from_array(jobs), DeviceBuffer(8 * len(jobs))
+ctx.check_records(2)
+ctx.me_batch_device(d_j.ptr, len(jobs), d_o.ptr)
+assert ctx.guard_status() == (0, 0xFFFFFFFF)
+ctx.check_records(0)
+report(f"me_batch_device, one list, guard on ({time.time() - t0:.1f} s)", d_o.download(abi.ME_RESULT), want, jobs)
 
 # whole-frame lookahead searches: every ordered pair of the three natural pictures' lowres planes, a few settings
 lj = []
