@@ -87,7 +87,7 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     cleared 2048 counters at its start once cost it 13 spilled registers and 5 % of every small call); me_big_kernel,
     at four waves per SIMD, spills nothing; the cost
     kernels spill nothing (cost_kernel at six waves spilled 14 dwords, 100 MB of scratch writes per 1080p launch,
-    and was 8 % slower than at five waves without spills); refine_kernel at four waves (113 registers) spills nothing;
+    and was 8 % slower than at five waves without spills); refine_kernel at four waves (127 registers) spills nothing;
     me_rest_kernel (the same search inside a list loop, six waves per SIMD) may spill a dozen dwords; me_team_kernel
     (three waves per SIMD for the tile classes) may spill eight in the set-up of a chunk of calls (fifteen scratch
     instructions in all, none inside the rounds of a search)."""
