@@ -557,8 +557,8 @@ typedef struct x265_hip_inter_pu_result
 
 /* Steps 1-3 for every job (x265_hip_inter_search_batch), then steps 4-6 for every unit, chained on the context's stream
  * without a host round trip.  job_results (njobs records) may be NULL in the host-array form.  The `_device` form keeps
- * internal arrays in device memory, grown on demand; any_bidir = 0 promises that every unit has no_bidir set (a P
- * picture) and skips the bidirectional kernels. */
+ * internal arrays in device memory, grown on demand; any_bidir = 0 treats every unit as if no_bidir were set (a P picture)
+ * and skips the bidirectional kernels. */
 int x265_hip_inter_decide_batch(x265_hip_ctx *ctx, const x265_hip_inter_job *jobs, int njobs, const x265_hip_inter_pu *pus, int npu,
                                 int pic_width, int pic_height, x265_hip_inter_result *job_results, x265_hip_inter_pu_result *results);
 int x265_hip_inter_decide_batch_device(x265_hip_ctx *ctx, const void *d_jobs, int njobs, const void *d_pus, int npu, int pic_width,

@@ -1370,7 +1370,7 @@ static int inter_decide_launch(x265_hip_ctx *c, const x265_hip_inter_job *d_jobs
     x265_hip_bidir_req *bireq = (x265_hip_bidir_req *)c->bidir.d;
     int32_t *satd = (int32_t *)((char *)c->bidir.d + req_bytes);
     LAUNCH(launch_inter_search(c->dev_tabs, d_jobs, njobs, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d, d_job_results, me_route(c, njobs > 0, any_routed)));
-    LAUNCH(launch_inter_decide_lists(c->dev_tabs, d_jobs, d_job_results, d_pus, npu, pic_w, pic_h, d_results, bireq, c->stream));
+    LAUNCH(launch_inter_decide_lists(c->dev_tabs, d_jobs, d_job_results, d_pus, npu, pic_w, pic_h, d_results, bireq, any_bidir, c->stream));
     if (any_bidir)
     {
         LAUNCH(launch_bidir_cost(c->dev_tabs, bireq, 2 * npu, satd, c->batch_counter, c->batch_parity ^= 1, c->stream));

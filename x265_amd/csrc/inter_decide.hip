@@ -62,7 +62,7 @@ __device__ __forceinline__ int s16d(int v) { return (int)(int16_t)v; }
 // the kernel may run
 __global__ __launch_bounds__(64) void inter_decide_lists_kernel(const DeviceTables *tabs, const x265_hip_inter_job *jobs, const x265_hip_inter_result *res,
                                                                const x265_hip_inter_pu *pus, int npu, int pic_w, int pic_h, x265_hip_inter_pu_result *out,
-                                                               x265_hip_bidir_req *bireq)
+                                                               x265_hip_bidir_req *bireq, int any_bidir)
 {
     const int u = blockIdx.x * 64 + threadIdx.x;
     if (u >= npu)
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64) void inter_decide_lists_kernel(const DeviceTabl
     b0.fenc_plane = q0.fenc_plane;
     b0.pu_x = q0.pu_x, b0.pu_y = q0.pu_y, b0.pu_w = q0.pu_w, b0.pu_h = q0.pu_h;
     b0.metric = X265_HIP_SATD;
-    const bool bidir = !p.no_bidir && o.list[0].cost != 0xffffffffu && o.list[1].cost != 0xffffffffu;
+    const bool bidir = any_bidir && !p.no_bidir && o.list[0].cost != 0xffffffffu && o.list[1].cost != 0xffffffffu;
     if (!bidir)
     {
         b0.ref0_plane = b0.ref1_plane = q0.ref_plane;
@@ -193,10 +193,11 @@ __global__ __launch_bounds__(64) void inter_decide_bidir_kernel(const DeviceTabl
 }
 
 void launch_inter_decide_lists(const DeviceTables *tabs, const x265_hip_inter_job *jobs, const x265_hip_inter_result *res, const x265_hip_inter_pu *pus, int npu,
-                               int pic_w, int pic_h, x265_hip_inter_pu_result *out, x265_hip_bidir_req *bireq, hipStream_t st)
+                               int pic_w, int pic_h, x265_hip_inter_pu_result *out, x265_hip_bidir_req *bireq, bool any_bidir, hipStream_t st)
 {
     if (npu > 0)
-        hipLaunchKernelGGL(inter_decide_lists_kernel, dim3((npu + 63) / 64), dim3(64), 0, st, tabs, jobs, res, pus, npu, pic_w, pic_h, out, bireq);
+        hipLaunchKernelGGL(inter_decide_lists_kernel, dim3((npu + 63) / 64), dim3(64), 0, st, tabs, jobs, res, pus, npu, pic_w, pic_h, out, bireq,
+                           any_bidir ? 1 : 0);
 }
 
 void launch_inter_decide_bidir(const DeviceTables *tabs, const x265_hip_inter_job *jobs, const x265_hip_inter_pu *pus, int npu, const int32_t *satd,

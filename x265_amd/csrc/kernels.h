@@ -93,7 +93,7 @@ void launch_inter_search(const DeviceTables *tabs, const x265_hip_inter_job *job
 // inter_decide.hip: predInterSearch behind its iterations (`bireq`: 2 npu requests for launch_bidir_cost, whose 2 npu
 // costs are `satd`)
 void launch_inter_decide_lists(const DeviceTables *tabs, const x265_hip_inter_job *jobs, const x265_hip_inter_result *res, const x265_hip_inter_pu *pus, int npu,
-                               int pic_w, int pic_h, x265_hip_inter_pu_result *out, x265_hip_bidir_req *bireq, hipStream_t st);
+                               int pic_w, int pic_h, x265_hip_inter_pu_result *out, x265_hip_bidir_req *bireq, bool any_bidir, hipStream_t st);
 void launch_inter_decide_bidir(const DeviceTables *tabs, const x265_hip_inter_job *jobs, const x265_hip_inter_pu *pus, int npu, const int32_t *satd,
                                x265_hip_inter_pu_result *out, hipStream_t st);
 // `counters`: X265HIP_COST_COUNTER_BYTES of zeroed device memory owned by the context (two alternating sets of
