@@ -71,3 +71,109 @@ def test_runner_plan_is_the_same_sharded_and_unsharded():
         parts = [p for r in range(world) for p in plan(r, world)]
         assert sorted(parts) == sorted(whole)
     assert all(seg[0] <= min(refs) and max(refs) < cur < seg[1] for seg, cur, refs in whole)
+
+
+class _FakeStreams:
+    """x265_hip_ctx as the streamed runner sees it: two in-order streams and two fences.  Records every operation with
+    the operations it is ordered behind (its stream's previous one and, through the fences, the other stream's)."""
+
+    def __init__(self):
+        self.ops = []                  # (kind, payload, set of op indices that happen before it)
+        self.last = {"copy": None, "compute": None}
+        self.gate = {"copy": set(), "compute": set()}  # what the stream's next operations wait for (a fence)
+
+    def _add(self, stream, kind, payload):
+        before = set(self.gate[stream])
+        if self.last[stream] is not None:
+            before.add(self.last[stream])
+        closure = set(before)
+        for b in before:
+            closure |= self.ops[b][2]
+        self.ops.append((kind, payload, closure))
+        self.last[stream] = len(self.ops) - 1
+
+    def plane_alloc(self, *a):
+        pass
+
+    def plane_release(self, *a):
+        pass
+
+    def plane_upload_async(self, plane, buf):
+        self._add("copy", "upload", plane)
+
+    def download_async(self, dev, host, nbytes):
+        self._add("copy", "download", (dev, host.tag))
+
+    def me_batch_device(self, d_jobs, n, d_out):
+        self._add("compute", "launch", (d_jobs, d_out))
+
+    def compute_wait_copy(self):
+        if self.last["copy"] is not None:
+            self.gate["compute"].add(self.last["copy"])
+
+    def copy_wait_compute(self):
+        if self.last["compute"] is not None:
+            self.gate["copy"].add(self.last["compute"])
+
+    def sync(self):
+        pass
+
+    def copy_sync(self):
+        pass
+
+
+def test_streamed_runner_orders_transfers_and_searches(monkeypatch):
+    """runner.SegmentStreamer against a model of the two streams: every search is ordered behind the last upload of every
+    plane it reads and is not concurrent with any upload into them, every result download lies between the search that
+    wrote the slot and the next search that writes it, and every P picture's results are downloaded exactly once"""
+    from x265_amd import hipmem, lib, runner, shard
+
+    class Buf:
+        n = 0
+
+        def __init__(self, nbytes):
+            Buf.n += 1
+            self.ptr = self.tag = 1000 + Buf.n
+            self.array = bytearray(0)
+
+        def free(self):
+            pass
+
+    monkeypatch.setattr(hipmem, "DeviceBuffer", Buf)
+    monkeypatch.setattr(lib, "PinnedBuffer", Buf)
+    for frames, gop, rank, world in ((70, 8, 0, 1), (70, 8, 1, 2), (33, 16, 0, 3), (5, 1, 0, 1), (9, 4, 1, 2)):
+        ctx = _FakeStreams()
+        st = runner.SegmentStreamer(ctx, (4096, 64, 0), gop, 100)
+        segments = shard.segments_for_rank(frames, gop, rank, world)
+        reads = {}
+
+        def jobs(cur, seg, s, reads=reads):
+            refs = dict(shard.reference_pairs(seg, 3))[cur]
+            token = len(reads) + 1
+            reads[token] = (cur, {s * gop + p - seg[0] for p in [cur] + refs})
+            return token, 10
+
+        st.run(segments, lambda pic: Buf(1), jobs)
+        ops = ctx.ops
+        launches = [i for i, o in enumerate(ops) if o[0] == "launch"]
+        assert [reads[ops[i][1][0]][0] for i in launches] == [cur for seg in segments for cur, _ in shard.reference_pairs(seg, 3)]
+        uploads = [i for i, o in enumerate(ops) if o[0] == "upload"]
+        assert len(uploads) == sum(b - a for a, b in segments)
+        for i in launches:
+            planes = reads[ops[i][1][0]][1]
+            for p in planes:
+                ups = [u for u in uploads if ops[u][1] == p]
+                assert any(u in ops[i][2] for u in ups), "a search reads a plane nothing was uploaded into before it"
+                for u in ups:
+                    assert u in ops[i][2] or i in ops[u][2], "an upload into a plane runs beside a search that reads it"
+        downloads = [i for i, o in enumerate(ops) if o[0] == "download"]
+        assert len(downloads) == len(launches)
+        for k, i in enumerate(launches):
+            slot = ops[i][1][1]
+            mine = [d for d in downloads if ops[d][1][0] == slot and i in ops[d][2]]
+            assert mine, "a search's results are never downloaded behind it"
+            d = min(mine)
+            later = [j for j in launches[k + 1:] if ops[j][1][1] == slot]
+            if later:
+                assert d in ops[later[0]][2], "a slot is written again before its results have left"
+                assert not any(ops[x][1][0] == slot and i in ops[x][2] and later[0] not in ops[x][2] and x != d for x in downloads)
