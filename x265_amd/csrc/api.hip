@@ -1293,12 +1293,12 @@ int x265_hip_inter_search_batch_device(x265_hip_ctx *c, const void *d_jobs, int 
             return vr;
     }
     int r;
-    if (c->mejobs.cap < (size_t)n * sizeof(x265_hip_me_job))
+    if (c->mejobs.cap < X265HIP_INTER_SCRATCH_BYTES(n))
         HIP_TRY(hipStreamSynchronize(c->stream)); // an earlier launch may still read the buffer that is about to be replaced
-    if ((r = push_tabs(c)) || (r = ensure(c, c->mejobs, (size_t)n * sizeof(x265_hip_me_job), false)) || (r = ensure_route(c, n)))
+    if ((r = push_tabs(c)) || (r = ensure(c, c->mejobs, X265HIP_INTER_SCRATCH_BYTES(n), false)) || (r = ensure_route(c, n)))
         return r;
     LAUNCH(launch_inter_search(c->dev_tabs, (const x265_hip_inter_job *)d_jobs, n, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d,
-                               (x265_hip_inter_result *)d_results, me_route(c, n > 0)));
+                               (x265_hip_inter_result *)d_results, me_route(c, n > 0), c->batch_counter, c->batch_parity ^= 1));
     return X265_HIP_OK;
 }
 
@@ -1318,11 +1318,11 @@ int x265_hip_inter_search_batch(x265_hip_ctx *c, const x265_hip_inter_job *jobs,
     int r;
     const size_t ob = (size_t)n * sizeof(*results);
     if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*jobs))) || (r = ensure(c, c->out, ob)) ||
-        (r = ensure(c, c->mejobs, (size_t)n * sizeof(x265_hip_me_job), false)) || (r = ensure_route(c, n)))
+        (r = ensure(c, c->mejobs, X265HIP_INTER_SCRATCH_BYTES(n), false)) || (r = ensure_route(c, n)))
         return r;
     HIP_TRY(hipMemcpyAsync(c->in.d, jobs, (size_t)n * sizeof(*jobs), hipMemcpyHostToDevice, c->stream));
     LAUNCH(launch_inter_search(c->dev_tabs, (const x265_hip_inter_job *)c->in.d, n, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d,
-                               (x265_hip_inter_result *)c->out.d, me_route(c, n > 0, any_routed_job(jobs, n))));
+                               (x265_hip_inter_result *)c->out.d, me_route(c, n > 0, any_routed_job(jobs, n)), c->batch_counter, c->batch_parity ^= 1));
     HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(results, c->out.h, ob);
@@ -1362,14 +1362,15 @@ static int inter_decide_launch(x265_hip_ctx *c, const x265_hip_inter_job *d_jobs
 {
     int r;
     const size_t req_bytes = ((size_t)2 * npu * sizeof(x265_hip_bidir_req) + 255) & ~(size_t)255;
-    if (c->mejobs.cap < (size_t)njobs * sizeof(x265_hip_me_job) || c->bidir.cap < req_bytes + (size_t)2 * npu * sizeof(int32_t))
+    if (c->mejobs.cap < X265HIP_INTER_SCRATCH_BYTES(njobs) || c->bidir.cap < req_bytes + (size_t)2 * npu * sizeof(int32_t))
         HIP_TRY(hipStreamSynchronize(c->stream)); // an earlier launch may still read a buffer that is about to be replaced
-    if ((r = ensure(c, c->mejobs, (size_t)njobs * sizeof(x265_hip_me_job), false)) || (r = ensure_route(c, njobs)) ||
+    if ((r = ensure(c, c->mejobs, X265HIP_INTER_SCRATCH_BYTES(njobs), false)) || (r = ensure_route(c, njobs)) ||
         (r = ensure(c, c->bidir, req_bytes + (size_t)2 * npu * sizeof(int32_t), false)))
         return r;
     x265_hip_bidir_req *bireq = (x265_hip_bidir_req *)c->bidir.d;
     int32_t *satd = (int32_t *)((char *)c->bidir.d + req_bytes);
-    LAUNCH(launch_inter_search(c->dev_tabs, d_jobs, njobs, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d, d_job_results, me_route(c, njobs > 0, any_routed)));
+    LAUNCH(launch_inter_search(c->dev_tabs, d_jobs, njobs, pic_w, pic_h, (x265_hip_me_job *)c->mejobs.d, d_job_results, me_route(c, njobs > 0, any_routed),
+                               c->batch_counter, c->batch_parity ^= 1));
     LAUNCH(launch_inter_decide_lists(c->dev_tabs, d_jobs, d_job_results, d_pus, npu, pic_w, pic_h, d_results, bireq, any_bidir, c->stream));
     if (any_bidir)
     {

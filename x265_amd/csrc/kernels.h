@@ -87,9 +87,12 @@ size_t me_route_counter_words();
 // (host-array callers check) and runs me_kernel with one workgroup per job
 bool me_job_is_routed(int w, int h, int method);
 void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x265_hip_me_result *out, const MeRoute &r);
-// the steps of predInterSearch in front of motionEstimate, then me_kernel on the jobs they produce (`mejobs`: n records of scratch)
+// the steps of predInterSearch in front of motionEstimate, then the searches of the jobs they produce.  `mejobs`: scratch of
+// X265HIP_INTER_SCRATCH_BYTES(n) bytes (n motionEstimate jobs, the candidates' 2 n cost requests, their 2 n costs);
+// `counters` / `parity`: the batch counters of the cost kernels
+#define X265HIP_INTER_SCRATCH_BYTES(n) ((size_t)(n) * (sizeof(x265_hip_me_job) + 2 * sizeof(x265_hip_cost_req) + 2 * sizeof(int32_t)))
 void launch_inter_search(const DeviceTables *tabs, const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h, x265_hip_me_job *mejobs,
-                         x265_hip_inter_result *out, const MeRoute &r);
+                         x265_hip_inter_result *out, const MeRoute &r, uint32_t *counters, int parity);
 // inter_decide.hip: predInterSearch behind its iterations (`bireq`: 2 npu requests for launch_bidir_cost, whose 2 npu
 // costs are `satd`)
 void launch_inter_decide_lists(const DeviceTables *tabs, const x265_hip_inter_job *jobs, const x265_hip_inter_result *res, const x265_hip_inter_pu *pus, int npu,

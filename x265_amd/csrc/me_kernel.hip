@@ -1685,74 +1685,84 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_BIG_WAVES
     me_list_loop<true>(lds, tabs, jobs, route, parity, cap, out, out_stride);
 }
 
-// The steps of predInterSearch in front of motionEstimate (reference Lib/TLibEncoder/TEncSearch.cpp:2315-2339), one wave
-// per job: the AMVP candidates are clipped and the block predicted at each of them from the reconstructed reference is
-// compared with the source block by SAD (q_eval: the pixels of xPredInterLumaBlk are subpelCompare's); the first
-// minimum is the predictor; xSetSearchRange gives the window.  The wave writes the motionEstimate job for me_kernel,
-// which runs behind it on the same stream, and the front of the result record.
-__global__ __launch_bounds__(64) void inter_prepare_kernel(const DeviceTables *tabs, const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h,
+// The steps of predInterSearch in front of motionEstimate (reference Lib/TLibEncoder/TEncSearch.cpp:2315-2339): the AMVP
+// candidates are clipped and the block predicted at each of them from the reconstructed reference is compared with the
+// source block by SAD (the pixels of xPredInterLumaBlk are subpelCompare's); the first minimum is the predictor;
+// xSetSearchRange gives the window.  Three launches: a thread per job writes the two candidates as cost requests,
+// cost_kernel measures them (its items are dealt over the lanes whatever the blocks' sizes; round 2 spent a whole wave on
+// the two candidates of a job: 0.55 ms for a 4K picture's 516 k iterations, more than half of what the searches take),
+// a thread per job picks, computes the window and writes the motionEstimate job and the front of the result record.
+__global__ __launch_bounds__(256) void inter_requests_kernel(const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h, x265_hip_cost_req *reqs)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const x265_hip_inter_job &j = jobs[i];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+    {
+        const int kk = k < (int)j.num_amvp ? k : 0; // a job with one candidate measures it twice (the second cost is not used)
+        int qx = j.amvp[2 * kk], qy = j.amvp[2 * kk + 1];
+        clip_mv(qx, qy, j.cu_x, j.cu_y, pic_w, pic_h);
+        x265_hip_cost_req r;
+        r.fenc_plane = j.fenc_plane;
+        r.ref_plane = j.pred_plane;
+        r.pu_x = j.pu_x;
+        r.pu_y = j.pu_y;
+        r.pu_w = j.pu_w;
+        r.pu_h = j.pu_h;
+        r.metric = X265_HIP_SAD;
+        r.pad = 0;
+        r.qmv_x = (int16_t)qx;
+        r.qmv_y = (int16_t)qy;
+        reqs[2 * i + k] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void inter_finish_kernel(const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h, const int32_t *sad,
                                                            x265_hip_me_job *mejobs, x265_hip_inter_result *out)
 {
-    __shared__ WaveLds lds;
-    if ((int)blockIdx.x >= n)
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= n)
         return;
-    const int id = xcd_chunked(blockIdx.x, n, ME_XCD_CHUNK);
     const x265_hip_inter_job &j = jobs[id];
-    Wave wv;
-    wave_init(wv, &lds, j.pu_w, j.pu_h);
-    const PlaneDesc fp = tabs->planes[j.fenc_plane], pp = tabs->planes[j.pred_plane];
-    wv.stride = pp.stride;
-    wv.ref = pp.origin + (long)j.pu_y * pp.stride + j.pu_x;
-    load_fenc(wv, fp.origin + (long)j.pu_y * fp.stride + j.pu_x, fp.stride);
-    const int na = min((int)j.num_amvp, 2);
-    wv.nq = 0;
-    for (int k = 0; k < na; k++)
-    {
-        int qx = j.amvp[2 * k], qy = j.amvp[2 * k + 1];
-        clip_mv(qx, qy, j.cu_x, j.cu_y, pic_w, pic_h);
-        q_push(wv, qx, qy, MV_NONE);
-    }
-    q_eval(wv, X265_HIP_SAD);
-    const int c0 = q_cost(wv, 0), c1 = na > 1 ? q_cost(wv, 1) : 0x7fffffff;
+    const int c0 = sad[2 * id], c1 = j.num_amvp > 1 ? sad[2 * id + 1] : 0x7fffffff;
     const int pick = c1 < c0 ? 1 : 0; // "if (bestCost > cost)": the first minimum
     const int mvpx = j.amvp[2 * pick], mvpy = j.amvp[2 * pick + 1];
     int lox, loy, hix, hiy;
     search_window(mvpx, mvpy, j.merange, j.ref_lag, j.cu_x, j.cu_y, pic_w, pic_h, lox, loy, hix, hiy);
-    if (wv.lane == 0)
-    {
-        x265_hip_me_job m;
-        m.fenc_plane = j.fenc_plane;
-        m.ref_plane = j.ref_plane;
-        m.pu_x = j.pu_x;
-        m.pu_y = j.pu_y;
-        m.pu_w = j.pu_w;
-        m.pu_h = j.pu_h;
-        m.method = j.method;
-        m.subme = j.subme;
-        m.mvmin_x = (int16_t)lox;
-        m.mvmin_y = (int16_t)loy;
-        m.mvmax_x = (int16_t)hix;
-        m.mvmax_y = (int16_t)hiy;
-        m.qmvp_x = (int16_t)mvpx;
-        m.qmvp_y = (int16_t)mvpy;
-        m.merange = j.merange;
-        m.qp = j.qp;
-        m.num_mvc = j.num_mvc;
-        for (int k = 0; k < 2 * X265_HIP_MAX_MVC; k++)
-            m.mvc[k] = j.mvc[k];
-        mejobs[id] = m;
-        x265_hip_inter_result &r = out[id];
-        r.amvp_sad[0] = c0;
-        r.amvp_sad[1] = c1;
-        r.mvmin_x = (int16_t)lox;
-        r.mvmin_y = (int16_t)loy;
-        r.mvmax_x = (int16_t)hix;
-        r.mvmax_y = (int16_t)hiy;
-        r.mvp_x = (int16_t)mvpx;
-        r.mvp_y = (int16_t)mvpy;
-        r.mvp_idx = (uint8_t)pick;
-        r.pad[0] = r.pad[1] = r.pad[2] = 0;
-    }
+    x265_hip_me_job m;
+    m.fenc_plane = j.fenc_plane;
+    m.ref_plane = j.ref_plane;
+    m.pu_x = j.pu_x;
+    m.pu_y = j.pu_y;
+    m.pu_w = j.pu_w;
+    m.pu_h = j.pu_h;
+    m.method = j.method;
+    m.subme = j.subme;
+    m.mvmin_x = (int16_t)lox;
+    m.mvmin_y = (int16_t)loy;
+    m.mvmax_x = (int16_t)hix;
+    m.mvmax_y = (int16_t)hiy;
+    m.qmvp_x = (int16_t)mvpx;
+    m.qmvp_y = (int16_t)mvpy;
+    m.merange = j.merange;
+    m.qp = j.qp;
+    m.num_mvc = j.num_mvc;
+    for (int k = 0; k < 2 * X265_HIP_MAX_MVC; k++)
+        m.mvc[k] = j.mvc[k];
+    mejobs[id] = m;
+    x265_hip_inter_result &r = out[id];
+    r.amvp_sad[0] = c0;
+    r.amvp_sad[1] = c1;
+    r.mvmin_x = (int16_t)lox;
+    r.mvmin_y = (int16_t)loy;
+    r.mvmax_x = (int16_t)hix;
+    r.mvmax_y = (int16_t)hiy;
+    r.mvp_x = (int16_t)mvpx;
+    r.mvp_y = (int16_t)mvpy;
+    r.mvp_idx = (uint8_t)pick;
+    r.pad[0] = r.pad[1] = r.pad[2] = 0;
 }
 
 // ---- whole-frame lookahead search (x265_hip_lookahead_batch) ----------------------------------------------------------
@@ -2520,13 +2530,20 @@ void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x26
     me_launch_both(tabs, jobs, n, out, (int)sizeof(x265_hip_me_result), r);
 }
 
+void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, uint32_t *counters, int parity, hipStream_t st);
+
 void launch_inter_search(const DeviceTables *tabs, const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h, x265_hip_me_job *mejobs,
-                         x265_hip_inter_result *out, const MeRoute &r)
+                         x265_hip_inter_result *out, const MeRoute &r, uint32_t *counters, int parity)
 {
     hipStream_t st = r.stream;
     if (n <= 0)
         return;
-    hipLaunchKernelGGL(inter_prepare_kernel, dim3(n), dim3(64), 0, st, tabs, jobs, n, pic_w, pic_h, mejobs, out);
+    // behind the n motionEstimate jobs `mejobs` has room for the candidates' 2 n cost requests and their 2 n costs
+    x265_hip_cost_req *reqs = (x265_hip_cost_req *)(mejobs + n);
+    int32_t *sad = (int32_t *)(reqs + 2 * (size_t)n);
+    hipLaunchKernelGGL(inter_requests_kernel, dim3((n + 255) / 256), dim3(256), 0, st, jobs, n, pic_w, pic_h, reqs);
+    launch_cost(tabs, reqs, 2 * n, sad, counters, parity, st);
+    hipLaunchKernelGGL(inter_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, jobs, n, pic_w, pic_h, sad, mejobs, out);
     // (cost, mv) head the result record
     static_assert(offsetof(x265_hip_inter_result, cost) == 0 && offsetof(x265_hip_inter_result, mvx) == 4, "x265_hip_me_result heads the record");
     me_launch_both(tabs, mejobs, n, (x265_hip_me_result *)out, (int)sizeof(x265_hip_inter_result), r);
