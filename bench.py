@@ -232,6 +232,25 @@ def main():
     (dt_sp, ev_sp, acc_sp), (dt_c1, ev_c1, acc_c1), (dt_me, ev_me, acc_me), (dt_fs, ev_fs, acc_fs), (dt_s2, ev_s2, acc_s2) = \
         three_legs(pics, args.steps, args.warmup)
 
+    # ---- predInterSearch as a stage: the ME-stage list of a picture with all its references as
+    # prediction units -- AMVP pick, window, search per iteration, then bits / xCheckBestMVP / choice per unit (P picture:
+    # every reference in list 0)
+    p3 = max(pics, key=lambda p: len(p.refs))
+    ij, pu = synth.inter_units(p3.me_host, len(p3.refs), UH)
+    d_ij, d_pu = torch.from_numpy(ij.view(np.uint8).copy()).to(dev), torch.from_numpy(pu.view(np.uint8).copy()).to(dev)
+    o_ij = torch.empty(len(ij) * abi.INTER_RESULT.itemsize, dtype=torch.uint8, device=dev)
+    o_pu = torch.empty(len(pu) * abi.INTER_PU_RESULT.itemsize, dtype=torch.uint8, device=dev)
+
+    def run_inter(s):
+        ctx.inter_decide_batch_device(d_ij.data_ptr(), len(ij), d_pu.data_ptr(), len(pu), UW, UH, o_ij.data_ptr(), o_pu.data_ptr(), any_bidir=False)
+    dt_in, ev_in, _ = leg(run_inter, max(4, args.steps // 4), 2)
+    inter_leg = {"workload": f"x265_hip_inter_decide_batch: the {len(pu)} square PUs of one 4K P picture as prediction units with {len(p3.refs)} "
+                             "iterations each (two AMVP candidates; HEX, subme 2, merange 57): AMVP pick, search window and motionEstimate per "
+                             "iteration, bits / xCheckBestMVP / best reference / choice per unit",
+                 "units_per_s": len(pu) * max(4, args.steps // 4) * world / dt_in, "iterations_per_unit": len(p3.refs),
+                 "kernel_ms_per_frame": ev_in / max(4, args.steps // 4)}
+    del d_ij, d_pu, o_ij, o_pu
+
     # ---- configs[4] as stated: a --frames picture 4K sequence in closed GOPs of --seq-gop, cut over the ranks (strong
     # scaling), streamed: the pictures of the next segment arrive from pinned host memory and the results of finished
     # pictures leave while the current segment is searched (runner.SegmentStreamer); the bracket holds the transfers.
@@ -469,6 +488,7 @@ def main():
                 "issue_ceiling": {"peak": VALU_ISSUE_4CYC / 1e12, "frac": me_model["lane_ops"] / (ms * 1e-3) / VALU_ISSUE_4CYC},
                 "model": {k: me_model[k] for k in ("sad_ops", "satd_ops", "interp_ops", "sad_candidates", "subpel_candidates", "calls")},
                 "traffic": (sum(traffic.get(k + "_4k", 0) for k in ("me_kernel", "me_big_kernel", "me_route_kernel", "me_team_kernel", "me_rest_kernel")) or None)}
+        line["inter_stage"] = inter_leg
         if seq_leg:
             line["sequence"] = seq_leg
         if hd:

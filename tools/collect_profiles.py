@@ -124,7 +124,7 @@ def busy_ms(intervals):
 line = json.loads(open(os.path.join(SRC, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
 K = line["steps"]
 # leg order of bench.py's three_legs: rings of 8, single requests, motionEstimate, full search, the subme-2 rings (two
-# refine_kernel launches per step); the streamed sequence (motionEstimate launches) follows
+# refine_kernel launches per step); the predInterSearch stage and the streamed sequence follow
 order = [("refine_kernel", "refine_kernel", 1), ("cost_kernel", "cost_kernel", 1), ("me_kernel", "me_kernel", 5), ("fullsearch2_kernel", "fullsearch2_kernel", 1),
          ("refine_kernel_subme2", "refine_kernel", 2)]
 # maximal runs of one kernel family; the legs are the first five consecutive runs of the expected families that are long
@@ -139,7 +139,7 @@ first_run = next(r_ for r_ in range(len(runs) - len(order) + 1)
                  if all(runs[r_ + q][0] == order[q][1] and runs[r_ + q][2] - runs[r_ + q][1] >= K * min(order[q][2], 4) for q in range(len(order))))
 legs, pos = {}, runs[first_run][1]
 for i, (leg_name, k, per) in enumerate(order):
-    nxt = order[i + 1][1] if i + 1 < len(order) else "me_kernel"
+    nxt = order[i + 1][1] if i + 1 < len(order) else "inter_requests_kernel"  # (the predInterSearch stage's leg follows)
     start = pos
     while pos < len(seqk) and seqk[pos][0] == k:
         pos += 1

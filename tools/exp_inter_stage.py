@@ -35,25 +35,10 @@ def timed(fn, reps=10):
 
 
 def units(lists):
-    """lists: [[reference planes of list 0], [of list 1]]; jobs unit-major"""
+    """lists: [[reference planes of list 0], [of list 1]]"""
     refs = lists[0] + lists[1]
     mj = synth.me_jobs(W, H, 3, refs, [seq.global_motion(3, r) for r in refs], method=abi.HEX, subme=2, merange=57)
-    n = len(mj) // len(refs)
-    mj = mj.reshape(len(refs), n).T.reshape(-1)  # unit-major: a unit's iterations are consecutive
-    ij = np.zeros(len(mj), abi.INTER_JOB)
-    for k in ("fenc_plane", "ref_plane", "pu_x", "pu_y", "pu_w", "pu_h", "method", "subme", "merange", "qp", "num_mvc", "mvc"):
-        ij[k] = mj[k]
-    ij["pred_plane"] = mj["ref_plane"]
-    ij["cu_x"], ij["cu_y"] = mj["pu_x"], mj["pu_y"]  # 2Nx2N units: the CU is the block
-    ij["amvp"][:, 0], ij["amvp"][:, 1] = mj["qmvp_x"], mj["qmvp_y"]
-    ij["amvp"][:, 2], ij["amvp"][:, 3] = mj["qmvp_x"] + 3, mj["qmvp_y"] - 2
-    ij["num_amvp"], ij["ref_lag"] = 2, H
-    pu = np.zeros(n, abi.INTER_PU)
-    pu["first_job"] = np.arange(n) * len(refs)
-    pu["num_ref"] = (len(lists[0]), len(lists[1]))
-    pu["list_sel_bits"] = (3, 3, 5) if lists[1] else (1, 3, 5)
-    pu["no_bidir"] = 0 if lists[1] else 1
-    pu["lambda_sad"] = 4771
+    ij, pu = synth.inter_units(mj, len(refs), H, n_list1=len(lists[1]))
     return mj, ij, pu
 
 

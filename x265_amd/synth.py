@@ -203,6 +203,31 @@ def me_jobs(w, h, fenc_plane, ref_planes, motions, method=1, subme=2, merange=57
     return jobs
 
 
+def inter_units(me, n_refs, height, n_list1=0, lambda_sad=4771):
+    """The iterations of me_jobs() (reference-major: n_refs runs of one job per PU) as prediction units for
+    x265_hip_inter_decide_batch: (x265_hip_inter_job records unit-major, x265_hip_inter_pu records).  The last n_list1
+    references form list 1 (a B picture; the bidirectional candidate is tried), the others list 0.  Every unit is a 2Nx2N
+    CU; its AMVP candidates are the job's predictor and a neighbour of it."""
+    from .abi import INTER_JOB, INTER_PU
+    n = len(me) // n_refs
+    mj = me.reshape(n_refs, n).T.reshape(-1)
+    ij = np.zeros(len(mj), INTER_JOB)
+    for k in ("fenc_plane", "ref_plane", "pu_x", "pu_y", "pu_w", "pu_h", "method", "subme", "merange", "qp", "num_mvc", "mvc"):
+        ij[k] = mj[k]
+    ij["pred_plane"] = mj["ref_plane"]
+    ij["cu_x"], ij["cu_y"] = mj["pu_x"], mj["pu_y"]
+    ij["amvp"][:, 0], ij["amvp"][:, 1] = mj["qmvp_x"], mj["qmvp_y"]
+    ij["amvp"][:, 2], ij["amvp"][:, 3] = mj["qmvp_x"] + 3, mj["qmvp_y"] - 2
+    ij["num_amvp"], ij["ref_lag"] = 2, height
+    pu = np.zeros(n, INTER_PU)
+    pu["first_job"] = np.arange(n) * n_refs
+    pu["num_ref"] = (n_refs - n_list1, n_list1)
+    pu["list_sel_bits"] = (3, 3, 5) if n_list1 else (1, 3, 5)  # xGetBlkBits of a 2Nx2N unit (TEncSearch.cpp:2509-2514)
+    pu["no_bidir"] = 0 if n_list1 else 1
+    pu["lambda_sad"] = lambda_sad
+    return ij, pu
+
+
 def subpel_requests(w, h, cur, refs, motions):
     """Cost requests of the sub-pel stage of one picture: every square PU x every reference x 16 candidates
     (half-pel ring, then quarter-pel ring, around the integer vector `motions[i]`), SATD after interpolation.
