@@ -993,6 +993,82 @@ def test_record_guard_on_the_device_skips_bad_jobs(gpu_ctx, oracle, small_seq, c
         gpu_ctx.check_records(False)
 
 
+def test_record_guard_of_the_request_lists(gpu_ctx, small_seq):
+    """x265_hip_ctx_check_records mode 2 for the request lists (cost, dist, refine, refine in runs, bidir): a thread per
+    record checks it on the device and the kernel runs a list in which the records that fail are replaced by harmless
+    ones; their results come back as -1 (all nine of a ring), every other result is the usual one, nothing is copied back
+    and the refusals are counted"""
+    from conftest import random_bidir_reqs, random_cost_reqs
+    from x265_amd import abi, lib
+    from x265_amd.hipmem import DeviceBuffer
+    W, H = small_seq[0].w, small_seq[0].h
+    rng = np.random.default_rng(4242)
+
+    def spoil(recs, fields):
+        bad = recs.copy()
+        idx = rng.choice(len(recs), len(fields), replace=False)
+        for i, (k, v) in zip(idx, fields):
+            bad[k][i] = v
+        return bad, np.sort(idx)
+
+    def run(call, recs, per):
+        d, o = DeviceBuffer.from_array(recs), DeviceBuffer(4 * per * len(recs))
+        call(d.ptr, len(recs), o.ptr)
+        n_ref, first = gpu_ctx.guard_status()
+        got = o.download(np.int32).reshape(len(recs), per)
+        d.free()
+        o.free()
+        return got, n_ref, first
+
+    cost = random_cost_reqs(rng, 3000, W, H, abi.COST_REQ, abi.PARTS)
+    ring = np.zeros(2000, abi.REFINE_REQ)
+    for k in ("fenc_plane", "ref_plane", "pu_x", "pu_y", "pu_w", "pu_h", "qmv_x", "qmv_y"):
+        ring[k] = cost[k][:2000]
+    ring["metric"] = cost["metric"][:2000] & 1
+    ring["pattern"] = rng.choice([abi.RING_HPEL, abi.RING_QPEL, abi.RING_HPEL | abi.RING_8, abi.RING_QPEL | abi.RING_8 | abi.RING_CENTRE], 2000)
+    bidir = random_bidir_reqs(rng, 2000, W, H, abi.BIDIR_REQ, abi.PARTS)
+    far = [("ref_plane", 300), ("fenc_plane", -1), ("pu_w", 20), ("metric", 9), ("qmv_y", 4 * (H + 400)), ("qmv_y", -4 * (H + 400)), ("pu_y", H + 300)]
+    gpu_ctx.check_records(2)
+    try:
+        for name, recs, fields, call, per, host in (
+                ("cost", cost, far, gpu_ctx.cost_batch_device, 1, gpu_ctx.cost_batch),
+                ("dist", cost, far, gpu_ctx.dist_batch_device, 1, gpu_ctx.dist_batch),
+                ("refine", ring, far[:3] + [("pattern", 0x40), ("qmv_y", 4 * (H + 400)), ("pu_y", H + 300)], gpu_ctx.refine_batch_device, 9,
+                 gpu_ctx.refine_batch),
+                ("bidir", bidir, [("ref1_plane", 300), ("ref0_plane", 511), ("pu_h", 20), ("metric", 0xC1), ("qmv1_y", 4 * (H + 400)),
+                                  ("qmv0_y", -4 * (H + 400))], gpu_ctx.bidir_cost_batch_device, 1, gpu_ctx.bidir_cost_batch)):
+            if name == "dist":
+                recs = recs.copy()
+                recs["metric"] = rng.integers(0, 4, len(recs))
+            want = np.asarray(host(recs)).reshape(len(recs), per)
+            bad, idx = spoil(recs, fields)
+            for i in idx:  # the host-array form refuses each of them
+                with pytest.raises(lib.X265HipError):
+                    host(bad[i:i + 1])
+            got, n_ref, first = run(call, bad, per)
+            ok = np.ones(len(recs), bool)
+            ok[idx] = False
+            assert np.array_equal(got[ok], want[ok]), name
+            assert (got[~ok] == -1).all() and (n_ref, first) == (len(idx), int(idx[0])), (name, n_ref, first, idx)
+            got, n_ref, first = run(call, recs, per)  # a good list
+            assert np.array_equal(got, want) and n_ref == 0, name
+        # rings in runs of one size (x265_hip_refine_sections_device)
+        runs = [ring[ring["pu_w"] == w_] for w_ in (16, 8)]
+        runs = [r_[r_["pu_h"] == r_["pu_w"]] for r_ in runs]
+        recs = np.concatenate(runs)
+        want = gpu_ctx.refine_batch(recs)
+        bad, idx = spoil(recs, [("ref_plane", 300), ("qmv_y", 4 * (H + 400))])
+        d, o = DeviceBuffer.from_array(bad), DeviceBuffer(36 * len(bad))
+        gpu_ctx.refine_sections_device(d.ptr, [(len(r_), int(r_["pu_w"][0]), int(r_["pu_h"][0])) for r_ in runs], o.ptr)
+        assert gpu_ctx.guard_status() == (2, int(idx[0]))
+        got = o.download(np.int32).reshape(len(bad), 9)
+        ok = np.ones(len(bad), bool)
+        ok[idx] = False
+        assert np.array_equal(got[ok], want[ok]) and (got[~ok] == -1).all()
+    finally:
+        gpu_ctx.check_records(False)
+
+
 @pytest.mark.parametrize("one_stream", [False, True])
 def test_large_block_jobs_and_their_routing(oracle, small_seq, costtabs, one_stream, monkeypatch):
     """blocks of 128 tiles and more are listed on the device and searched by me_big_kernel beside me_kernel (on a second

@@ -92,6 +92,7 @@ struct x265_hip_ctx
     Buf in, out;       // staging of the host-array batch calls
     Buf mejobs;        // motionEstimate jobs made on the device by x265_hip_inter_search_batch (device side only is used)
     Buf route;         // motionEstimate launches: the list of large-block jobs me_route_kernel makes for me_big_kernel (device side only)
+    Buf guard;         // record guard of the request lists: the list the kernel runs and a byte per record (device side only)
     Buf bidir;         // x265_hip_inter_decide_batch: two bidir requests and two costs per unit (device side only)
     float *bitsizes = nullptr; // BitCost::s_bitsizes (device)
     Buf look;          // x265_hip_lookahead_batch: row counters (64 bytes per search) behind one status word
@@ -368,7 +369,7 @@ void x265_hip_ctx_destroy(x265_hip_ctx *c)
     for (int i = 0; i < X265_HIP_MAX_QP; i++)
         if (c->owned_tab[i])
             (void)hipFree(c->owned_tab[i]);
-    Buf *bufs[8] = { &c->in, &c->out, &c->prim_a, &c->prim_b, &c->mejobs, &c->look, &c->route, &c->bidir };
+    Buf *bufs[9] = { &c->in, &c->out, &c->prim_a, &c->prim_b, &c->mejobs, &c->look, &c->route, &c->bidir, &c->guard };
     for (Buf *b : bufs)
     {
         if (b->d)
@@ -453,7 +454,7 @@ int x265_hip_ctx_sync(x265_hip_ctx *c)
         if (r)
             return r;
         if (w[0])
-            return fail(X265_HIP_ERANGE, "the record guard refused %u motionEstimate job(s), the first at index %u of its list: their results are (cost -1, mv 0)",
+            return fail(X265_HIP_ERANGE, "the record guard refused %u record(s), the first at index %u of its list: their results are -1",
                         w[0], w[1]);
     }
     return X265_HIP_OK;
@@ -1233,6 +1234,37 @@ static int checked_records(x265_hip_ctx *c, const void *d_recs, int n, F validat
 }
 } // extern "C++"
 
+// Record guard of a request list (mode 2): a plane the replaced records can point at -- one that holds a 64x64 block at
+// its origin with the filters' margins -- or -1 (then the call falls back to the copy-back of mode 1)
+static int guard_safe_plane(const x265_hip_ctx *c)
+{
+    for (int id = 0; id < X265_HIP_MAX_PLANES; id++)
+    {
+        const PlaneDesc &p = c->host_tabs.planes[id];
+        if (!p.origin || p.stride < 64)
+            continue;
+        const long first = c->plane_origin[id] + (-1 - 3) * (long)p.stride + (-1 - 3 - 3);
+        const long last = c->plane_origin[id] + (67 + 4 - 1) * (long)p.stride + (65 + 4 + 12);
+        if (first >= 0 && last <= (long)c->plane_bytes[id] + 16)
+            return id;
+    }
+    return -1;
+}
+
+// room for the guarded copy of n records of `rec` bytes and their flags; *sane / *bad point into it
+static int guard_room(x265_hip_ctx *c, int n, size_t rec, void **sane, uint8_t **bad)
+{
+    const size_t list = ((size_t)n * rec + 255) & ~(size_t)255, need = list + (size_t)n;
+    if (c->guard.cap < need)
+        HIP_TRY(hipStreamSynchronize(c->stream)); // an earlier launch may still read the buffer that is about to be replaced
+    int r = ensure(c, c->guard, need, false);
+    if (r)
+        return r;
+    *sane = c->guard.d;
+    *bad = (uint8_t *)c->guard.d + list;
+    return 0;
+}
+
 // ---- batched entry points -----------------------------------------------------------------------
 
 int x265_hip_me_batch_device(x265_hip_ctx *c, const void *d_jobs, int n, void *d_results)
@@ -1528,15 +1560,28 @@ int x265_hip_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void 
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    const int safe = c->check_records == 2 ? guard_safe_plane(c) : -1;
     {
-        int vr = checked_records<x265_hip_cost_req>(c, d_reqs, n, [&](const x265_hip_cost_req *h) { return validate_cost(c, h, n); });
+        int vr = checked_records<x265_hip_cost_req>(c, d_reqs, n, [&](const x265_hip_cost_req *h) { return validate_cost(c, h, n); }, safe >= 0);
         if (vr)
             return vr;
     }
     int r = push_tabs(c);
     if (r)
         return r;
+    uint8_t *bad = nullptr;
+    if (safe >= 0)
+    {
+        void *sane;
+        if ((r = guard_room(c, n, sizeof(x265_hip_cost_req), &sane, &bad)))
+            return r;
+        LAUNCH(launch_guard_cost(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, X265_HIP_SATD, safe, (x265_hip_cost_req *)sane, bad, c->guard_words,
+                                 c->stream));
+        d_reqs = sane;
+    }
     LAUNCH(launch_cost(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    if (bad)
+        LAUNCH(launch_guard_fix(bad, n, 1, (int32_t *)d_costs, c->stream));
     return X265_HIP_OK;
 }
 
@@ -1605,15 +1650,27 @@ int x265_hip_refine_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, voi
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    const int safe = c->check_records == 2 ? guard_safe_plane(c) : -1;
     {
-        int vr = checked_records<x265_hip_refine_req>(c, d_reqs, n, [&](const x265_hip_refine_req *h) { return validate_refine(c, h, n); });
+        int vr = checked_records<x265_hip_refine_req>(c, d_reqs, n, [&](const x265_hip_refine_req *h) { return validate_refine(c, h, n); }, safe >= 0);
         if (vr)
             return vr;
     }
     int r = push_tabs(c);
     if (r)
         return r;
+    uint8_t *bad = nullptr;
+    if (safe >= 0)
+    {
+        void *sane;
+        if ((r = guard_room(c, n, sizeof(x265_hip_refine_req), &sane, &bad)))
+            return r;
+        LAUNCH(launch_guard_refine(c->dev_tabs, (const x265_hip_refine_req *)d_reqs, n, safe, (x265_hip_refine_req *)sane, bad, c->guard_words, c->stream));
+        d_reqs = sane;
+    }
     LAUNCH(launch_refine(c->dev_tabs, (const x265_hip_refine_req *)d_reqs, n, (int32_t *)d_costs9, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    if (bad)
+        LAUNCH(launch_guard_fix(bad, n, X265_HIP_RING_COSTS, (int32_t *)d_costs9, c->stream));
     return X265_HIP_OK;
 }
 
@@ -1635,6 +1692,7 @@ int x265_hip_refine_sections_device(x265_hip_ctx *c, const void *d_reqs, const x
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    const int safe = c->check_records == 2 ? guard_safe_plane(c) : -1;
     {
         int vr = checked_records<x265_hip_refine_req>(c, d_reqs, (int)n, [&](const x265_hip_refine_req *h) {
             int r = validate_refine(c, h, (int)n);
@@ -1644,15 +1702,29 @@ int x265_hip_refine_sections_device(x265_hip_ctx *c, const void *d_reqs, const x
                     if (h[i].pu_w != sections[s].pu_w || h[i].pu_h != sections[s].pu_h)
                         r = fail(X265_HIP_EINVAL, "refine_req[%ld]: %dx%d in a section of %dx%d", i, h[i].pu_w, h[i].pu_h, sections[s].pu_w, sections[s].pu_h);
             return r;
-        });
+        }, safe >= 0);
         if (vr)
             return vr;
     }
     int r = push_tabs(c);
     if (r)
         return r;
+    uint8_t *bad = nullptr;
+    if (safe >= 0)
+    {
+        // (a record of another size than its run's only costs time: the runs size the batches, the kernel takes a
+        // request's strips from the request)
+        void *sane;
+        if ((r = guard_room(c, (int)n, sizeof(x265_hip_refine_req), &sane, &bad)))
+            return r;
+        LAUNCH(launch_guard_refine(c->dev_tabs, (const x265_hip_refine_req *)d_reqs, (int)n, safe, (x265_hip_refine_req *)sane, bad, c->guard_words,
+                                   c->stream));
+        d_reqs = sane;
+    }
     LAUNCH(launch_refine_sections(c->dev_tabs, (const x265_hip_refine_req *)d_reqs, sections, nsections, (int32_t *)d_costs9, c->batch_counter,
                                   c->batch_parity ^= 1, c->stream));
+    if (bad)
+        LAUNCH(launch_guard_fix(bad, (int)n, X265_HIP_RING_COSTS, (int32_t *)d_costs9, c->stream));
     return X265_HIP_OK;
 }
 
@@ -1703,15 +1775,28 @@ int x265_hip_dist_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void 
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    const int safe = c->check_records == 2 ? guard_safe_plane(c) : -1;
     {
-        int vr = checked_records<x265_hip_cost_req>(c, d_reqs, n, [&](const x265_hip_cost_req *h) { return validate_dist(c, h, n); });
+        int vr = checked_records<x265_hip_cost_req>(c, d_reqs, n, [&](const x265_hip_cost_req *h) { return validate_dist(c, h, n); }, safe >= 0);
         if (vr)
             return vr;
     }
     int r = push_tabs(c);
     if (r)
         return r;
+    uint8_t *bad = nullptr;
+    if (safe >= 0)
+    {
+        void *sane;
+        if ((r = guard_room(c, n, sizeof(x265_hip_cost_req), &sane, &bad)))
+            return r;
+        LAUNCH(launch_guard_cost(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, X265_HIP_SSE, safe, (x265_hip_cost_req *)sane, bad, c->guard_words,
+                                 c->stream));
+        d_reqs = sane;
+    }
     LAUNCH(launch_dist(c->dev_tabs, (const x265_hip_cost_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    if (bad)
+        LAUNCH(launch_guard_fix(bad, n, 1, (int32_t *)d_costs, c->stream));
     return X265_HIP_OK;
 }
 
@@ -1790,15 +1875,27 @@ int x265_hip_bidir_cost_batch_device(x265_hip_ctx *c, const void *d_reqs, int n,
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    const int safe = c->check_records == 2 ? guard_safe_plane(c) : -1;
     {
-        int vr = checked_records<x265_hip_bidir_req>(c, d_reqs, n, [&](const x265_hip_bidir_req *h) { return validate_bidir(c, h, n); });
+        int vr = checked_records<x265_hip_bidir_req>(c, d_reqs, n, [&](const x265_hip_bidir_req *h) { return validate_bidir(c, h, n); }, safe >= 0);
         if (vr)
             return vr;
     }
     int r = push_tabs(c);
     if (r)
         return r;
+    uint8_t *bad = nullptr;
+    if (safe >= 0)
+    {
+        void *sane;
+        if ((r = guard_room(c, n, sizeof(x265_hip_bidir_req), &sane, &bad)))
+            return r;
+        LAUNCH(launch_guard_bidir(c->dev_tabs, (const x265_hip_bidir_req *)d_reqs, n, safe, (x265_hip_bidir_req *)sane, bad, c->guard_words, c->stream));
+        d_reqs = sane;
+    }
     LAUNCH(launch_bidir_cost(c->dev_tabs, (const x265_hip_bidir_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    if (bad)
+        LAUNCH(launch_guard_fix(bad, n, 1, (int32_t *)d_costs, c->stream));
     return X265_HIP_OK;
 }
 

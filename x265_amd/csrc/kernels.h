@@ -93,6 +93,16 @@ void launch_me(const DeviceTables *tabs, const x265_hip_me_job *jobs, int n, x26
 #define X265HIP_INTER_SCRATCH_BYTES(n) ((size_t)(n) * (sizeof(x265_hip_me_job) + 2 * sizeof(x265_hip_cost_req) + 2 * sizeof(int32_t)))
 void launch_inter_search(const DeviceTables *tabs, const x265_hip_inter_job *jobs, int n, int pic_w, int pic_h, x265_hip_me_job *mejobs,
                          x265_hip_inter_result *out, const MeRoute &r, uint32_t *counters, int parity);
+// guard.hip: record guards of the request lists (check_records mode 2).  `sane`: the list the kernel will run, `bad`: a
+// byte per record, `words`: the context's two guard words; launch_guard_fix sets the results of the replaced records
+// (`per` words each) to -1 behind the kernel
+void launch_guard_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int max_metric, int safe_plane, x265_hip_cost_req *sane, uint8_t *bad,
+                       uint32_t *words, hipStream_t st);
+void launch_guard_refine(const DeviceTables *tabs, const x265_hip_refine_req *reqs, int n, int safe_plane, x265_hip_refine_req *sane, uint8_t *bad,
+                         uint32_t *words, hipStream_t st);
+void launch_guard_bidir(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int safe_plane, x265_hip_bidir_req *sane, uint8_t *bad,
+                        uint32_t *words, hipStream_t st);
+void launch_guard_fix(const uint8_t *bad, int n, int per, int32_t *out, hipStream_t st);
 // inter_decide.hip: predInterSearch behind its iterations (`bireq`: 2 npu requests for launch_bidir_cost, whose 2 npu
 // costs are `satd`)
 void launch_inter_decide_lists(const DeviceTables *tabs, const x265_hip_inter_job *jobs, const x265_hip_inter_result *res, const x265_hip_inter_pu *pus, int npu,

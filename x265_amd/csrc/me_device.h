@@ -797,4 +797,50 @@ __device__ __forceinline__ int mvcost_q(const uint16_t *tab, int mvpx, int mvpy,
     return (uint16_t)(tab_at(tab, mvpx, qx) + tab_at(tab, mvpy, qy));
 }
 
+// ---- record guards (x265_hip_ctx_check_records mode 2): api.hip's checks against the plane directory in device memory
+__device__ __forceinline__ bool guard_partition(int w, int h) // x265_hip_partition_from_sizes >= 0 (primitives.h:38-46)
+{
+    const int a = w > h ? w : h, b = w > h ? h : w; // the table is symmetric in (w, h)
+    switch (a)
+    {
+    case 4: return b == 4;
+    case 8: return b == 8 || b == 4;
+    case 16: return b == 16 || b == 8 || b == 12 || b == 4;
+    case 32: return b == 32 || b == 16 || b == 24 || b == 8;
+    case 64: return b == 64 || b == 32 || b == 48 || b == 16;
+    default: return false;
+    }
+}
+
+
+// check_block: both planes uploaded, the size a luma partition
+__device__ __forceinline__ bool guard_block(const DeviceTables *tabs, int fp, int rp, int w, int h)
+{
+    return (unsigned)fp < X265_HIP_MAX_PLANES && (unsigned)rp < X265_HIP_MAX_PLANES && tabs->planes[fp].origin && tabs->planes[rp].origin &&
+           guard_partition(w, h);
+}
+
+// check_inside: the block itself, exactly
+__device__ __forceinline__ bool guard_inside(const DeviceTables *tabs, int id, int x, int y, int w, int h)
+{
+    const long stride = tabs->planes[id].stride;
+    const long first = (long)y * stride + x, last = (long)(y + h - 1) * stride + x + w;
+    return first >= tabs->span_first[id] && last <= tabs->span_end[id] && x + w <= stride;
+}
+
+// check_reach: picture samples [x0, x1) x [y0, y1) with the filters' 3 before / 4 behind and the loads' overhang
+__device__ __forceinline__ bool guard_reach(const DeviceTables *tabs, int id, long x0, long y0, long x1, long y1)
+{
+    const long stride = tabs->planes[id].stride;
+    const long first = (y0 - 3) * stride + (x0 - 3 - 3), last = (y1 + 4 - 1) * stride + (x1 + 4 + 12);
+    return first >= tabs->span_first[id] && last <= tabs->span_end[id] + 16;
+}
+
+// check_displaced: the block displaced by a quarter-pel vector
+__device__ __forceinline__ bool guard_displaced(const DeviceTables *tabs, int id, int x, int y, int w, int h, int qx, int qy)
+{
+    const long bx = x + (qx >> 2), by = y + (qy >> 2);
+    return guard_reach(tabs, id, bx, by, bx + w, by + h);
+}
+
 } // namespace x265hip

@@ -1576,20 +1576,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_REST_WAVE
 // cost table, and that every sample the search may touch, filter margins included, lies inside the planes' buffers).  A
 // record that fails is put on no list (no kernel ever reads it), gets the result (cost -1, mv 0) and is counted in
 // guard[0]; guard[1] keeps the lowest index of one.  Nothing is copied back to the host.
-__device__ __forceinline__ bool guard_partition(int w, int h) // x265_hip_partition_from_sizes >= 0 (primitives.h:38-46)
-{
-    const int a = w > h ? w : h, b = w > h ? h : w; // the table is symmetric in (w, h)
-    switch (a)
-    {
-    case 4: return b == 4;
-    case 8: return b == 8 || b == 4;
-    case 16: return b == 16 || b == 8 || b == 12 || b == 4;
-    case 32: return b == 32 || b == 16 || b == 24 || b == 8;
-    case 64: return b == 64 || b == 32 || b == 48 || b == 16;
-    default: return false;
-    }
-}
-
 __device__ bool guard_me_job(const DeviceTables *tabs, const x265_hip_me_job &j)
 {
     const int method = j.method & ~X265_HIP_LOWRES_REF;
