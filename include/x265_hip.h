@@ -327,12 +327,19 @@ int x265_hip_bidir_cost_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int 
  * luma (source/Lib/TLibCommon/TComPrediction.cpp:330-387).  Uni-directional: xPredInterLumaBlk to pixels
  * (:400-433: luma_copy_pp / luma_hpp / luma_vpp / luma_hps + luma_vsp).  Bi-directional: both lists to 14-bit
  * intermediates (:436-473: luma_p2s / luma_hps / luma_vps / luma_hps + luma_vss; ipfilter.cpp:38-54, 117-160,
- * 204-239, 285-317) and luma_addAvg (common/pixel.cpp:819-839).  Weighted bi-prediction (xWeightedPredictionBi)
- * is not covered.  Weighted uni-directional prediction is: with ref1_plane == X265_HIP_PRED_WEIGHTED the block
+ * 204-239, 285-317) and luma_addAvg (common/pixel.cpp:819-839).  Weighted uni-directional prediction: with
+ * ref1_plane == X265_HIP_PRED_WEIGHTED the block
  * goes the way motionCompensation takes whenever the PPS enables weighted prediction (TComPrediction.cpp:265-279):
  * the 14-bit intermediate of ref0, then TComWeightPrediction::addWeightUni (TComWeightPrediction.cpp:433-458,
  * 678-697) = weight_sp (common/pixel.cpp:492-508) with w0 = qmv1_x (wpScalingParam::inputWeight), offset = qmv1_y
  * (inputOffset), shift = log2_denom + 6 and round = 1 << (shift - 1).
+ * Weighted bi-prediction (the PPS's weighted_bipred_flag, --weightb; xPredInterBi's getWPBiPred branch,
+ * TComPrediction.cpp:347-350): with weighted_bi != 0 and ref1_plane >= 0 the two 14-bit intermediates are combined by
+ * TComWeightPrediction::xWeightedPredictionBi / addWeightBi (TComWeightPrediction.cpp:203-255, 609-618) with the
+ * parameters getWpScaling derives for two lists (:534-547): weights wp_w0, wp_w1 (inputWeight of each list's
+ * reference), offset = wp_o0 + wp_o1 (inputOffset), shift = log2_denom + 7 (the denominator of list 0's entry) and
+ * round = 1 << (shift - 1): clip((w0 (P0 + 8192) + w1 (P1 + 8192) + round + (offset << (shift - 1))) >> shift).
+ * (A block of such a slice that uses one list goes through addWeightUni, the X265_HIP_PRED_WEIGHTED form.)
  * pu_w x pu_h samples are written at (pu_x, pu_y) of dst_plane, which must not be one of the
  * request's references; requests of one batch whose destination blocks overlap race. */
 #define X265_HIP_PRED_WEIGHTED (-2)
@@ -342,9 +349,11 @@ typedef struct x265_hip_pred_req
     int32_t ref0_plane, ref1_plane; /* ref1_plane < 0: uni-directional prediction from ref0 */
     int16_t pu_x, pu_y;
     uint8_t pu_w, pu_h; /* one of the 25 partitions */
-    uint8_t log2_denom; /* X265_HIP_PRED_WEIGHTED only: wpScalingParam::log2WeightDenom, 0..7 */
-    uint8_t pad;
+    uint8_t log2_denom;  /* the weighted forms: wpScalingParam::log2WeightDenom, 0..7 */
+    uint8_t weighted_bi; /* != 0 with ref1_plane >= 0: weighted bi-prediction with wp_w0 .. wp_o1 */
     int16_t qmv0_x, qmv0_y, qmv1_x, qmv1_y;
+    int16_t wp_w0, wp_o0; /* weighted_bi: inputWeight (-128..255) and inputOffset (-128..127) of list 0's reference */
+    int16_t wp_w1, wp_o1; /* ... of list 1's */
 } x265_hip_pred_req;
 
 int x265_hip_predict_batch(x265_hip_ctx *ctx, const x265_hip_pred_req *reqs, int n);

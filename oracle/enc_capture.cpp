@@ -631,10 +631,11 @@ void wrap_aw(MotionReference *self, int rows, int numRows)
 
 /* X265_USE_HIP_MC=1: the luma block of every TComPrediction::motionCompensation call (TComPrediction.cpp:252-297) is
  * predicted again by x265_hip_predict_batch, compared with what the reference wrote and then written over it, so
- * the encoder goes on with the GPU's pixels.  Weighted bi-prediction (off at the medium preset) is left alone. */
+ * the encoder goes on with the GPU's pixels.  With X265_CAPTURE_WEIGHTB=1 (--weightb) the blocks of B slices go
+ * through xWeightedPredictionBi (TComPrediction.cpp:347-368) and so through the weighted forms of the request. */
 namespace {
 bool g_hip_mc = false;
-long g_mc_calls = 0, g_mc_weighted = 0, g_mc_bi = 0, g_mc_mismatch = 0, g_mc_skipped = 0;
+long g_mc_calls = 0, g_mc_weighted = 0, g_mc_bi = 0, g_mc_wbi = 0, g_mc_mismatch = 0;
 const int MC_DST = 60; /* plane id of the destination picture, outside device_plane's slots */
 std::vector<uint8_t> g_mc_buf;
 }
@@ -652,7 +653,7 @@ void wrap_mc(TComPrediction *self, TComDataCU *cu, TComYuv *predYuv, int list, i
     if (slice->isInterP())
         list = REF_PIC_LIST_0;
     int lists[2] = { -1, -1 };
-    bool weighted = false;
+    bool weighted = false, weighted_bi = false;
     if (list != REF_PIC_LIST_X)
     {
         lists[0] = list;
@@ -660,23 +661,23 @@ void wrap_mc(TComPrediction *self, TComDataCU *cu, TComYuv *predYuv, int list, i
     }
     else
     {
-        if (slice->getPPS()->getWPBiPred())
-        {
-            g_mc_skipped++;
-            return;
-        }
+        const bool wpbi = slice->getPPS()->getWPBiPred();
         const int r0 = cu->getCUMvField(REF_PIC_LIST_0)->getRefIdx(partAddr), r1 = cu->getCUMvField(REF_PIC_LIST_1)->getRefIdx(partAddr);
         if (r0 >= 0 && r1 >= 0)
         {
-            /* xCheckIdenticalMotion, TComPrediction.cpp:232-250 */
-            const bool same = slice->getRefPic(REF_PIC_LIST_0, r0)->getPOC() == slice->getRefPic(REF_PIC_LIST_1, r1)->getPOC() &&
+            /* xCheckIdenticalMotion, TComPrediction.cpp:232-250: never identical in a slice with weighted_bipred */
+            const bool same = !wpbi && slice->getRefPic(REF_PIC_LIST_0, r0)->getPOC() == slice->getRefPic(REF_PIC_LIST_1, r1)->getPOC() &&
                 cu->getCUMvField(REF_PIC_LIST_0)->getMv(partAddr) == cu->getCUMvField(REF_PIC_LIST_1)->getMv(partAddr);
             lists[0] = 0;
             if (!same)
                 lists[1] = 1;
+            weighted_bi = wpbi; /* xPredInterBi :347-350 */
         }
         else
+        {
             lists[0] = r0 >= 0 ? 0 : 1;
+            weighted = wpbi; /* xPredInterBi :356-368: xWeightedPredictionBi with one list = addWeightUni */
+        }
     }
     const int rows = (g_height + 63) / 64 * 64;
     x265_hip_pred_req q;
@@ -714,6 +715,16 @@ void wrap_mc(TComPrediction *self, TComDataCU *cu, TComYuv *predYuv, int list, i
             if (g_slots[q.ref0_plane].base != base0) /* evicted by the second upload: cannot happen with 60 slots in use by a handful of pictures, but check */
                 abort();
             q.ref1_plane = id, q.qmv1_x = mv.x, q.qmv1_y = mv.y;
+            if (weighted_bi)
+            {
+                wpScalingParam *wp0, *wp1;
+                slice->getWpScaling(REF_PIC_LIST_0, cu->getCUMvField(REF_PIC_LIST_0)->getRefIdx(partAddr), wp0);
+                slice->getWpScaling(REF_PIC_LIST_1, cu->getCUMvField(REF_PIC_LIST_1)->getRefIdx(partAddr), wp1);
+                q.weighted_bi = 1;
+                q.wp_w0 = (int16_t)wp0[0].inputWeight, q.wp_o0 = (int16_t)wp0[0].inputOffset;
+                q.wp_w1 = (int16_t)wp1[0].inputWeight, q.wp_o1 = (int16_t)wp1[0].inputOffset;
+                q.log2_denom = (uint8_t)wp0[0].log2WeightDenom;
+            }
         }
     }
     const size_t plane_bytes = (size_t)stride * (rows + 2 * MY);
@@ -741,6 +752,7 @@ void wrap_mc(TComPrediction *self, TComDataCU *cu, TComYuv *predYuv, int list, i
     g_mc_calls++;
     g_mc_weighted += weighted;
     g_mc_bi += lists[1] >= 0;
+    g_mc_wbi += weighted_bi;
     g_mc_mismatch += diff;
     if (g_mc_calls % 200000 == 0)
         fprintf(stderr, "enc_capture: %ld motionCompensation calls answered so far\n", g_mc_calls);
@@ -958,8 +970,63 @@ bool wrap_pi(TEncSearch *self, TComDataCU *cu, TComYuv *predYuv, bool bMergeOnly
     return ok;
 }
 
+/* --wpbi in.bin out.bin: TComWeightPrediction::xWeightedPredictionBi (TComWeightPrediction.cpp:609-618) of the reference on
+ * given intermediates, for tests/golden/wpbi.npz.  in.bin: int32 n, then per case seven int32 (w, h, inputWeight and
+ * inputOffset of list 0's entry, of list 1's, log2WeightDenom) and two 64x64 int16 blocks (the ShortYuv of each list);
+ * out.bin: per case the 64x64 uint8 block the reference wrote (w x h of it).  The slice's weight table is set the way
+ * weightAnalyse's result is stored (TComSlice::setWpScaling) and read back by the reference's own getWpScaling. */
+static int wpbi_fixture(const char *in_path, const char *out_path)
+{
+    FILE *in = fopen(in_path, "rb"), *out = fopen(out_path, "wb");
+    int32_t n = 0;
+    if (!in || !out || fread(&n, 4, 1, in) != 1)
+        return 1;
+    TComPPS pps;
+    pps.setWPBiPred(true);
+    TComSlice slice;
+    slice.setPPS(&pps);
+    slice.setSliceType(B_SLICE);
+    TComDataCU cu;
+    cu.m_slice = &slice;
+    ShortYuv s0, s1;
+    TComYuv dst;
+    if (!s0.create(64, 64, X265_CSP_I420) || !s1.create(64, 64, X265_CSP_I420) || !dst.create(64, 64, X265_CSP_I420))
+        return 1;
+    TComWeightPrediction wp;
+    for (int i = 0; i < n; i++)
+    {
+        int32_t hd[7];
+        if (fread(hd, 4, 7, in) != 7 || fread(s0.getLumaAddr(), 2, 64 * 64, in) != 64 * 64 || fread(s1.getLumaAddr(), 2, 64 * 64, in) != 64 * 64)
+            return 1;
+        if (s0.m_width != 64 || s1.m_width != 64 || dst.getStride() != 64)
+            return 1;
+        wpScalingParam tab[2][MAX_NUM_REF][3];
+        memset(tab, 0, sizeof(tab));
+        for (int l = 0; l < 2; l++)
+            for (int c = 0; c < 3; c++)
+            {
+                tab[l][0][c].bPresentFlag = true;
+                tab[l][0][c].log2WeightDenom = (uint32_t)hd[6];
+                tab[l][0][c].inputWeight = hd[2 + 2 * l];
+                tab[l][0][c].inputOffset = hd[3 + 2 * l];
+            }
+        slice.setWpScaling(tab);
+        memset(dst.getLumaAddr(), 0, 64 * 64);
+        wp.xWeightedPredictionBi(&cu, &s0, &s1, 0, 0, 0, hd[0], hd[1], &dst, true, false);
+        fwrite(dst.getLumaAddr(), 1, 64 * 64, out);
+    }
+    fclose(in);
+    fclose(out);
+    s0.destroy();
+    s1.destroy();
+    dst.destroy();
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc == 4 && !strcmp(argv[1], "--wpbi"))
+        return wpbi_fixture(argv[2], argv[3]);
     if (argc < 6)
     {
         fprintf(stderr, "usage: %s in.yuv width height frames out_dir [max_full [max_lowres [first_full [pool_threads [frame_threads]]]]]\n", argv[0]);
@@ -996,6 +1063,8 @@ int main(int argc, char **argv)
     p->frameNumThreads = frame_threads;
     p->poolNumThreads = pool_threads;
     p->logLevel = X265_LOG_WARNING;
+    if (getenv("X265_CAPTURE_WEIGHTB")) /* --weightb: weighted prediction in B slices (param.cpp:610) */
+        p->bEnableWeightedBiPred = 1;
     x265_encoder *enc = x265_encoder_open(p);
     if (!enc)
     {
@@ -1138,8 +1207,8 @@ int main(int argc, char **argv)
         fprintf(stderr, "enc_capture: %ld batches of weighted reference rows made on the GPU as applyWeight added them, %ld differed\n", g_aw_batches,
                 g_aw_batch_mismatch);
     if (g_hip_mc)
-        fprintf(stderr, "enc_capture: %ld motionCompensation luma blocks predicted on the GPU (%ld weighted, %ld bi-directional), %ld differed from the reference's own pixels, %ld left alone\n",
-                g_mc_calls, g_mc_weighted, g_mc_bi, g_mc_mismatch, g_mc_skipped);
+        fprintf(stderr, "enc_capture: %ld motionCompensation luma blocks predicted on the GPU (%ld weighted, %ld bi-directional), %ld differed from the reference's own pixels; %ld of the bi-directional ones weighted\n",
+                g_mc_calls, g_mc_weighted, g_mc_bi, g_mc_mismatch, g_mc_wbi);
     if (g_hip_look)
     {
         fprintf(stderr, "enc_capture: %ld lookahead frame searches asked for, %ld launches of x265_hip_lookahead_batch in %.3f s (%.3f ms each, upload and download included), %ld lowres motionEstimate calls answered from them, %ld differed from the reference's own answer%s\n",

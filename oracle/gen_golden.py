@@ -12,6 +12,7 @@ been run.  The fixtures hold inputs and the reference's outputs (data, no refere
               motionEstimate call records against them (ref->isLowres)
   encoder_pu.npz  the prediction units of a reference encoder run: their iterations, xGetBlkBits / lambda, and what
               predInterSearch left in the CU (direction, vectors, AMVP indices) -- see gen_encoder_pu
+  wpbi.npz    weighted bi-prediction (xWeightedPredictionBi) of random intermediates -- see gen_wpbi
   me.npz      motionEstimate call records (inputs) and (cost, qmv) results on a small synthetic
               sequence for every search method and sub-pel level, plus two per-CTU full searches
 
@@ -187,6 +188,52 @@ def gen_pred(R):
     np.savez_compressed(os.path.join(OUT, "pred.npz"), reqs=np.stack(batches), crc=np.array(crcs, np.uint32))
 
 
+def wpbi_cases(rng, n):
+    """weighted bi-prediction cases: every partition, intermediates over the range the filters produce (with their
+    overshoot) and at its ends, weights and offsets of each kind (unit, near the unit ones, the whole range)"""
+    hd = np.zeros((n, 7), np.int32)
+    src = np.zeros((n, 2, 64, 64), np.int16)
+    for i in range(n):
+        w, h = pyoracle.PARTS[i % 25]
+        kind = int(rng.integers(3))
+        denom = 6 if kind == 1 else int(rng.integers(0, 8))
+        wo = []
+        for _ in range(2):
+            wo += [1 << denom if kind == 0 else int(rng.integers(40, 90)) if kind == 1 else int(rng.integers(-128, 256)),
+                   0 if kind == 0 else int(rng.integers(-20, 20)) if kind == 1 else int(rng.integers(-128, 128))]
+        hd[i] = [w, h] + wo + [denom]
+        # p2s gives (pixel << 6) - 8192; the 8-tap filters overshoot that range by up to about a quarter
+        src[i] = rng.integers(-8192 - 2800, 8128 + 2800, (2, 64, 64))
+        if i % 5 == 0:
+            src[i][rng.integers(0, 2, (2, 64, 64)) == 0] = rng.choice([-8192, 8128])
+    return hd, src
+
+
+def gen_wpbi():
+    """wpbi.npz: TComWeightPrediction::xWeightedPredictionBi of the reference (the whole encoder library, through
+    oracle/_ref/enc_capture --wpbi) on random intermediates: inputs and the blocks it wrote"""
+    import subprocess
+    import tempfile
+    exe = os.path.join(HERE, "_ref", "enc_capture")
+    if not os.path.exists(exe):
+        sys.exit("oracle/_ref/enc_capture missing: run `make -C oracle capture`")
+    hd, src = wpbi_cases(np.random.default_rng(87), 75)
+    with tempfile.TemporaryDirectory() as tmp:
+        fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(np.int32(len(hd)).tobytes())
+            for h_, s_ in zip(hd, src):
+                f.write(h_.tobytes())
+                f.write(s_.tobytes())
+        subprocess.run([exe, "--wpbi", fin, fout], check=True)
+        dst = np.fromfile(fout, np.uint8).reshape(len(hd), 64, 64)
+    for (w, h), s_, d_ in zip(hd[:, :2], src, dst):  # only the block is read and written
+        assert not d_[h:].any() and not d_[:, w:].any()
+    np.savez_compressed(os.path.join(OUT, "wpbi.npz"), params=hd,
+                        src=np.concatenate([s_[:, :h, :w].reshape(-1) for (w, h), s_ in zip(hd[:, :2], src)]),
+                        dst=np.concatenate([d_[:h, :w].reshape(-1) for (w, h), d_ in zip(hd[:, :2], dst)]))
+
+
 CAPTURE_CALL = np.dtype([
     ("fenc_plane", "<i4"), ("ref_plane", "<i4"), ("pu_x", "<i2"), ("pu_y", "<i2"), ("pu_w", "u1"), ("pu_h", "u1"),
     ("method", "u1"), ("subme", "u1"), ("mvmin_x", "<i2"), ("mvmin_y", "<i2"), ("mvmax_x", "<i2"), ("mvmax_y", "<i2"),
@@ -333,6 +380,7 @@ def main():
     gen_lowres(R)
     gen_dist(R)
     gen_pred(R)
+    gen_wpbi()
     gen_encoder()
     gen_encoder_pu()
     for f in sorted(os.listdir(OUT)):
@@ -344,5 +392,9 @@ if __name__ == "__main__":
         gen_encoder()
     elif len(sys.argv) > 1 and sys.argv[1] == "encoder_pu":
         gen_encoder_pu()
+    elif len(sys.argv) > 1 and sys.argv[1] == "wpbi":
+        gen_wpbi()
+    elif len(sys.argv) > 1 and sys.argv[1] == "pred":
+        gen_pred(pyoracle.load_ref())
     else:
         main()

@@ -51,10 +51,11 @@ assert BIDIR_REQ.itemsize == 28
 PRED_REQ = np.dtype([
     ("dst_plane", "<i4"), ("ref0_plane", "<i4"), ("ref1_plane", "<i4"),
     ("pu_x", "<i2"), ("pu_y", "<i2"),
-    ("pu_w", "u1"), ("pu_h", "u1"), ("log2_denom", "u1"), ("pad", "u1"),
+    ("pu_w", "u1"), ("pu_h", "u1"), ("log2_denom", "u1"), ("weighted_bi", "u1"),
     ("qmv0_x", "<i2"), ("qmv0_y", "<i2"), ("qmv1_x", "<i2"), ("qmv1_y", "<i2"),
+    ("wp_w0", "<i2"), ("wp_o0", "<i2"), ("wp_w1", "<i2"), ("wp_o1", "<i2"),
 ])
-assert PRED_REQ.itemsize == 28
+assert PRED_REQ.itemsize == 36
 
 
 INTER_JOB = np.dtype([
@@ -351,6 +352,15 @@ class Checker:
     def luma_addavg(self, part, src0, o0, src1, o1, dst, doff, sstride0, sstride1, dstride):
         self._f("luma_addavg")(C.c_int(part), _ptr(src0, 2 * o0), _ptr(src1, 2 * o1), _ptr(dst, doff), C.c_ssize_t(sstride0),
                                C.c_ssize_t(sstride1), C.c_ssize_t(dstride))
+
+    def add_weight_bi(self, src0, src1, width, height, w0, o0, w1, o1, log2_denom):
+        """xWeightedPredictionBi's luma block from the two lists' intermediates (64x64 int16 arrays): 64x64 uint8, zero
+        outside width x height"""
+        src0, src1 = np.ascontiguousarray(src0, np.int16), np.ascontiguousarray(src1, np.int16)
+        dst = np.zeros((64, 64), np.uint8)
+        self._f("add_weight_bi")(_ptr(src0), _ptr(src1), _ptr(dst), C.c_ssize_t(64), C.c_ssize_t(64), C.c_ssize_t(64), C.c_int(width),
+                                 C.c_int(height), C.c_int(w0), C.c_int(o0), C.c_int(w1), C.c_int(o1), C.c_int(log2_denom))
+        return dst
 
     def ctu_fullsearch(self, fenc, ref, costtab, ctu_x, ctu_y, mvmin, mvmax, qmvp):
         out = np.zeros(85, ME_RESULT)

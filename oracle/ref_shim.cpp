@@ -399,6 +399,13 @@ void x265r_predict_batch(const x265o_plane *planes, const x265o_pred_req *reqs, 
         }
         else
         {
+            if (r->weighted_bi)
+            {
+                /* xWeightedPredictionBi is a member of the encoder's prediction class, not a primitive: it is run by
+                 * oracle/_ref/enc_capture --wpbi, which links the whole encoder (tests/golden/wpbi.npz) */
+                fprintf(stderr, "x265r_predict_batch: weighted bi-prediction is not reachable through the primitive table\n");
+                abort();
+            }
             const x265o_plane &b = planes[r->ref1_plane];
             pixel *pb = (pixel *)b.origin + r->pu_x + (intptr_t)r->pu_y * b.stride;
             ref_predict_luma_short(part, r->pu_w, r->pu_h, pa, a.stride, r->qmv0_x, r->qmv0_y, s0);

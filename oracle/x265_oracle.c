@@ -1280,9 +1280,26 @@ void x265o_weight_sp(const int16_t *src, uint8_t *dst, intptr_t sstride, intptr_
         }
 }
 
+/* ref: TComWeightPrediction::addWeightBi on two ShortYuv, luma, TComWeightPrediction.cpp:203-255 (weightBidirY :46-49)
+ * with the parameters getWpScaling derives for a block that uses both lists (:534-547): w = inputWeight,
+ * o = inputOffset (8-bit samples: x 1), shift = log2WeightDenom of list 0's entry, + IF_INTERNAL_PREC - X265_DEPTH + 1,
+ * round = 1 << (shift - 1) (bRound is true at both call sites, :581, :617) */
+void x265o_add_weight_bi(const int16_t *src0, const int16_t *src1, uint8_t *dst, intptr_t sstride0, intptr_t sstride1,
+                         intptr_t dstride, int width, int height, int w0, int o0, int w1, int o1, int log2_denom)
+{
+    int offset = o0 + o1, shift = log2_denom + 6 + 1, round = 1 << (shift - 1);
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++)
+        {
+            int v = (w0 * (src0[y * sstride0 + x] + 8192) + w1 * (src1[y * sstride1 + x] + 8192) + round + offset * (1 << (shift - 1))) >> shift;
+            dst[y * dstride + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+}
+
 /* ref: TComPrediction::xPredInterUni / xPredInterBi for luma, TComPrediction.cpp:330-387; weighted
  * uni-directional prediction: motionCompensation's getUseWP branch, TComPrediction.cpp:265-279, with
- * TComWeightPrediction::addWeightUni, TComWeightPrediction.cpp:433-458 (weighted bi-prediction is not covered) */
+ * TComWeightPrediction::addWeightUni, TComWeightPrediction.cpp:433-458; weighted bi-prediction: xPredInterBi's
+ * getWPBiPred branch, TComPrediction.cpp:347-350, with xWeightedPredictionBi, TComWeightPrediction.cpp:609-618 */
 void x265o_predict_batch(const x265o_plane *planes, const x265o_pred_req *reqs, int n)
 {
     for (int i = 0; i < n; i++)
@@ -1314,7 +1331,11 @@ void x265o_predict_batch(const x265o_plane *planes, const x265o_pred_req *reqs, 
                                r->qmv0_y, s0);
             predict_luma_short(part, r->pu_w, r->pu_h, b->origin + r->pu_x + (intptr_t)r->pu_y * b->stride, b->stride, r->qmv1_x,
                                r->qmv1_y, s1);
-            x265o_luma_addavg(part, s0, s1, dst, 64, 64, d->stride);
+            if (r->weighted_bi)
+                x265o_add_weight_bi(s0, s1, dst, 64, 64, d->stride, r->pu_w, r->pu_h, r->wp_w0, r->wp_o0, r->wp_w1, r->wp_o1,
+                                    r->log2_denom);
+            else
+                x265o_luma_addavg(part, s0, s1, dst, 64, 64, d->stride);
         }
     }
 }

@@ -204,7 +204,8 @@ void x265o_bidir_cost_batch(const x265o_plane *planes, const x265o_bidir_req *re
 /* motion-compensated luma prediction (TComPrediction.cpp:330-473): the remaining interpolation primitives
  * (ipfilter.cpp:37-54, 203-239, 284-317, 362-369), luma_addAvg (pixel.cpp:819-839) and the batch that writes
  * predictions into planes[dst_plane] (uni-directional when ref1_plane < 0; ref1_plane == X265O_PRED_WEIGHTED:
- * weighted uni-directional prediction, w0 = qmv1_x, offset = qmv1_y, see x265o_weight_sp) */
+ * weighted uni-directional prediction, w0 = qmv1_x, offset = qmv1_y, see x265o_weight_sp; weighted_bi != 0 with
+ * ref1_plane >= 0: weighted bi-prediction, see x265o_add_weight_bi) */
 #define X265O_PRED_WEIGHTED (-2)
 typedef struct x265o_pred_req
 {
@@ -212,9 +213,10 @@ typedef struct x265o_pred_req
     int32_t ref0_plane, ref1_plane;
     int16_t pu_x, pu_y;
     uint8_t pu_w, pu_h;
-    uint8_t log2_denom; /* weighted uni-directional requests (ref1_plane == X265O_PRED_WEIGHTED): log2WeightDenom */
-    uint8_t pad;
+    uint8_t log2_denom;  /* the weighted forms: log2WeightDenom */
+    uint8_t weighted_bi; /* != 0 with ref1_plane >= 0: xWeightedPredictionBi with the four values below */
     int16_t qmv0_x, qmv0_y, qmv1_x, qmv1_y;
+    int16_t wp_w0, wp_o0, wp_w1, wp_o1; /* inputWeight / inputOffset of list 0's and list 1's reference */
 } x265o_pred_req;
 void x265o_luma_p2s(const uint8_t *src, intptr_t sstride, int16_t *dst, int width, int height);
 void x265o_luma_vps(int part, const uint8_t *src, intptr_t sstride, int16_t *dst, intptr_t dstride, int coeffIdx);
@@ -224,6 +226,8 @@ void x265o_luma_addavg(int part, const int16_t *src0, const int16_t *src1, uint8
                        intptr_t dstride);
 void x265o_weight_sp(const int16_t *src, uint8_t *dst, intptr_t sstride, intptr_t dstride, int width, int height, int w0,
                      int round, int shift, int offset);
+void x265o_add_weight_bi(const int16_t *src0, const int16_t *src1, uint8_t *dst, intptr_t sstride0, intptr_t sstride1,
+                         intptr_t dstride, int width, int height, int w0, int o0, int w1, int o1, int log2_denom);
 void x265o_predict_batch(const x265o_plane *planes, const x265o_pred_req *reqs, int n);
 
 /* lookahead planes: frame_init_lowres_core (pixel.cpp:595-618) and extendPicBorder (pixel.cpp:893-911) */

@@ -134,10 +134,10 @@ def random_cost_reqs(rng, n, W, H, dtype, parts, metrics=(0, 1), planes=(1, (0, 
     return reqs
 
 
-def random_pred_reqs(rng, W, H, dtype, parts, dst_plane=5, refs=(0, 2), cell=64):
+def random_pred_reqs(rng, W, H, dtype, parts, dst_plane=5, refs=(0, 2), cell=64, weighted_bi=False):
     """one prediction request per 64x64 cell of the picture (destination blocks of a batch must not overlap):
     every partition, uni- and bi-directional and weighted uni-directional (ref1_plane -2: w0 in qmv1_x, offset in
-    qmv1_y), all fractions"""
+    qmv1_y), all fractions; with `weighted_bi` half of the bi-directional ones are weighted (xWeightedPredictionBi)"""
     cells = [(cx, cy) for cy in range(0, H - cell + 1, cell) for cx in range(0, W - cell + 1, cell)]
     reqs = np.zeros(len(cells), dtype)
     for r, (cx, cy) in zip(reqs, cells):
@@ -156,6 +156,14 @@ def random_pred_reqs(rng, W, H, dtype, parts, dst_plane=5, refs=(0, 2), cell=64)
             r["ref1_plane"], r["log2_denom"] = -2, denom
             r["qmv1_x"] = 1 << denom if kind == 0 else int(rng.integers(96, 160)) if kind == 1 else int(rng.integers(-128, 256))
             r["qmv1_y"] = 0 if kind == 0 else int(rng.integers(-20, 20)) if kind == 1 else int(rng.integers(-128, 128))
+        elif weighted_bi and r["ref1_plane"] >= 0 and rng.integers(2):
+            # xPredInterBi's getWPBiPred branch: unit weights, weights near the unit ones, the whole range
+            kind = int(rng.integers(3))
+            denom = 6 if kind == 1 else int(rng.integers(0, 8))
+            r["weighted_bi"], r["log2_denom"] = 1, denom
+            for w_, o_ in (("wp_w0", "wp_o0"), ("wp_w1", "wp_o1")):
+                r[w_] = 1 << denom if kind == 0 else int(rng.integers(40, 90)) if kind == 1 else int(rng.integers(-128, 256))
+                r[o_] = 0 if kind == 0 else int(rng.integers(-20, 20)) if kind == 1 else int(rng.integers(-128, 128))
     return reqs
 
 
@@ -211,3 +219,18 @@ def random_inter_units(rng, n_units, W, H, job_dtype, pu_dtype, parts, qps=(20, 
             j["amvp"][2], j["amvp"][3] = (base[0] + int(rng.integers(-12, 13)), base[1] + int(rng.integers(-12, 13))) if rng.integers(4) else (0, 0)
             jobs.append(j)
     return np.array(jobs, job_dtype), np.array(pus, pu_dtype)
+
+
+def wpbi_fixture():
+    """[(params, src (2, 64, 64) int16, dst (64, 64) uint8)] of tests/golden/wpbi.npz"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wpbi.npz"))
+    out, so, do = [], 0, 0
+    for hd in g["params"]:
+        w, h = int(hd[0]), int(hd[1])
+        src, dst = np.zeros((2, 64, 64), np.int16), np.zeros((64, 64), np.uint8)
+        src[:, :h, :w] = g["src"][so:so + 2 * w * h].reshape(2, h, w)
+        dst[:h, :w] = g["dst"][do:do + w * h].reshape(h, w)
+        so, do = so + 2 * w * h, do + w * h
+        out.append(([int(x) for x in hd], src, dst))
+    return out
+

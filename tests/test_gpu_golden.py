@@ -368,6 +368,18 @@ def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
             assert m and int(m.group(1)) > 100 and int(m.group(2)) > 0 and int(m.group(4)) == 0, r.stderr
         hashes.append(re.search(r"%d pictures in .* bitstream hash ([0-9a-f]+)" % N, r.stderr).group(1))
     assert len(set(hashes)) == 1, hashes
+    # --weightb: the blocks of B slices go through xWeightedPredictionBi (two lists: addWeightBi; one: addWeightUni)
+    hashes = []
+    for modes in ({"X265_CAPTURE_WEIGHTB": "1"}, {"X265_CAPTURE_WEIGHTB": "1", "X265_USE_HIP_MC": "1"}):
+        r = subprocess.run([exe, str(clip), str(W), str(H), str(N), str(tmp_path), "0", "0", "0", "2", "1"], env=dict(os.environ, **modes),
+                           capture_output=True, text=True, timeout=100)
+        assert r.returncode == 0, r.stderr
+        if "X265_USE_HIP_MC" in modes:
+            m = re.search(r"(\d+) motionCompensation luma blocks predicted on the GPU \((\d+) weighted, (\d+) bi-directional\), (\d+) differed "
+                          r"from the reference's own pixels; (\d+) of the bi-directional ones weighted", r.stderr)
+            assert m and int(m.group(4)) == 0 and int(m.group(5)) > 20 and m.group(5) == m.group(3), r.stderr
+        hashes.append(re.search(r"%d pictures in .* bitstream hash ([0-9a-f]+)" % N, r.stderr).group(1))
+    assert len(set(hashes)) == 1, hashes
     # three frame threads: MotionReference::applyWeight weights a reference's CU rows while the picture is still being
     # reconstructed; each batch of rows is made again by x265_hip_plane_weight_rows (with the table's extendRowBorder
     # installed as well: the frame filter and applyWeight extend their rows through it)

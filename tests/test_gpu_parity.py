@@ -453,16 +453,19 @@ def test_primitive_table_distortions(oracle):
 
 def test_predict_batch(gpu_ctx, oracle, small_seq):
     """x265_hip_predict_batch against the oracle: whole destination buffers (nothing outside the blocks may change),
-    every partition, uni- and bi-directional, all fraction pairs"""
+    every partition, uni- and bi-directional, weighted uni-directional and (every other batch) weighted bi-directional,
+    all fraction pairs"""
     from conftest import random_pred_reqs
-    from x265_amd import abi
+    from x265_amd import abi, lib
     rng = np.random.default_rng(62)
     p0 = small_seq[0]
     planes = [p.as_tuple() for p in small_seq]
     want = np.full_like(p0.buf, 0x5A)
     gpu_ctx.plane_upload(5, want, p0.stride, p0.origin)
-    for _ in range(40):
-        reqs = random_pred_reqs(rng, p0.w, p0.h, abi.PRED_REQ, oracle_parts(), dst_plane=5)
+    n_wbi = 0
+    for it in range(40):
+        reqs = random_pred_reqs(rng, p0.w, p0.h, abi.PRED_REQ, oracle_parts(), dst_plane=5, weighted_bi=bool(it & 1))
+        n_wbi += int(reqs["weighted_bi"].sum())
         gpu_ctx.predict_batch(reqs)
         reqs_o = reqs.copy()
         reqs_o["dst_plane"] = 3
@@ -470,6 +473,16 @@ def test_predict_batch(gpu_ctx, oracle, small_seq):
         got = gpu_ctx.plane_download(5, want.size)
         bad = np.nonzero(got != want)[0]
         assert len(bad) == 0, (len(bad), divmod(int(bad[0]) - p0.origin, p0.stride))
+    assert n_wbi > 50
+    # weights outside what the slice header can carry, and a weighted pair with one reference, are refused
+    bi = reqs[(reqs["ref1_plane"] >= 0)][:1].copy()
+    bi["weighted_bi"], bi["wp_w0"], bi["wp_w1"], bi["log2_denom"] = 1, 64, 64, 6
+    gpu_ctx.predict_batch(bi)
+    for k, v in (("wp_w0", 256), ("wp_w1", -129), ("wp_o0", 128), ("wp_o1", -129), ("log2_denom", 8), ("ref1_plane", -1)):
+        q = bi.copy()
+        q[k] = v
+        with pytest.raises(lib.X265HipError):
+            gpu_ctx.predict_batch(q)
     gpu_ctx.plane_release(5)
 
 

@@ -178,6 +178,16 @@ def test_predictions_match_reference_fixtures(oracle):
         assert zlib.crc32(dst.tobytes()) & 0xffffffff == int(want)
 
 
+def test_weighted_bi_prediction_matches_reference_fixture(oracle):
+    """wpbi.npz: TComWeightPrediction::xWeightedPredictionBi of the reference (getWpScaling + addWeightBi, run through
+    oracle/_ref/enc_capture --wpbi) on 75 blocks of intermediates: every partition, unit / typical / extreme weights"""
+    from conftest import wpbi_fixture
+    cases = wpbi_fixture()
+    assert len(cases) == 75 and any(c[0][2] < 0 for c in cases) and any(c[0][6] == 0 for c in cases)
+    for hd, src, dst in cases:
+        assert np.array_equal(oracle.add_weight_bi(src[0], src[1], *hd), dst), hd
+
+
 def test_lowres_bidir_costs_match_reference_fixtures(oracle):
     """lowres_bidir.npz: the lookahead's bidirectional cost (lowresMC x 2, pixelavg_pp, satd) by the reference build"""
     g = np.load(os.path.join(GOLD, "lowres_bidir.npz"))

@@ -97,7 +97,7 @@ dst = np.full_like(planes[0].buf, 0x5A)
 ctx.plane_upload(5, dst, planes[0].stride, planes[0].origin)
 npred, nbad = 0, 0
 for _ in range(max(10, N // 200)):
-    pr = random_pred_reqs(rng, W, H, abi.PRED_REQ, abi.PARTS, dst_plane=5, refs=(0, 2, 4))
+    pr = random_pred_reqs(rng, W, H, abi.PRED_REQ, abi.PARTS, dst_plane=5, refs=(0, 2, 4), weighted_bi=True)
     ctx.predict_batch(pr)
     O.predict_batch(pl + [(dst, planes[0].origin, planes[0].stride)], pr)
     nbad += int((ctx.plane_download(5, dst.size) != dst).sum())

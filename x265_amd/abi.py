@@ -46,15 +46,17 @@ BIDIR_REQ = np.dtype([
 assert BIDIR_REQ.itemsize == 28
 
 # x265_hip_pred_req: motion-compensated luma prediction into dst_plane (uni-directional when ref1_plane < 0;
-# ref1_plane == PRED_WEIGHTED: weighted uni-directional, w0 in qmv1_x, offset in qmv1_y, log2_denom)
+# ref1_plane == PRED_WEIGHTED: weighted uni-directional, w0 in qmv1_x, offset in qmv1_y, log2_denom;
+# weighted_bi != 0 with ref1_plane >= 0: weighted bi-prediction with wp_w0, wp_o0, wp_w1, wp_o1, log2_denom)
 PRED_WEIGHTED = -2
 PRED_REQ = np.dtype([
     ("dst_plane", "<i4"), ("ref0_plane", "<i4"), ("ref1_plane", "<i4"),
     ("pu_x", "<i2"), ("pu_y", "<i2"),
-    ("pu_w", "u1"), ("pu_h", "u1"), ("log2_denom", "u1"), ("pad", "u1"),
+    ("pu_w", "u1"), ("pu_h", "u1"), ("log2_denom", "u1"), ("weighted_bi", "u1"),
     ("qmv0_x", "<i2"), ("qmv0_y", "<i2"), ("qmv1_x", "<i2"), ("qmv1_y", "<i2"),
+    ("wp_w0", "<i2"), ("wp_o0", "<i2"), ("wp_w1", "<i2"), ("wp_o1", "<i2"),
 ])
-assert PRED_REQ.itemsize == 28
+assert PRED_REQ.itemsize == 36
 
 # x265_hip_refine_req: one sub-pel ring around `qmv` (costs of centre + square1[i] * step); nine costs per request
 RING_QPEL, RING_HPEL, RING_8, RING_CENTRE, RING_COSTS = 0x01, 0x02, 0x10, 0x20, 9

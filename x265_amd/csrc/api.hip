@@ -1093,6 +1093,12 @@ static int validate_pred(const x265_hip_ctx *c, const x265_hip_pred_req *reqs, i
             (q.log2_denom > 7 || q.qmv1_x < -128 || q.qmv1_x > 255 || q.qmv1_y < -128 || q.qmv1_y > 127))
             return fail(X265_HIP_EINVAL, "pred_req[%d]: weight %d / offset %d / log2 denominator %d out of range", i, q.qmv1_x,
                         q.qmv1_y, q.log2_denom);
+        if (q.weighted_bi && q.ref1_plane < 0)
+            return fail(X265_HIP_EINVAL, "pred_req[%d]: weighted bi-prediction takes two references", i);
+        if (q.weighted_bi && (q.log2_denom > 7 || q.wp_w0 < -128 || q.wp_w0 > 255 || q.wp_w1 < -128 || q.wp_w1 > 255 || q.wp_o0 < -128 ||
+                              q.wp_o0 > 127 || q.wp_o1 < -128 || q.wp_o1 > 127))
+            return fail(X265_HIP_EINVAL, "pred_req[%d]: weights %d %d / offsets %d %d / log2 denominator %d out of range", i, q.wp_w0,
+                        q.wp_w1, q.wp_o0, q.wp_o1, q.log2_denom);
         if ((r = check_inside(c, q.dst_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, "pred_req", i)) ||
             (r = check_displaced(c, q.ref0_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv0_x, q.qmv0_y, "pred_req", i)) ||
             (q.ref1_plane >= 0 &&

@@ -2007,6 +2007,16 @@ __device__ __forceinline__ int req_weight(const x265_hip_pred_req &r)
 }
 __device__ __forceinline__ int req_weight(const x265_hip_cost_req &) { return 0; }
 __device__ __forceinline__ int req_weight(const x265_hip_bidir_req &) { return 0; }
+// weighted bi-prediction: w0 | w1 << 16 and (o0 + o1) | log2 denominator << 16
+__device__ __forceinline__ bool req_weighted_bi(const x265_hip_pred_req &r) { return r.weighted_bi != 0; }
+__device__ __forceinline__ int req_bi_weights(const x265_hip_pred_req &r) { return (r.wp_w0 & 0xffff) | ((int)r.wp_w1 << 16); }
+__device__ __forceinline__ int req_bi_offset(const x265_hip_pred_req &r) { return ((r.wp_o0 + r.wp_o1) & 0xffff) | ((r.log2_denom & 7) << 16); }
+__device__ __forceinline__ bool req_weighted_bi(const x265_hip_cost_req &) { return false; }
+__device__ __forceinline__ bool req_weighted_bi(const x265_hip_bidir_req &) { return false; }
+__device__ __forceinline__ int req_bi_weights(const x265_hip_cost_req &) { return 0; }
+__device__ __forceinline__ int req_bi_weights(const x265_hip_bidir_req &) { return 0; }
+__device__ __forceinline__ int req_bi_offset(const x265_hip_cost_req &) { return 0; }
+__device__ __forceinline__ int req_bi_offset(const x265_hip_bidir_req &) { return 0; }
 
 // weight_sp on a packed pair of 14-bit intermediates (reference common/pixel.cpp:492-508): the pair of pixels
 __device__ __forceinline__ uint32_t weight_pair(uint32_t p, int wpack)
@@ -2015,6 +2025,18 @@ __device__ __forceinline__ uint32_t weight_pair(uint32_t p, int wpack)
     const int round = 1 << (shift - 1);
     int lo = ((((int16_t)(p & 0xffff) + 8192) * w0 + round) >> shift) + offset;
     int hi = (((((int)p >> 16) + 8192) * w0 + round) >> shift) + offset;
+    lo = min(max(lo, 0), 255);
+    hi = min(max(hi, 0), 255);
+    return (uint32_t)lo | ((uint32_t)hi << 16);
+}
+// TComWeightPrediction::addWeightBi on packed pairs of the two lists' 14-bit intermediates (reference
+// TComWeightPrediction.cpp:46-49, 225-249): clip((w0 (P0 + 8192) + w1 (P1 + 8192) + round + (offset << (shift - 1))) >> shift)
+__device__ __forceinline__ uint32_t weight_bi_pair(uint32_t a, uint32_t b, int wpack, int opack)
+{
+    const int w0 = (int16_t)(wpack & 0xffff), w1 = wpack >> 16, offset = (int16_t)(opack & 0xffff), shift = (opack >> 16) + 7;
+    const int add = (1 + offset) * (1 << (shift - 1)) + 8192 * (w0 + w1);
+    int lo = (w0 * (int16_t)(a & 0xffff) + w1 * (int16_t)(b & 0xffff) + add) >> shift;
+    int hi = (w0 * ((int)a >> 16) + w1 * ((int)b >> 16) + add) >> shift;
     lo = min(max(lo, 0), 255);
     hi = min(max(hi, 0), 255);
     return (uint32_t)lo | ((uint32_t)hi << 16);
@@ -2033,14 +2055,14 @@ __device__ __forceinline__ int req_qy1(const x265_hip_bidir_req &r) { return r.q
 // an even slot so that the two halves of an 8x8 block sit in lanes 2j and 2j + 1 (sa8d_strip).
 // MODE_PRED: requests are x265_hip_pred_req; nothing is compared, the predicted strips are stored into the
 // destination plane (uni-directional: the pixels of the other modes; bi-directional: luma_addAvg of the two
-// lists' 14-bit intermediates, INFO_PRED_BI; weighted uni-directional: weight_sp of the 14-bit intermediate,
-// INFO_PRED_W, parameters in rstride1[]).
+// lists' 14-bit intermediates, INFO_PRED_BI, or with INFO_PRED_WBI their weighted sum, parameters in wbi[];
+// weighted uni-directional: weight_sp of the 14-bit intermediate, INFO_PRED_W, parameters in rstride1[]).
 // The modes are bits: bidir_cost_kernel is MODE_BIDIR | MODE_DIST (all four comparisons).  With INFO_MCAVG a
 // bidirectional request combines its two predictions the way motion compensation does (14-bit intermediates +
 // luma_addAvg, xPredInterBi) instead of pixelavg_pp: what xMergeEstimation measures on a bi-directional merge
 // candidate (TEncSearch.cpp:2209-2210) and mode decision on a bi-predicted block.
 enum { MODE_COST = 0, MODE_BIDIR = 1, MODE_DIST = 2, MODE_PRED = 4 };
-enum { INFO_LOWRES = 1 << 24, INFO_MCAVG = 1 << 25, INFO_PRED_BI = 1 << 26, INFO_PRED_W = 1 << 27 };
+enum { INFO_LOWRES = 1 << 24, INFO_MCAVG = 1 << 25, INFO_PRED_BI = 1 << 26, INFO_PRED_W = 1 << 27, INFO_PRED_WBI = 1 << 28 };
 #define DIST_UNITS 16 // 64x64: sixteen 16x16 blocks; 32x24 / 24x32: twelve 8x8 blocks
 
 template <int MODE, typename Req>
@@ -2069,6 +2091,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
     __shared__ int units_lds[DIST ? 4 : 1][COST_BATCH * DIST_UNITS];
     // Lowres references of bidirectional requests: half-pel planes 1..3 of both references at the displaced block
     __shared__ const uint8_t *low_lds[BIDIR ? 4 : 1][6][BIDIR ? COST_BATCH : 1];
+    __shared__ int wbi_lds[PRED ? 4 : 1][2][PRED ? COST_BATCH : 1];      // weighted bi-prediction: weights, offset and shift
     __shared__ PlaneDesc planes[X265_HIP_MAX_PLANES];
     static_assert(sizeof(PlaneDesc) == 16, "plane directory copy below: one 16-byte entry per thread and round");
     for (int i = threadIdx.x; i < X265_HIP_MAX_PLANES; i += 256)
@@ -2079,6 +2102,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
     int *const count = count_lds[threadIdx.x >> 6];
     int *const units = units_lds[DIST ? threadIdx.x >> 6 : 0];
     auto &low = low_lds[BIDIR ? threadIdx.x >> 6 : 0];
+    auto &wbi = wbi_lds[PRED ? threadIdx.x >> 6 : 0];
     const int lane = threadIdx.x & 63;
     if (!PRED && rb > 1)
     {
@@ -2152,6 +2176,12 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
             {
                 if (PRED)
                     info |= INFO_PRED_BI;
+                if (PRED && req_weighted_bi(cur))
+                {
+                    info |= INFO_PRED_WBI;
+                    wbi[0][lane] = req_bi_weights(cur);
+                    wbi[1][lane] = req_bi_offset(cur);
+                }
                 if (BIDIR && (req_metric(cur) & X265_HIP_MC_AVG))
                     info |= INFO_MCAVG;
                 const PlaneDesc rp1 = planes[req_ref1(cur)];
@@ -2248,11 +2278,24 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                         uint32_t pix1[R][2];
                         ref_strip<NT, true>(r0, rstride, xf, yf, pix);
                         ref_strip<NT, true>(L.ref1[k] + R * ty * rs1 + 4 * tx, rs1, (info >> 15) & 3, (info >> 17) & 3, pix1);
-#pragma unroll
-                        for (int y = 0; y < R; y++)
+                        if (info & INFO_PRED_WBI)
                         {
-                            pix[y][0] = add_avg_pair(pix[y][0], pix1[y][0]);
-                            pix[y][1] = add_avg_pair(pix[y][1], pix1[y][1]);
+                            const int wpack = wbi[0][k], opack = wbi[1][k];
+#pragma unroll
+                            for (int y = 0; y < R; y++)
+                            {
+                                pix[y][0] = weight_bi_pair(pix[y][0], pix1[y][0], wpack, opack);
+                                pix[y][1] = weight_bi_pair(pix[y][1], pix1[y][1], wpack, opack);
+                            }
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int y = 0; y < R; y++)
+                            {
+                                pix[y][0] = add_avg_pair(pix[y][0], pix1[y][0]);
+                                pix[y][1] = add_avg_pair(pix[y][1], pix1[y][1]);
+                            }
                         }
                     }
                     else if (info & INFO_PRED_W)
