@@ -539,8 +539,8 @@ int x265_hip_inter_search_batch_device(x265_hip_ctx *ctx, const void *d_jobs, in
  *   6. the cheapest of list 0, list 1 and both (:2449-2499; the merge candidate's cost is the caller's to compare).
  * BitCost's float table of bit sizes (bitcost.cpp:68-80) is made inside the library the way the reference makes it
  * and lives in device memory beside the cost tables.  What stays with the caller: fillMvpCand, xGetBlkBits' three
- * numbers (they depend on the partition and on the previous unit's mode), lambda, merge estimation, and writing the
- * outcome into the CU. */
+ * numbers (they depend on the partition and on the previous unit's mode), lambda, and writing the outcome into the CU;
+ * merge estimation is x265_hip_merge_estimate_batch below. */
 typedef struct x265_hip_inter_pu
 {
     int32_t first_job;        /* its iterations are jobs first_job .. of the job list: list 0's references 0 .., then list 1's */
@@ -579,6 +579,64 @@ int x265_hip_inter_decide_batch(x265_hip_ctx *ctx, const x265_hip_inter_job *job
                                 int pic_width, int pic_height, x265_hip_inter_result *job_results, x265_hip_inter_pu_result *results);
 int x265_hip_inter_decide_batch_device(x265_hip_ctx *ctx, const void *d_jobs, int njobs, const void *d_pus, int npu, int pic_width,
                                        int pic_height, void *d_job_results, void *d_results, int any_bidir);
+
+/* SATD of a source block against the prediction TComPrediction::motionCompensation makes for it, in every form of a
+ * prediction request (uni- and bi-directional, weighted or not): the request's dst_plane names the SOURCE picture, nothing
+ * is written to it, and costs[i] = satd[partition](source block, prediction) -- what TEncSearch::xMergeEstimation measures
+ * on a merge candidate (source/Lib/TLibEncoder/TEncSearch.cpp:2209-2210: motionCompensation into m_predTempYuv, then
+ * MotionEstimate::bufSATD, encoder/motion.h:79-82). */
+int x265_hip_mc_satd_batch(x265_hip_ctx *ctx, const x265_hip_pred_req *reqs, int n, int32_t *costs);
+int x265_hip_mc_satd_batch_device(x265_hip_ctx *ctx, const void *d_reqs, int n, void *d_costs);
+
+/* TEncSearch::xMergeEstimation for a prediction unit (TEncSearch.cpp:2160-2226), behind
+ * TComDataCU::getInterMergeCandidates (neighbour CU state: the caller's, like fillMvpCand) and the conversion of
+ * bidirectional candidates under isBipredRestriction (:2181-2191, also the caller's: such a candidate is handed over
+ * with ref_plane[1] = -1).  Per candidate in order: passed over if a vector of either list reaches mvy_limit (the frame
+ * threads' guard, :2197-2202); otherwise both vectors through TComDataCU::clipMv, the luma prediction as
+ * motionCompensation(cu, .., REF_PIC_LIST_X, ..) makes it for the slice (TComPrediction.cpp:252-297: a P slice predicts
+ * from list 0, through addWeightUni where the PPS has weighted prediction; a B slice from both lists by luma_addAvg, from
+ * list 0 alone where xCheckIdenticalMotion holds -- the same plane and vector on both lists --, through
+ * xWeightedPredictionBi where the PPS has weighted bi-prediction, or from its one list), SATD against the source block,
+ * + RDCost::getCost(getTUBits(candidate, num_cand)); the first cheapest wins (:2213-2218). */
+#define X265_HIP_MRG_MAX_NUM_CANDS 5
+typedef struct x265_hip_merge_cand /* mvFieldNeighbours[c][0..1] */
+{
+    int32_t ref_plane[2];     /* getRefPic(l, refIdx)->getPicYuvRec() of each list as a plane; < 0: refIdx NOT_VALID */
+    int16_t mv[4];            /* list 0's vector (x, y), list 1's: quarter-pel, as getInterMergeCandidates gave them */
+    int16_t wp_w[2], wp_o[2]; /* weighted slices: inputWeight / inputOffset of each list's reference */
+    uint8_t log2_denom[2];    /* ... and its log2WeightDenom */
+    uint8_t pad[2];
+} x265_hip_merge_cand;
+
+typedef struct x265_hip_merge_pu
+{
+    int32_t fenc_plane; /* the source picture */
+    int16_t pu_x, pu_y;
+    uint8_t pu_w, pu_h;
+    uint8_t num_cand;   /* MergeData::maxNumMergeCand, 1..5 */
+    uint8_t weighted;   /* 0: no weighted prediction in this slice; 1: a P slice of a PPS with getUseWP; 2: a B slice of
+                         * a PPS with getWPBiPred */
+    int16_t cu_x, cu_y; /* getCUPelX / getCUPelY (clipMv) */
+    int16_t mvy_limit;  /* (searchRange + 1) * 4 with frame threads > 1, else 32767 */
+    uint16_t pad;
+    uint32_t lambda_sad; /* RDCost::m_lambdaSAD */
+    x265_hip_merge_cand cand[X265_HIP_MRG_MAX_NUM_CANDS];
+} x265_hip_merge_pu;
+
+typedef struct x265_hip_merge_result
+{
+    uint32_t cost;  /* what xMergeEstimation returns; UINT32_MAX: every candidate was passed over */
+    uint32_t bits;  /* MergeData::bits */
+    uint8_t index;  /* MergeData::index */
+    uint8_t inter_dir; /* MergeData::interDir: 1 list 0, 2 list 1, 3 both (from the candidate's ref_plane[]) */
+    uint8_t pad[2];
+    int32_t satd[X265_HIP_MRG_MAX_NUM_CANDS]; /* the candidates' SATDs (-1: passed over or absent) */
+} x265_hip_merge_result;
+
+/* The `_device` form keeps an internal array of 5 n prediction requests and their costs in device memory, grown on demand. */
+int x265_hip_merge_estimate_batch(x265_hip_ctx *ctx, const x265_hip_merge_pu *pus, int n, int pic_width, int pic_height,
+                                  x265_hip_merge_result *results);
+int x265_hip_merge_estimate_batch_device(x265_hip_ctx *ctx, const void *d_pus, int n, int pic_width, int pic_height, void *d_results);
 
 /* Exhaustive integer-pel search of every square PU (64,32,16,8: 85 per CTU) of the listed 64x64
  * CTUs over [mvmin, mvmax], SAD + mvcost, first minimum in raster order -- the integer stage of

@@ -19,6 +19,7 @@
  *   X265_USE_HIP=1         the primitive table is installed through source/common/hip/hip-primitives.cpp
  *   X265_USE_HIP_ME=1      every MotionEstimate::motionEstimate call, the lookahead's included -> x265_hip_me_batch
  *   X265_USE_HIP_MC=1      the luma block of every TComPrediction::motionCompensation call -> x265_hip_predict_batch
+ *   X265_USE_HIP_MERGE=1   every TEncSearch::xMergeEstimation call is made again by x265_hip_merge_estimate_batch and compared
  *   X265_USE_HIP_PLANES=1  Lowres::init -> x265_hip_lowres_init, MotionReference::applyWeight -> x265_hip_plane_weight
  *   X265_USE_HIP_PLANES=2  ... and every applyWeight call that adds CU rows -> x265_hip_plane_weight_rows for those rows
  *                          (what frame threads > 1 do while the reference picture is still being reconstructed)
@@ -50,6 +51,7 @@
 #include "TLibCommon/TComPic.h"
 #include "TLibCommon/TComDataCU.h"
 #include "TLibEncoder/TEncSearch.h"
+#include "encoder.h"
 #include "rdcost.h"
 #ifdef WITH_HIP
 #include "TLibCommon/TComPrediction.h"
@@ -83,6 +85,12 @@ int wrap_fm(TComDataCU *self, uint32_t partIdx, uint32_t partAddr, int picList, 
 #define PI_SYM "_ZN4x26510TEncSearch15predInterSearchEPNS_10TComDataCUEPNS_7TComYuvEbb"
 bool real_pi(TEncSearch *self, TComDataCU *cu, TComYuv *predYuv, bool bMergeOnly, bool bChroma) asm("__real_" PI_SYM);
 bool wrap_pi(TEncSearch *self, TComDataCU *cu, TComYuv *predYuv, bool bMergeOnly, bool bChroma) asm("__wrap_" PI_SYM);
+
+/* TEncSearch::xMergeEstimation (TEncSearch.cpp:2160-2226) is defined and called in one translation unit, so the linker
+ * cannot intercept it: wrap_pi runs it once more, on the CU as predInterSearch left it, for every prediction unit of a
+ * partition other than 2Nx2N (merge_probe), and writes the candidates getInterMergeCandidates gave it, what it measured
+ * them against and what it chose to merge.bin (with X265_USE_HIP_MERGE=1 in the drop-in build the same record is answered
+ * by x265_hip_merge_estimate_batch and compared). */
 
 #ifdef WITH_HIP
 #define MC_SYM "_ZN4x26514TComPrediction18motionCompensationEPNS_10TComDataCUEPNS_7TComYuvEiibb"
@@ -142,6 +150,29 @@ struct PuRec /* pu.bin: one per prediction unit that searched (read by oracle/ge
 };
 #pragma pack(pop)
 static_assert(sizeof(PuRec) == 80, "layout read by gen_golden.py");
+#pragma pack(push, 1)
+struct MergeCandRec
+{
+    int32_t ref_plane[2]; /* snapshot ids of getRefPic(l, refIdx)->getPicYuvRec(), -1: refIdx NOT_VALID */
+    int16_t mv[4];
+    int16_t wp_w[2], wp_o[2];
+    uint8_t log2_denom[2], pad[2];
+};
+struct MergeRec /* merge.bin: the layout of x265_hip_merge_pu, then what xMergeEstimation returned and left in MergeData */
+{
+    int32_t fenc_plane;
+    int16_t pu_x, pu_y;
+    uint8_t pu_w, pu_h, num_cand, weighted;
+    int16_t cu_x, cu_y, mvy_limit;
+    uint16_t pad;
+    uint32_t lambda_sad;
+    MergeCandRec cand[5];
+    uint32_t out_cost, out_bits;
+    uint8_t out_index, out_dir, cand_dir[5], pad2;
+};
+#pragma pack(pop)
+static_assert(sizeof(MergeRec) == 164 + 16, "layout read by gen_golden.py");
+std::vector<MergeRec> g_merges;
 std::vector<PuRec> g_pus;
 struct PuCall
 {
@@ -906,12 +937,131 @@ int wrap_me(MotionEstimate *self, ReferencePlanes *ref, const MV &mvmin, const M
     return cost;
 }
 
+#ifdef WITH_HIP
+namespace {
+bool g_hip_merge = false;
+long g_mg_calls = 0, g_mg_mismatch = 0, g_mg_bi = 0, g_mg_weighted = 0;
+}
+#endif
+
+static void merge_probe(TEncSearch *self, TComDataCU *cu, int puIdx)
+{
+    bool record = false;
+#ifdef WITH_HIP
+    const bool answer = g_hip_merge;
+#else
+    const bool answer = false;
+#endif
+    {
+        std::lock_guard<std::mutex> g(g_mu);
+        /* recorded while the full-resolution motionEstimate calls are (the same pictures, so the same planes) */
+        if (!answer && g_seen_full >= g_first_full && g_n_full > 0 && g_n_full < g_max_full)
+            record = true;
+    }
+    if (!record && !answer)
+        return;
+    /* the call as predInterSearch makes it (TEncSearch.cpp:2256-2269); it leaves each candidate's motion in the CU's
+     * fields at the unit's first entry (:2204-2207), which is put back */
+    uint32_t partAddr;
+    int w, h;
+    cu->getPartIndexAndSize(puIdx, partAddr, w, h);
+    MV keep_mv[2];
+    char keep_ref[2];
+    for (int l = 0; l < 2; l++)
+    {
+        keep_mv[l] = cu->getCUMvField(l)->m_mv[partAddr];
+        keep_ref[l] = cu->getCUMvField(l)->m_refIdx[partAddr];
+    }
+    {
+        TComPicYuv *src = cu->getSlice()->getPic()->getPicYuvOrg();
+        self->m_me.setSourcePU((int)(src->getLumaAddr(cu->getAddr(), cu->getZorderIdxInCU() + partAddr) - src->getLumaAddr()), w, h);
+    }
+    MergeData m;
+    m.absPartIdx = partAddr;
+    m.width = w;
+    m.height = h;
+    const uint32_t cost = self->xMergeEstimation(cu, puIdx, m);
+    for (int l = 0; l < 2; l++)
+    {
+        cu->getCUMvField(l)->m_mv[partAddr] = keep_mv[l];
+        cu->getCUMvField(l)->m_refIdx[partAddr] = keep_ref[l];
+    }
+    std::lock_guard<std::mutex> g(g_mu);
+    TComSlice *slice = cu->getSlice();
+    TComPicYuv *fenc = slice->getPic()->getPicYuvOrg();
+    const int stride = fenc->getStride(), rows = (g_height + 63) / 64 * 64;
+    const intptr_t off = fenc->getLumaAddr(cu->getAddr(), cu->getZorderIdxInCU() + m.absPartIdx) - fenc->getLumaAddr();
+    MergeRec r;
+    memset(&r, 0, sizeof(r));
+    auto plane_of = [&](const pixel *origin, int st) {
+#ifdef WITH_HIP
+        if (answer)
+            return device_plane(origin, st, rows);
+#endif
+        return snapshot(origin, st, rows);
+    };
+    r.fenc_plane = plane_of(fenc->getLumaAddr(), stride);
+    r.pu_x = (int16_t)(off % stride), r.pu_y = (int16_t)(off / stride);
+    r.pu_w = (uint8_t)m.width, r.pu_h = (uint8_t)m.height;
+    r.num_cand = (uint8_t)m.maxNumMergeCand;
+    r.weighted = slice->isInterP() ? (slice->getPPS()->getUseWP() ? 1 : 0) : (slice->getPPS()->getWPBiPred() ? 2 : 0);
+    r.cu_x = (int16_t)cu->getCUPelX(), r.cu_y = (int16_t)cu->getCUPelY();
+    r.mvy_limit = self->m_cfg->m_totalFrameThreads > 1 ? (int16_t)((self->m_cfg->m_param->searchRange + 1) * 4) : 32767;
+    r.lambda_sad = (uint32_t)self->m_rdCost->m_lambdaSAD;
+    for (uint32_t c = 0; c < m.maxNumMergeCand && c < 5; c++)
+    {
+        r.cand_dir[c] = m.interDirNeighbours[c];
+        for (int l = 0; l < 2; l++)
+        {
+            const TComMvField &f = m.mvFieldNeighbours[c][l];
+            r.cand[c].mv[2 * l] = f.mv.x, r.cand[c].mv[2 * l + 1] = f.mv.y;
+            r.cand[c].ref_plane[l] = -1;
+            if (f.refIdx >= 0 && !(l == 1 && slice->isInterP()))
+            {
+                TComPicYuv *rp = slice->getRefPic(l, f.refIdx)->getPicYuvRec();
+                r.cand[c].ref_plane[l] = plane_of(rp->getLumaAddr(), rp->getStride());
+                wpScalingParam *wp;
+                slice->getWpScaling(l, f.refIdx, wp);
+                r.cand[c].wp_w[l] = (int16_t)wp[0].inputWeight, r.cand[c].wp_o[l] = (int16_t)wp[0].inputOffset;
+                r.cand[c].log2_denom[l] = (uint8_t)wp[0].log2WeightDenom;
+            }
+        }
+    }
+    r.out_cost = cost, r.out_bits = m.bits;
+    r.out_index = (uint8_t)m.index, r.out_dir = (uint8_t)m.interDir;
+#ifdef WITH_HIP
+    if (answer)
+    {
+        static_assert(sizeof(x265_hip_merge_pu) == 164, "MergeRec starts with an x265_hip_merge_pu");
+        x265_hip_merge_pu pu;
+        memcpy(&pu, &r, sizeof(pu));
+        x265_hip_merge_result out;
+        if (x265_hip_merge_estimate_batch(g_ctx, &pu, 1, g_width, g_height, &out) != X265_HIP_OK)
+        {
+            fprintf(stderr, "merge_estimate_batch: %s\n", x265_hip_last_error());
+            abort();
+        }
+        g_mg_calls++;
+        g_mg_weighted += r.weighted != 0;
+        if (cost != 0xFFFFFFFFu)
+            g_mg_bi += m.interDir == 3;
+        if (out.cost != cost || (cost != 0xFFFFFFFFu && (out.bits != m.bits || out.index != m.index || out.inter_dir != m.interDir)))
+            g_mg_mismatch++;
+        return;
+    }
+#endif
+    g_merges.push_back(r);
+}
+
 bool wrap_pi(TEncSearch *self, TComDataCU *cu, TComYuv *predYuv, bool bMergeOnly, bool bChroma)
 {
     t_pu_active = true;
     t_pu_calls.clear();
     const bool ok = real_pi(self, cu, predYuv, bMergeOnly, bChroma);
     t_pu_active = false;
+    if (cu->getPartitionSize(0) != SIZE_2Nx2N)
+        for (int part = 0; part < cu->getNumPartInter(); part++)
+            merge_probe(self, cu, part);
     if (t_pu_calls.empty())
         return ok;
     const PartSize partSize = cu->getPartitionSize(0);
@@ -1065,6 +1215,8 @@ int main(int argc, char **argv)
     p->logLevel = X265_LOG_WARNING;
     if (getenv("X265_CAPTURE_WEIGHTB")) /* --weightb: weighted prediction in B slices (param.cpp:610) */
         p->bEnableWeightedBiPred = 1;
+    if (getenv("X265_CAPTURE_RECT")) /* --rect --amp (param.cpp:562-563): partitions other than 2Nx2N, so xMergeEstimation runs */
+        p->bEnableRectInter = p->bEnableAMP = 1;
     x265_encoder *enc = x265_encoder_open(p);
     if (!enc)
     {
@@ -1106,6 +1258,16 @@ int main(int argc, char **argv)
         }
         g_hip_mc = g_hip_sparse = true;
         fprintf(stderr, "enc_capture: motionCompensation (luma) answered by x265_hip_predict_batch\n");
+    }
+    if (getenv("X265_USE_HIP_MERGE"))
+    {
+        if (!g_ctx && x265_hip_ctx_create(0, &g_ctx) != X265_HIP_OK)
+        {
+            fprintf(stderr, "x265_hip_ctx_create: %s\n", x265_hip_last_error());
+            return 1;
+        }
+        g_hip_merge = g_hip_sparse = true;
+        fprintf(stderr, "enc_capture: xMergeEstimation answered again by x265_hip_merge_estimate_batch\n");
     }
     if (getenv("X265_USE_HIP_LOOKAHEAD"))
     {
@@ -1194,6 +1356,9 @@ int main(int argc, char **argv)
     out = fopen((dir + "/amvp.bin").c_str(), "wb");
     fwrite(g_amvp.data(), sizeof(AmvpRec), g_amvp.size(), out);
     fclose(out);
+    out = fopen((dir + "/merge.bin").c_str(), "wb");
+    fwrite(g_merges.data(), sizeof(MergeRec), g_merges.size(), out);
+    fclose(out);
     out = fopen((dir + "/pu.bin").c_str(), "wb");
     fwrite(g_pus.data(), sizeof(PuRec), g_pus.size(), out);
     fclose(out);
@@ -1209,6 +1374,9 @@ int main(int argc, char **argv)
     if (g_hip_mc)
         fprintf(stderr, "enc_capture: %ld motionCompensation luma blocks predicted on the GPU (%ld weighted, %ld bi-directional), %ld differed from the reference's own pixels; %ld of the bi-directional ones weighted\n",
                 g_mc_calls, g_mc_weighted, g_mc_bi, g_mc_mismatch, g_mc_wbi);
+    if (g_hip_merge)
+        fprintf(stderr, "enc_capture: %ld xMergeEstimation calls answered on the GPU (%ld in weighted slices, %ld chose a bi-directional candidate), %ld differed\n",
+                g_mg_calls, g_mg_weighted, g_mg_bi, g_mg_mismatch);
     if (g_hip_look)
     {
         fprintf(stderr, "enc_capture: %ld lookahead frame searches asked for, %ld launches of x265_hip_lookahead_batch in %.3f s (%.3f ms each, upload and download included), %ld lowres motionEstimate calls answered from them, %ld differed from the reference's own answer%s\n",

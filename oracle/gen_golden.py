@@ -12,6 +12,7 @@ been run.  The fixtures hold inputs and the reference's outputs (data, no refere
               motionEstimate call records against them (ref->isLowres)
   encoder_pu.npz  the prediction units of a reference encoder run: their iterations, xGetBlkBits / lambda, and what
               predInterSearch left in the CU (direction, vectors, AMVP indices) -- see gen_encoder_pu
+  encoder_merge.npz  xMergeEstimation calls of a reference encoder run with rectangular partitions -- see gen_encoder_merge
   wpbi.npz    weighted bi-prediction (xWeightedPredictionBi) of random intermediates -- see gen_wpbi
   me.npz      motionEstimate call records (inputs) and (cost, qmv) results on a small synthetic
               sequence for every search method and sub-pel level, plus two per-CTU full searches
@@ -310,6 +311,11 @@ CAPTURE_PU = np.dtype([("call", "<i4", (8,)), ("call_list", "u1", (8,)), ("call_
 assert CAPTURE_PU.itemsize == 80  # PuRec of oracle/enc_capture.cpp
 
 
+CAPTURE_MERGE = np.dtype([("pu", pyoracle.MERGE_PU), ("out_cost", "<u4"), ("out_bits", "<u4"), ("out_index", "u1"), ("out_dir", "u1"),
+                          ("cand_dir", "u1", (5,)), ("pad2", "u1")])
+assert CAPTURE_MERGE.itemsize == 180  # MergeRec of oracle/enc_capture.cpp
+
+
 def gen_encoder_pu():
     """What predInterSearch left in the CU for every prediction unit (oracle/enc_capture.cpp, pu.bin): the same encoder
     run as gen_encoder with the first 3600 full-resolution calls kept -- the first P picture and the B pictures behind
@@ -369,6 +375,53 @@ def gen_encoder_pu():
         len(pus), int((pus["is_p"] == 0).sum()), int((pus["inter_dir"] == 3).sum()), len(order), len(planes)))
 
 
+def gen_encoder_merge():
+    """TEncSearch::xMergeEstimation inside the reference encoder (oracle/enc_capture.cpp, merge.bin): rectangular and
+    asymmetric partitions switched on (--rect --amp; the medium preset has neither, so it never estimates a merge), a
+    208x128 clip that fades (weighted P slices) and --weightb (weighted B slices).  Per call: the candidates
+    getInterMergeCandidates produced as an x265_hip_merge_pu record, and the cost / bits / index / direction the
+    reference chose.  Kept: the calls made while the first 1500 motionEstimate calls were, with the planes they read."""
+    import subprocess
+    cap = os.path.join(HERE, "_ref", "capture_merge")
+    exe = os.path.join(HERE, "_ref", "enc_capture")
+    os.makedirs(cap, exist_ok=True)
+    W, H, N = 208, 128, 24
+    seq = synth.Sequence(W, H, seed=11, n_patches=2)
+    with open(os.path.join(cap, "in.yuv"), "wb") as f:
+        for i in range(N):
+            f.write(np.clip(seq.frame(i) * (1.0 - 0.03 * i) + 0.5, 0, 255).astype(np.uint8).tobytes())
+            f.write(bytes([128]) * (W * H // 2))
+    env = dict(os.environ, X265_CAPTURE_RECT="1", X265_CAPTURE_WEIGHTB="1")
+    subprocess.check_call([exe, os.path.join(cap, "in.yuv"), str(W), str(H), str(N), cap, "1500", "0"], env=env)
+    os.remove(os.path.join(cap, "in.yuv"))
+    mg = np.fromfile(os.path.join(cap, "merge.bin"), dtype=CAPTURE_MERGE)
+    raw = open(os.path.join(cap, "planes.bin"), "rb").read()
+    planes, pos = [], 0
+    while pos < len(raw):
+        pid, stride, origin, nbytes = (int(v) for v in np.frombuffer(raw, dtype="<i4", count=4, offset=pos))
+        planes.append((np.frombuffer(raw, dtype=np.uint8, count=nbytes, offset=pos + 16).copy(), origin, stride))
+        pos += 16 + nbytes
+    # only the planes the merge records name (the motionEstimate calls' weighted reference planes are not among them)
+    used = sorted((set(mg["pu"]["fenc_plane"].tolist()) | set(mg["pu"]["cand"]["ref_plane"].reshape(-1).tolist())) - {-1})
+    remap = np.full(len(planes) + 1, -1, np.int32)
+    remap[used] = np.arange(len(used))
+    pu = mg["pu"].copy()
+    pu["fenc_plane"] = remap[pu["fenc_plane"]]
+    pu["cand"]["ref_plane"] = remap[pu["cand"]["ref_plane"]]  # (-1 indexes the spare last entry: stays -1)
+    for m_ in mg:  # interDirNeighbours agrees with the references the candidates carry (list 1 is dropped in a P slice)
+        for c in range(int(m_["pu"]["num_cand"])):
+            have = m_["pu"]["cand"][c]["ref_plane"] >= 0
+            assert int(m_["cand_dir"][c]) == int(have[0]) | 2 * int(have[1]), (m_["cand_dir"], m_["pu"]["cand"]["ref_plane"])
+    planes = [planes[i] for i in used]
+    geo = np.array([(len(b), o, s) for (b, o, s) in planes], np.int32)
+    mout = np.zeros(len(mg), np.dtype([("cost", "<u4"), ("bits", "<u4"), ("index", "u1"), ("inter_dir", "u1")]))
+    mout["cost"], mout["bits"], mout["index"], mout["inter_dir"] = mg["out_cost"], mg["out_bits"], mg["out_index"], mg["out_dir"]
+    np.savez_compressed(os.path.join(OUT, "encoder_merge.npz"), merge_pus=pu, merge_out=mout, plane_geo=geo,
+                        plane_bytes=np.concatenate([b for (b, _, _) in planes]), pic_size=np.array([W, H], np.int32))
+    print("encoder_merge: %d merge estimations (%d in weighted P slices, %d in weighted B slices, %d chose a bi-directional candidate), %d planes" % (
+        len(mg), int((pu["weighted"] == 1).sum()), int((pu["weighted"] == 2).sum()), int((mout["inter_dir"] == 3).sum()), len(planes)))
+
+
 def main():
     if not pyoracle.have_ref():
         sys.exit("oracle/_ref/libx265ref.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -383,6 +436,7 @@ def main():
     gen_wpbi()
     gen_encoder()
     gen_encoder_pu()
+    gen_encoder_merge()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
@@ -392,6 +446,8 @@ if __name__ == "__main__":
         gen_encoder()
     elif len(sys.argv) > 1 and sys.argv[1] == "encoder_pu":
         gen_encoder_pu()
+    elif len(sys.argv) > 1 and sys.argv[1] == "encoder_merge":
+        gen_encoder_merge()
     elif len(sys.argv) > 1 and sys.argv[1] == "wpbi":
         gen_wpbi()
     elif len(sys.argv) > 1 and sys.argv[1] == "pred":

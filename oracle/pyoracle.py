@@ -57,6 +57,19 @@ PRED_REQ = np.dtype([
 ])
 assert PRED_REQ.itemsize == 36
 
+# x265_hip_merge_pu / x265_hip_merge_result: TEncSearch::xMergeEstimation of a prediction unit
+MRG_MAX_NUM_CANDS = 5
+MERGE_CAND = np.dtype([("ref_plane", "<i4", (2,)), ("mv", "<i2", (4,)), ("wp_w", "<i2", (2,)), ("wp_o", "<i2", (2,)),
+                       ("log2_denom", "u1", (2,)), ("pad", "u1", (2,))])
+assert MERGE_CAND.itemsize == 28
+MERGE_PU = np.dtype([("fenc_plane", "<i4"), ("pu_x", "<i2"), ("pu_y", "<i2"), ("pu_w", "u1"), ("pu_h", "u1"), ("num_cand", "u1"),
+                     ("weighted", "u1"), ("cu_x", "<i2"), ("cu_y", "<i2"), ("mvy_limit", "<i2"), ("pad", "<u2"), ("lambda_sad", "<u4"),
+                     ("cand", MERGE_CAND, (MRG_MAX_NUM_CANDS,))])
+assert MERGE_PU.itemsize == 164
+MERGE_RESULT = np.dtype([("cost", "<u4"), ("bits", "<u4"), ("index", "u1"), ("inter_dir", "u1"), ("pad", "u1", (2,)),
+                         ("satd", "<i4", (MRG_MAX_NUM_CANDS,))])
+assert MERGE_RESULT.itemsize == 32
+
 
 INTER_JOB = np.dtype([
     ("fenc_plane", "<i4"), ("ref_plane", "<i4"), ("pred_plane", "<i4"),
@@ -352,6 +365,19 @@ class Checker:
     def luma_addavg(self, part, src0, o0, src1, o1, dst, doff, sstride0, sstride1, dstride):
         self._f("luma_addavg")(C.c_int(part), _ptr(src0, 2 * o0), _ptr(src1, 2 * o1), _ptr(dst, doff), C.c_ssize_t(sstride0),
                                C.c_ssize_t(sstride1), C.c_ssize_t(dstride))
+
+    def mc_satd_batch(self, planes, reqs):
+        """satd of the block of plane reqs.dst_plane (the source picture) against the prediction of each request"""
+        reqs = np.ascontiguousarray(reqs, dtype=PRED_REQ)
+        out = np.zeros(len(reqs), np.int32)
+        self._f("mc_satd_batch")(self._planes(planes), _ptr(reqs), C.c_int(len(reqs)), _ptr(out))
+        return out
+
+    def merge_estimate_batch(self, planes, pus, pic_width, pic_height):
+        pus = np.ascontiguousarray(pus, dtype=MERGE_PU)
+        out = np.zeros(len(pus), MERGE_RESULT)
+        self._f("merge_estimate_batch")(self._planes(planes), _ptr(pus), C.c_int(len(pus)), C.c_int(pic_width), C.c_int(pic_height), _ptr(out))
+        return out
 
     def add_weight_bi(self, src0, src1, width, height, w0, o0, w1, o1, log2_denom):
         """xWeightedPredictionBi's luma block from the two lists' intermediates (64x64 int16 arrays): 64x64 uint8, zero

@@ -1300,42 +1300,155 @@ void x265o_add_weight_bi(const int16_t *src0, const int16_t *src1, uint8_t *dst,
  * uni-directional prediction: motionCompensation's getUseWP branch, TComPrediction.cpp:265-279, with
  * TComWeightPrediction::addWeightUni, TComWeightPrediction.cpp:433-458; weighted bi-prediction: xPredInterBi's
  * getWPBiPred branch, TComPrediction.cpp:347-350, with xWeightedPredictionBi, TComWeightPrediction.cpp:609-618 */
+static void predict_one(const x265o_plane *planes, const x265o_pred_req *r, uint8_t *dst, intptr_t dstride)
+{
+    const x265o_plane *a = &planes[r->ref0_plane];
+    int part = x265o_partition_from_sizes(r->pu_w, r->pu_h);
+    uint8_t tmp[64 * 64];
+    if (r->ref1_plane == X265O_PRED_WEIGHTED)
+    {
+        int16_t s0[64 * 64];
+        int shift = r->log2_denom + 6; /* IF_INTERNAL_PREC - X265_DEPTH */
+        predict_luma_short(part, r->pu_w, r->pu_h, a->origin + r->pu_x + (intptr_t)r->pu_y * a->stride, a->stride, r->qmv0_x,
+                           r->qmv0_y, s0);
+        x265o_weight_sp(s0, dst, 64, dstride, r->pu_w, r->pu_h, r->qmv1_x, 1 << (shift - 1), shift, r->qmv1_y);
+    }
+    else if (r->ref1_plane < 0)
+    {
+        predict_luma(part, r->pu_w, a->origin + r->pu_x + (intptr_t)r->pu_y * a->stride, a->stride, r->qmv0_x, r->qmv0_y, tmp);
+        for (int y = 0; y < r->pu_h; y++)
+            memcpy(dst + y * dstride, tmp + y * 64, r->pu_w);
+    }
+    else
+    {
+        const x265o_plane *b = &planes[r->ref1_plane];
+        int16_t s0[64 * 64], s1[64 * 64];
+        predict_luma_short(part, r->pu_w, r->pu_h, a->origin + r->pu_x + (intptr_t)r->pu_y * a->stride, a->stride, r->qmv0_x,
+                           r->qmv0_y, s0);
+        predict_luma_short(part, r->pu_w, r->pu_h, b->origin + r->pu_x + (intptr_t)r->pu_y * b->stride, b->stride, r->qmv1_x,
+                           r->qmv1_y, s1);
+        if (r->weighted_bi)
+            x265o_add_weight_bi(s0, s1, dst, 64, 64, dstride, r->pu_w, r->pu_h, r->wp_w0, r->wp_o0, r->wp_w1, r->wp_o1, r->log2_denom);
+        else
+            x265o_luma_addavg(part, s0, s1, dst, 64, 64, dstride);
+    }
+}
+
 void x265o_predict_batch(const x265o_plane *planes, const x265o_pred_req *reqs, int n)
 {
     for (int i = 0; i < n; i++)
     {
+        const x265o_plane *d = &planes[reqs[i].dst_plane];
+        predict_one(planes, &reqs[i], (uint8_t *)d->origin + reqs[i].pu_x + (intptr_t)reqs[i].pu_y * d->stride, d->stride);
+    }
+}
+
+/* ref: what TEncSearch::xMergeEstimation measures on a candidate, TEncSearch.cpp:2209-2210: motionCompensation into a
+ * temporary block, then MotionEstimate::bufSATD (motion.h:79-82: satd[partEnum] against the source PU).  dst_plane of
+ * the request names the source picture. */
+void x265o_mc_satd_batch(const x265o_plane *planes, const x265o_pred_req *reqs, int n, int32_t *out)
+{
+    for (int i = 0; i < n; i++)
+    {
         const x265o_pred_req *r = &reqs[i];
-        const x265o_plane *d = &planes[r->dst_plane], *a = &planes[r->ref0_plane];
-        int part = x265o_partition_from_sizes(r->pu_w, r->pu_h);
-        uint8_t *dst = (uint8_t *)d->origin + r->pu_x + (intptr_t)r->pu_y * d->stride;
-        uint8_t tmp[64 * 64];
-        if (r->ref1_plane == X265O_PRED_WEIGHTED)
+        const x265o_plane *f = &planes[r->dst_plane];
+        uint8_t pred[64 * 64];
+        predict_one(planes, r, pred, 64);
+        out[i] = x265o_satd(x265o_partition_from_sizes(r->pu_w, r->pu_h), f->origin + r->pu_x + (intptr_t)r->pu_y * f->stride, f->stride,
+                            pred, 64);
+    }
+}
+
+static void clip_mv(int *qx, int *qy, int cu_x, int cu_y, int pic_w, int pic_h);
+
+/* ref: TEncSearch::xMergeEstimation, Lib/TLibEncoder/TEncSearch.cpp:2160-2226, behind getInterMergeCandidates and the
+ * conversion under isBipredRestriction (the caller's).  Per candidate (:2194-2219): the frame threads' guard on mv.y, the
+ * candidate's motion written into the CU and predicted by motionCompensation(cu, .., REF_PIC_LIST_X, ..)
+ * (TComPrediction.cpp:252-297), bufSATD, getTUBits (TEncSearch.h:94-97), RDCost::getCost (rdcost.h:112-115), first
+ * minimum. */
+void x265o_merge_estimate_batch(const x265o_plane *planes, const x265o_merge_pu *pus, int n, int pic_w, int pic_h,
+                                x265o_merge_result *out)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const x265o_merge_pu *p = &pus[i];
+        x265o_merge_result *o = &out[i];
+        memset(o, 0, sizeof(*o));
+        o->cost = UINT32_MAX;
+        for (int c = 0; c < X265O_MRG_MAX_NUM_CANDS; c++)
+            o->satd[c] = -1;
+        for (int c = 0; c < p->num_cand; c++)
         {
-            int16_t s0[64 * 64];
-            int shift = r->log2_denom + 6; /* IF_INTERNAL_PREC - X265_DEPTH */
-            predict_luma_short(part, r->pu_w, r->pu_h, a->origin + r->pu_x + (intptr_t)r->pu_y * a->stride, a->stride, r->qmv0_x,
-                               r->qmv0_y, s0);
-            x265o_weight_sp(s0, dst, 64, d->stride, r->pu_w, r->pu_h, r->qmv1_x, 1 << (shift - 1), shift, r->qmv1_y);
-        }
-        else if (r->ref1_plane < 0)
-        {
-            predict_luma(part, r->pu_w, a->origin + r->pu_x + (intptr_t)r->pu_y * a->stride, a->stride, r->qmv0_x, r->qmv0_y, tmp);
-            for (int y = 0; y < r->pu_h; y++)
-                memcpy(dst + y * d->stride, tmp + y * 64, r->pu_w);
-        }
-        else
-        {
-            const x265o_plane *b = &planes[r->ref1_plane];
-            int16_t s0[64 * 64], s1[64 * 64];
-            predict_luma_short(part, r->pu_w, r->pu_h, a->origin + r->pu_x + (intptr_t)r->pu_y * a->stride, a->stride, r->qmv0_x,
-                               r->qmv0_y, s0);
-            predict_luma_short(part, r->pu_w, r->pu_h, b->origin + r->pu_x + (intptr_t)r->pu_y * b->stride, b->stride, r->qmv1_x,
-                               r->qmv1_y, s1);
-            if (r->weighted_bi)
-                x265o_add_weight_bi(s0, s1, dst, 64, 64, d->stride, r->pu_w, r->pu_h, r->wp_w0, r->wp_o0, r->wp_w1, r->wp_o1,
-                                    r->log2_denom);
+            const x265o_merge_cand *m = &p->cand[c];
+            if (m->mv[1] >= p->mvy_limit || m->mv[3] >= p->mvy_limit) /* :2197-2202 */
+                continue;
+            int ref[2] = { m->ref_plane[0], m->ref_plane[1] }; /* refIdx >= 0 <=> a plane */
+            int mv[2][2] = { { m->mv[0], m->mv[1] }, { m->mv[2], m->mv[3] } };
+            x265o_pred_req r;
+            memset(&r, 0, sizeof(r));
+            r.dst_plane = p->fenc_plane;
+            r.pu_x = p->pu_x, r.pu_y = p->pu_y, r.pu_w = p->pu_w, r.pu_h = p->pu_h;
+            r.ref1_plane = -1;
+            int lists[2], nl = 0; /* the lists motionCompensation predicts from */
+            int weighted_uni = 0;
+            if (p->weighted == 1)
+            {
+                /* a P slice: list = REF_PIC_LIST_0 (:261-262), through the intermediate and addWeightUni (:265-279) */
+                if (ref[0] < 0)
+                    continue;
+                lists[nl++] = 0;
+                weighted_uni = 1;
+            }
+            else if (ref[0] >= 0 && ref[1] >= 0)
+            {
+                /* xCheckIdenticalMotion (:232-250): the same picture and vector on both lists, never with weighted
+                 * bi-prediction -> xPredInterUni of list 0 (:287-290) */
+                int same = p->weighted != 2 && ref[0] == ref[1] && mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1];
+                lists[nl++] = 0;
+                if (!same)
+                    lists[nl++] = 1;
+            }
+            else if (ref[0] >= 0 || ref[1] >= 0)
+            {
+                /* xPredInterBi with one list (:356-386): weighted where the PPS has weighted bi-prediction */
+                lists[nl++] = ref[0] >= 0 ? 0 : 1;
+                weighted_uni = p->weighted == 2;
+            }
             else
-                x265o_luma_addavg(part, s0, s1, dst, 64, 64, d->stride);
+                continue;
+            for (int l = 0; l < 2; l++)
+                clip_mv(&mv[l][0], &mv[l][1], p->cu_x, p->cu_y, pic_w, pic_h); /* xPredInterUni :305-306, :321-322 */
+            r.ref0_plane = ref[lists[0]];
+            r.qmv0_x = (int16_t)mv[lists[0]][0], r.qmv0_y = (int16_t)mv[lists[0]][1];
+            if (nl == 2)
+            {
+                r.ref1_plane = ref[1];
+                r.qmv1_x = (int16_t)mv[1][0], r.qmv1_y = (int16_t)mv[1][1];
+                if (p->weighted == 2) /* xWeightedPredictionBi, :347-350 */
+                {
+                    r.weighted_bi = 1;
+                    r.wp_w0 = m->wp_w[0], r.wp_o0 = m->wp_o[0], r.wp_w1 = m->wp_w[1], r.wp_o1 = m->wp_o[1];
+                    r.log2_denom = m->log2_denom[0];
+                }
+            }
+            else if (weighted_uni)
+            {
+                r.ref1_plane = X265O_PRED_WEIGHTED;
+                r.qmv1_x = m->wp_w[lists[0]], r.qmv1_y = m->wp_o[lists[0]];
+                r.log2_denom = m->log2_denom[lists[0]];
+            }
+            int32_t satd;
+            x265o_mc_satd_batch(planes, &r, 1, &satd);
+            uint32_t bits = (uint32_t)(c + (c < p->num_cand - 1));
+            uint32_t cost = (uint32_t)satd + (uint32_t)((bits * p->lambda_sad + 128) >> 8);
+            o->satd[c] = satd;
+            if (cost < o->cost)
+            {
+                o->cost = cost;
+                o->bits = bits;
+                o->index = (uint8_t)c;
+                o->inter_dir = (uint8_t)((ref[0] >= 0 ? 1 : 0) | (ref[1] >= 0 ? 2 : 0));
+            }
         }
     }
 }

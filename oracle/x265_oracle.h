@@ -229,6 +229,36 @@ void x265o_weight_sp(const int16_t *src, uint8_t *dst, intptr_t sstride, intptr_
 void x265o_add_weight_bi(const int16_t *src0, const int16_t *src1, uint8_t *dst, intptr_t sstride0, intptr_t sstride1,
                          intptr_t dstride, int width, int height, int w0, int o0, int w1, int o1, int log2_denom);
 void x265o_predict_batch(const x265o_plane *planes, const x265o_pred_req *reqs, int n);
+void x265o_mc_satd_batch(const x265o_plane *planes, const x265o_pred_req *reqs, int n, int32_t *out);
+
+/* TEncSearch::xMergeEstimation (TEncSearch.cpp:2160-2226): same layout as x265_hip_merge_pu / _result */
+#define X265O_MRG_MAX_NUM_CANDS 5
+typedef struct x265o_merge_cand
+{
+    int32_t ref_plane[2];
+    int16_t mv[4];
+    int16_t wp_w[2], wp_o[2];
+    uint8_t log2_denom[2];
+    uint8_t pad[2];
+} x265o_merge_cand;
+typedef struct x265o_merge_pu
+{
+    int32_t fenc_plane;
+    int16_t pu_x, pu_y;
+    uint8_t pu_w, pu_h, num_cand, weighted;
+    int16_t cu_x, cu_y, mvy_limit;
+    uint16_t pad;
+    uint32_t lambda_sad;
+    x265o_merge_cand cand[X265O_MRG_MAX_NUM_CANDS];
+} x265o_merge_pu;
+typedef struct x265o_merge_result
+{
+    uint32_t cost, bits;
+    uint8_t index, inter_dir, pad[2];
+    int32_t satd[X265O_MRG_MAX_NUM_CANDS];
+} x265o_merge_result;
+void x265o_merge_estimate_batch(const x265o_plane *planes, const x265o_merge_pu *pus, int n, int pic_w, int pic_h,
+                                x265o_merge_result *out);
 
 /* lookahead planes: frame_init_lowres_core (pixel.cpp:595-618) and extendPicBorder (pixel.cpp:893-911) */
 void x265o_frame_init_lowres(const uint8_t *src0, uint8_t *dst0, uint8_t *dsth, uint8_t *dstv, uint8_t *dstc,

@@ -234,3 +234,38 @@ def wpbi_fixture():
         out.append(([int(x) for x in hd], src, dst))
     return out
 
+
+def random_merge_pus(rng, n, W, H, dtype, parts, fenc_plane=1, refs=(0, 2)):
+    """prediction units with merge candidates of every kind xMergeEstimation meets: one list or both, the same plane and
+    vector on both lists (xCheckIdenticalMotion), slices without / with weighted prediction (P) / with weighted
+    bi-prediction (B), vectors past the picture edge (clipMv), candidates at the frame threads' limit (passed over), one
+    to five candidates"""
+    pus = np.zeros(n, dtype)
+    for p in pus:
+        w, h = parts[int(rng.integers(1, 25))]  # (no 4x4 inter partition)
+        cu = 8
+        while cu < max(w, h):
+            cu *= 2
+        p["fenc_plane"] = fenc_plane
+        p["pu_w"], p["pu_h"] = w, h
+        # the unit is the first or the second partition of a CU on the CU grid (clipMv keeps the block within reach of the
+        # padding only for a unit inside its CU)
+        p["cu_x"], p["cu_y"] = cu * int(rng.integers(0, W // cu)), cu * int(rng.integers(0, H // cu))
+        p["pu_x"], p["pu_y"] = int(p["cu_x"]) + (cu - w) * int(rng.integers(0, 2)), int(p["cu_y"]) + (cu - h) * int(rng.integers(0, 2))
+        p["num_cand"] = int(rng.integers(1, 6))
+        p["weighted"] = int(rng.integers(0, 3))
+        p["mvy_limit"] = 32767 if rng.integers(3) else 4 * 58
+        p["lambda_sad"] = int(rng.integers(200, 12000))
+        for c in p["cand"][:int(p["num_cand"])]:
+            kind = int(rng.integers(0, 4)) if p["weighted"] != 1 else 0  # 0 list 0, 1 list 1, 2 both, 3 identical
+            far = rng.integers(8) == 0
+            for l in range(2):
+                c["mv"][2 * l] = int(rng.integers(-4 * W, 4 * W)) if far else int(rng.integers(-120, 120))
+                c["mv"][2 * l + 1] = int(rng.integers(-4 * H, 4 * H)) if far else int(rng.integers(-120, 260 if p["mvy_limit"] < 32767 else 120))
+                c["wp_w"][l], c["wp_o"][l] = int(rng.integers(-128, 256)) if rng.integers(4) == 0 else int(rng.integers(20, 90)), int(rng.integers(-30, 30))
+                c["log2_denom"][l] = int(rng.integers(0, 8))
+            c["ref_plane"] = [int(rng.choice(refs)) if kind in (0, 2, 3) else -1, int(rng.choice(refs)) if kind in (1, 2, 3) else -1]
+            if kind == 3:
+                c["ref_plane"][1] = c["ref_plane"][0]
+                c["mv"][2:] = c["mv"][:2]
+    return pus

@@ -125,13 +125,14 @@ def test_python_struct_layouts_match_the_header(tmp_path):
     if not cc:
         pytest.skip("no C compiler")
     src = tmp_path / "sizes.c"
-    src.write_text('#include <stdio.h>\n#include "x265_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", '
+    src.write_text('#include <stdio.h>\n#include "x265_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", '
                    'sizeof(x265_hip_primitives), sizeof(x265_hip_me_job), sizeof(x265_hip_me_result), sizeof(x265_hip_cost_req), '
-                   'sizeof(x265_hip_bidir_req), sizeof(x265_hip_pred_req), sizeof(x265_hip_ctu_job), sizeof(x265_hip_refine_req), sizeof(x265_hip_inter_job), sizeof(x265_hip_inter_result), sizeof(x265_hip_lookahead_job), sizeof(x265_hip_refine_section)); return 0; }\n')
+                   'sizeof(x265_hip_bidir_req), sizeof(x265_hip_pred_req), sizeof(x265_hip_ctu_job), sizeof(x265_hip_refine_req), sizeof(x265_hip_inter_job), sizeof(x265_hip_inter_result), sizeof(x265_hip_lookahead_job), sizeof(x265_hip_refine_section), sizeof(x265_hip_inter_pu), sizeof(x265_hip_inter_pu_result), sizeof(x265_hip_merge_cand), sizeof(x265_hip_merge_pu), sizeof(x265_hip_merge_result)); return 0; }\n')
     exe = tmp_path / "sizes"
     subprocess.check_call([cc, "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(lib.Primitives), abi.ME_JOB.itemsize, abi.ME_RESULT.itemsize, abi.COST_REQ.itemsize,
             abi.BIDIR_REQ.itemsize, abi.PRED_REQ.itemsize, lib.CTU_JOB.itemsize, abi.REFINE_REQ.itemsize, abi.INTER_JOB.itemsize, abi.INTER_RESULT.itemsize,
-            abi.LOOKAHEAD_JOB.itemsize, abi.REFINE_SECTION.itemsize]
+            abi.LOOKAHEAD_JOB.itemsize, abi.REFINE_SECTION.itemsize, abi.INTER_PU.itemsize, abi.INTER_PU_RESULT.itemsize, abi.MERGE_CAND.itemsize,
+            abi.MERGE_PU.itemsize, abi.MERGE_RESULT.itemsize]
     assert got == want

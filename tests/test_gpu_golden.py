@@ -319,6 +319,22 @@ def test_bad_arguments_are_rejected(gpu_ctx):
         gpu_ctx.predict_batch(pr)  # weighted prediction with a denominator beyond log2WeightDenom's 0..7
 
 
+def test_merge_estimation_reproduces_the_reference_encoder(gpu_ctx):
+    """encoder_merge.npz through x265_hip_merge_estimate_batch: the reference encoder's own xMergeEstimation outcomes"""
+    from test_oracle_golden import check_merge, merge_fixture
+    g, planes = merge_fixture()
+    for i, (buf, origin, stride) in enumerate(planes):
+        gpu_ctx.plane_upload(20 + i, buf, stride, origin)
+    pus = g["merge_pus"].copy()
+    pus["fenc_plane"] += 20
+    rp = pus["cand"]["ref_plane"]
+    rp[rp >= 0] += 20
+    W, H = (int(v) for v in g["pic_size"])
+    check_merge(gpu_ctx.merge_estimate_batch(pus, W, H), g["merge_out"])
+    for i in range(len(planes)):
+        gpu_ctx.plane_release(20 + i)
+
+
 def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
     """the drop-in itself: oracle/_ref/enc_hip is the reference encoder (its own sources) linked with
     source/common/hip/hip-primitives.cpp and libx265_hip.so; with the table installed, with every motionEstimate
@@ -380,6 +396,14 @@ def test_reference_encoder_with_hip_table_gives_the_same_bitstream(tmp_path):
             assert m and int(m.group(4)) == 0 and int(m.group(5)) > 20 and m.group(5) == m.group(3), r.stderr
         hashes.append(re.search(r"%d pictures in .* bitstream hash ([0-9a-f]+)" % N, r.stderr).group(1))
     assert len(set(hashes)) == 1, hashes
+    # --rect --amp --weightb: every xMergeEstimation the encoder's state gives rise to, made again on the GPU
+    r = subprocess.run([exe, str(clip), str(W), str(H), str(N), str(tmp_path), "0", "0", "0", "2", "1"],
+                       env=dict(os.environ, X265_CAPTURE_RECT="1", X265_CAPTURE_WEIGHTB="1", X265_USE_HIP_MERGE="1"), capture_output=True, text=True,
+                       timeout=200)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"(\d+) xMergeEstimation calls answered on the GPU \((\d+) in weighted slices, (\d+) chose a bi-directional candidate\), (\d+) differed",
+                  r.stderr)
+    assert m and int(m.group(1)) > 500 and int(m.group(2)) > 100 and int(m.group(4)) == 0, r.stderr
     # three frame threads: MotionReference::applyWeight weights a reference's CU rows while the picture is still being
     # reconstructed; each batch of rows is made again by x265_hip_plane_weight_rows (with the table's extendRowBorder
     # installed as well: the frame filter and applyWeight extend their rows through it)

@@ -486,6 +486,46 @@ def test_predict_batch(gpu_ctx, oracle, small_seq):
     gpu_ctx.plane_release(5)
 
 
+def test_mc_satd_and_merge_estimation(gpu_ctx, oracle, small_seq):
+    """x265_hip_mc_satd_batch (satd of the source block against motionCompensation's prediction, every form of the
+    request) and x265_hip_merge_estimate_batch (xMergeEstimation) against the oracle, host-array and device forms"""
+    from conftest import random_merge_pus, random_pred_reqs
+    from x265_amd import abi, lib
+    from x265_amd.hipmem import DeviceBuffer
+    rng = np.random.default_rng(77)
+    p0 = small_seq[0]
+    planes = [p.as_tuple() for p in small_seq]
+    for it in range(6):
+        reqs = random_pred_reqs(rng, p0.w, p0.h, abi.PRED_REQ, oracle_parts(), dst_plane=1, refs=(0, 2), weighted_bi=True)
+        assert np.array_equal(gpu_ctx.mc_satd_batch(reqs), oracle.mc_satd_batch(planes, reqs))
+    pus = random_merge_pus(rng, 3000, p0.w, p0.h, abi.MERGE_PU, abi.PARTS)
+    want = oracle.merge_estimate_batch(planes, pus, p0.w, p0.h)
+    assert (want["cost"] == 0xFFFFFFFF).sum() > 5 and (want["satd"] < 0).sum() > 1000 and len(np.unique(want["index"])) == 5
+    got = gpu_ctx.merge_estimate_batch(pus, p0.w, p0.h)
+    assert np.array_equal(got, want)
+    d_pus, d_out = DeviceBuffer.from_array(pus), DeviceBuffer(abi.MERGE_RESULT.itemsize * len(pus))
+    gpu_ctx.merge_estimate_batch_device(d_pus.ptr, len(pus), p0.w, p0.h, d_out.ptr)
+    gpu_ctx.sync()
+    assert np.array_equal(d_out.download(abi.MERGE_RESULT), want)
+    d_pus.free()
+    d_out.free()
+    # refused: no candidates, a candidate without a reference, a plane that was not uploaded
+    for k, v in (("num_cand", 0), ("num_cand", 6), ("weighted", 3), ("fenc_plane", 300)):
+        q = pus[:1].copy()
+        q[k] = v
+        with pytest.raises(lib.X265HipError):
+            gpu_ctx.merge_estimate_batch(q, p0.w, p0.h)
+    q = pus[:1].copy()
+    q["cand"]["ref_plane"][0, 0] = [-1, -1]
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.merge_estimate_batch(q, p0.w, p0.h)
+    q = pus[:1].copy()
+    q["cand"]["ref_plane"][0, 0] = [300, -1]
+    with pytest.raises(lib.X265HipError):
+        gpu_ctx.merge_estimate_batch(q, p0.w, p0.h)
+    assert len(gpu_ctx.merge_estimate_batch(pus[:0], p0.w, p0.h)) == 0
+
+
 def test_primitive_table_mc_entries(oracle):
     """luma_vps / luma_vss / luma_hvpp / luma_p2s / luma_addAvg of the function-pointer table: host pointers, odd
     strides; whole destination buffers compared"""

@@ -188,6 +188,31 @@ def test_weighted_bi_prediction_matches_reference_fixture(oracle):
         assert np.array_equal(oracle.add_weight_bi(src[0], src[1], *hd), dst), hd
 
 
+def merge_fixture():
+    g = np.load(os.path.join(GOLD, "encoder_merge.npz"))
+    planes, pos = [], 0
+    for nbytes, origin, stride in g["plane_geo"]:
+        planes.append((g["plane_bytes"][pos:pos + nbytes].copy(), int(origin), int(stride)))
+        pos += int(nbytes)
+    return g, planes
+
+
+def check_merge(res, want):
+    for k in ("cost", "bits", "index", "inter_dir"):
+        assert np.array_equal(res[k], want[k]), k
+
+
+def test_merge_estimation_matches_the_reference_encoder(oracle):
+    """encoder_merge.npz: 930 TEncSearch::xMergeEstimation calls of a reference encoder run with rectangular and
+    asymmetric partitions (oracle/gen_golden.py gen_encoder_merge): weighted P slices, weighted B slices, candidates of
+    one list and of both; cost, bits, index and direction as the reference left them"""
+    g, planes = merge_fixture()
+    pus, want = g["merge_pus"], g["merge_out"]
+    assert len(pus) > 900 and (pus["weighted"] == 1).sum() > 300 and (pus["weighted"] == 2).sum() > 100 and (want["inter_dir"] == 3).sum() > 30
+    W, H = (int(v) for v in g["pic_size"])
+    check_merge(oracle.merge_estimate_batch(planes, pus, W, H), want)
+
+
 def test_lowres_bidir_costs_match_reference_fixtures(oracle):
     """lowres_bidir.npz: the lookahead's bidirectional cost (lowresMC x 2, pixelavg_pp, satd) by the reference build"""
     g = np.load(os.path.join(GOLD, "lowres_bidir.npz"))

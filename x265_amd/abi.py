@@ -119,6 +119,19 @@ INTER_PU_RESULT = np.dtype([("list", INTER_SIDE, (2,)), ("bidir", INTER_SIDE, (2
                             ("inter_dir", "u1"), ("zero_tried", "u1"), ("pending", "u1"), ("pad", "u1")])
 assert INTER_PU_RESULT.itemsize == 92
 
+# x265_hip_merge_pu / x265_hip_merge_result: TEncSearch::xMergeEstimation of a prediction unit
+MRG_MAX_NUM_CANDS = 5
+MERGE_CAND = np.dtype([("ref_plane", "<i4", (2,)), ("mv", "<i2", (4,)), ("wp_w", "<i2", (2,)), ("wp_o", "<i2", (2,)),
+                       ("log2_denom", "u1", (2,)), ("pad", "u1", (2,))])
+assert MERGE_CAND.itemsize == 28
+MERGE_PU = np.dtype([("fenc_plane", "<i4"), ("pu_x", "<i2"), ("pu_y", "<i2"), ("pu_w", "u1"), ("pu_h", "u1"), ("num_cand", "u1"),
+                     ("weighted", "u1"), ("cu_x", "<i2"), ("cu_y", "<i2"), ("mvy_limit", "<i2"), ("pad", "<u2"), ("lambda_sad", "<u4"),
+                     ("cand", MERGE_CAND, (MRG_MAX_NUM_CANDS,))])
+assert MERGE_PU.itemsize == 164
+MERGE_RESULT = np.dtype([("cost", "<u4"), ("bits", "<u4"), ("index", "u1"), ("inter_dir", "u1"), ("pad", "u1", (2,)),
+                         ("satd", "<i4", (MRG_MAX_NUM_CANDS,))])
+assert MERGE_RESULT.itemsize == 32
+
 REFINE_SECTION = np.dtype([("count", "<i4"), ("pu_w", "u1"), ("pu_h", "u1"), ("pad", "u1", (2,))])
 assert REFINE_SECTION.itemsize == 8
 MAX_SECTIONS = 4

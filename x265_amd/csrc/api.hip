@@ -13,6 +13,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <string>
 #include <vector>
 
 #include "kernels.h"
@@ -1079,7 +1080,7 @@ static int validate_dist(const x265_hip_ctx *c, const x265_hip_cost_req *reqs, i
     return 0;
 }
 
-static int validate_pred(const x265_hip_ctx *c, const x265_hip_pred_req *reqs, int n)
+static int validate_pred(const x265_hip_ctx *c, const x265_hip_pred_req *reqs, int n, bool satd = false)
 {
     for (int i = 0; i < n; i++)
     {
@@ -1087,7 +1088,7 @@ static int validate_pred(const x265_hip_ctx *c, const x265_hip_pred_req *reqs, i
         int r = check_block(c, q.dst_plane, q.ref0_plane, q.pu_w, q.pu_h, "pred_req", i);
         if (r || (q.ref1_plane >= 0 && (r = check_block(c, q.dst_plane, q.ref1_plane, q.pu_w, q.pu_h, "pred_req", i))))
             return r;
-        if (q.dst_plane == q.ref0_plane || q.dst_plane == q.ref1_plane)
+        if (!satd && (q.dst_plane == q.ref0_plane || q.dst_plane == q.ref1_plane)) // (mc_satd writes nothing)
             return fail(X265_HIP_EINVAL, "pred_req[%d]: the destination plane is one of the references", i);
         if (q.ref1_plane == X265_HIP_PRED_WEIGHTED &&
             (q.log2_denom > 7 || q.qmv1_x < -128 || q.qmv1_x > 255 || q.qmv1_y < -128 || q.qmv1_y > 127))
@@ -1870,6 +1871,136 @@ int x265_hip_predict_batch(x265_hip_ctx *c, const x265_hip_pred_req *reqs, int n
     HIP_TRY(hipMemcpyAsync(c->in.d, reqs, (size_t)n * sizeof(*reqs), hipMemcpyHostToDevice, c->stream));
     LAUNCH(launch_predict(c->dev_tabs, (const x265_hip_pred_req *)c->in.d, n, c->batch_counter, c->batch_parity ^= 1, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream)); // `reqs` is read by the copy until here
+    return X265_HIP_OK;
+}
+
+int x265_hip_mc_satd_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, void *d_costs)
+{
+    if (!c || n < 0 || (n && (!d_reqs || !d_costs)))
+        return fail(X265_HIP_EINVAL, "mc_satd_batch_device: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = checked_records<x265_hip_pred_req>(c, d_reqs, n, [&](const x265_hip_pred_req *h) { return validate_pred(c, h, n, true); });
+        if (vr)
+            return vr;
+    }
+    int r = push_tabs(c);
+    if (r)
+        return r;
+    LAUNCH(launch_mc_satd(c->dev_tabs, (const x265_hip_pred_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    return X265_HIP_OK;
+}
+
+int x265_hip_mc_satd_batch(x265_hip_ctx *c, const x265_hip_pred_req *reqs, int n, int32_t *costs)
+{
+    if (!c || n < 0 || (n && (!reqs || !costs)))
+        return fail(X265_HIP_EINVAL, "mc_satd_batch: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = validate_pred(c, reqs, n, true);
+        if (vr)
+            return vr;
+    }
+    int r;
+    const size_t ob = (size_t)n * sizeof(int32_t);
+    if ((r = push_tabs(c)) || (r = ensure(c, c->in, (size_t)n * sizeof(*reqs))) || (r = ensure(c, c->out, ob)))
+        return r;
+    HIP_TRY(hipMemcpyAsync(c->in.d, reqs, (size_t)n * sizeof(*reqs), hipMemcpyHostToDevice, c->stream));
+    LAUNCH(launch_mc_satd(c->dev_tabs, (const x265_hip_pred_req *)c->in.d, n, (int32_t *)c->out.d, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(costs, c->out.h, ob);
+    return X265_HIP_OK;
+}
+
+// ---- xMergeEstimation -----------------------------------------------------------------------------------------------
+
+// the requests the device will make of the units' candidates, put through the checks of a prediction request
+static int validate_merge(const x265_hip_ctx *c, const x265_hip_merge_pu *pus, int n, int pic_w, int pic_h)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const x265_hip_merge_pu &p = pus[i];
+        if (p.num_cand < 1 || p.num_cand > X265_HIP_MRG_MAX_NUM_CANDS || p.weighted > 2)
+            return fail(X265_HIP_EINVAL, "merge_pu[%d]: %d candidates / weighted %d out of range", i, p.num_cand, p.weighted);
+        int r = check_block(c, p.fenc_plane, p.fenc_plane, p.pu_w, p.pu_h, "merge_pu", i);
+        if (r || (r = check_inside(c, p.fenc_plane, p.pu_x, p.pu_y, p.pu_w, p.pu_h, "merge_pu", i)))
+            return r;
+        for (int k = 0; k < p.num_cand; k++)
+        {
+            if (p.cand[k].ref_plane[0] < 0 && (p.cand[k].ref_plane[1] < 0 || p.weighted == 1))
+                return fail(X265_HIP_EINVAL, "merge_pu[%d]: candidate %d has no reference", i, k);
+            x265_hip_pred_req q;
+            if (merge_make_req(p, k, pic_w, pic_h, q) && (r = validate_pred(c, &q, 1, true)))
+            {
+                const std::string why = x265_hip_last_error();
+                return fail(r, "merge_pu[%d] candidate %d: %s", i, k, why.c_str());
+            }
+        }
+    }
+    return 0;
+}
+
+#define X265HIP_MERGE_SCRATCH_BYTES(n) ((size_t)(n) * X265_HIP_MRG_MAX_NUM_CANDS * (sizeof(x265_hip_pred_req) + sizeof(int32_t)))
+
+static int merge_launch(x265_hip_ctx *c, const x265_hip_merge_pu *d_pus, int n, int pic_w, int pic_h, x265_hip_merge_result *d_out)
+{
+    int r;
+    if (c->mejobs.cap < X265HIP_MERGE_SCRATCH_BYTES(n))
+        HIP_TRY(hipStreamSynchronize(c->stream)); // an earlier launch may still read the buffer that is about to be replaced
+    if ((r = push_tabs(c)) || (r = ensure(c, c->mejobs, X265HIP_MERGE_SCRATCH_BYTES(n), false)))
+        return r;
+    x265_hip_pred_req *reqs = (x265_hip_pred_req *)c->mejobs.d;
+    int32_t *satd = (int32_t *)(reqs + (size_t)n * X265_HIP_MRG_MAX_NUM_CANDS);
+    LAUNCH(launch_merge_estimate(c->dev_tabs, d_pus, n, pic_w, pic_h, reqs, satd, d_out, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    return X265_HIP_OK;
+}
+
+int x265_hip_merge_estimate_batch_device(x265_hip_ctx *c, const void *d_pus, int n, int pic_w, int pic_h, void *d_results)
+{
+    if (!c || n < 0 || pic_w <= 0 || pic_h <= 0 || (n && (!d_pus || !d_results)))
+        return fail(X265_HIP_EINVAL, "merge_estimate_batch_device: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = checked_records<x265_hip_merge_pu>(c, d_pus, n, [&](const x265_hip_merge_pu *h) { return validate_merge(c, h, n, pic_w, pic_h); });
+        if (vr)
+            return vr;
+    }
+    return merge_launch(c, (const x265_hip_merge_pu *)d_pus, n, pic_w, pic_h, (x265_hip_merge_result *)d_results);
+}
+
+int x265_hip_merge_estimate_batch(x265_hip_ctx *c, const x265_hip_merge_pu *pus, int n, int pic_w, int pic_h, x265_hip_merge_result *results)
+{
+    if (!c || n < 0 || pic_w <= 0 || pic_h <= 0 || (n && (!pus || !results)))
+        return fail(X265_HIP_EINVAL, "merge_estimate_batch: bad argument");
+    if (n == 0)
+        return X265_HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    {
+        int vr = validate_merge(c, pus, n, pic_w, pic_h);
+        if (vr)
+            return vr;
+    }
+    int r;
+    const size_t ob = (size_t)n * sizeof(*results);
+    if ((r = ensure(c, c->in, (size_t)n * sizeof(*pus))) || (r = ensure(c, c->out, ob)))
+        return r;
+    HIP_TRY(hipMemcpyAsync(c->in.d, pus, (size_t)n * sizeof(*pus), hipMemcpyHostToDevice, c->stream));
+    if ((r = merge_launch(c, (const x265_hip_merge_pu *)c->in.d, n, pic_w, pic_h, (x265_hip_merge_result *)c->out.d)))
+        return r;
+    HIP_TRY(hipMemcpyAsync(c->out.h, c->out.d, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(results, c->out.h, ob);
     return X265_HIP_OK;
 }
 

@@ -115,6 +115,10 @@ void launch_inter_decide_bidir(const DeviceTables *tabs, const x265_hip_inter_jo
 void launch_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, uint32_t *counters, int parity,
                  hipStream_t st);
 void launch_predict(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int n, uint32_t *counters, int parity, hipStream_t st);
+void launch_mc_satd(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int n, int32_t *out, uint32_t *counters, int parity, hipStream_t st);
+// xMergeEstimation: reqs / satd are scratch for X265_HIP_MRG_MAX_NUM_CANDS * n requests and their costs
+void launch_merge_estimate(const DeviceTables *tabs, const x265_hip_merge_pu *pus, int n, int pic_w, int pic_h, x265_hip_pred_req *reqs,
+                           int32_t *satd, x265_hip_merge_result *out, uint32_t *counters, int parity, hipStream_t st);
 void launch_dist(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int32_t *out, uint32_t *counters, int parity,
                  hipStream_t st);
 void launch_bidir_cost(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int32_t *out, uint32_t *counters, int parity,

@@ -760,6 +760,65 @@ __host__ __device__ inline void clip_mv(int &qx, int &qy, int cu_x, int cu_y, in
     qy = qy > ymax ? ymax : qy < ymin ? ymin : qy;
 }
 
+// TEncSearch::xMergeEstimation's candidates (reference Lib/TLibEncoder/TEncSearch.cpp:2194-2210).  Whether candidate c
+// of a unit is measured: present, with a reference, and neither list's vector at the frame threads' limit.
+__host__ __device__ inline bool merge_cand_used(const x265_hip_merge_pu &p, int c)
+{
+    if (c >= p.num_cand)
+        return false;
+    const x265_hip_merge_cand &m = p.cand[c];
+    const bool v0 = m.ref_plane[0] >= 0, v1 = m.ref_plane[1] >= 0 && p.weighted != 1;
+    return (v0 || v1) && m.mv[1] < p.mvy_limit && m.mv[3] < p.mvy_limit;
+}
+
+// The prediction motionCompensation(cu, .., REF_PIC_LIST_X, ..) makes for the candidate (TComPrediction.cpp:252-297), as
+// a prediction request against the source picture (x265_hip_mc_satd_batch).  A candidate that is not measured gives a
+// request any list may hold (the unit's 4x4 corner predicted from the source picture itself) and false.
+__host__ __device__ inline bool merge_make_req(const x265_hip_merge_pu &p, int c, int pic_w, int pic_h, x265_hip_pred_req &r)
+{
+    r = x265_hip_pred_req{};
+    r.dst_plane = r.ref0_plane = p.fenc_plane;
+    r.ref1_plane = -1;
+    r.pu_x = p.pu_x, r.pu_y = p.pu_y;
+    r.pu_w = r.pu_h = 4;
+    if (!merge_cand_used(p, c))
+        return false;
+    r.pu_w = p.pu_w, r.pu_h = p.pu_h;
+    const x265_hip_merge_cand &m = p.cand[c];
+    bool v0 = m.ref_plane[0] >= 0, v1 = m.ref_plane[1] >= 0 && p.weighted != 1; // a P slice predicts from list 0 (:261-262)
+    // xCheckIdenticalMotion (:232-250; never in a slice with weighted bi-prediction): list 0 alone, unweighted
+    const bool same = v0 && v1 && p.weighted != 2 && m.ref_plane[0] == m.ref_plane[1] && m.mv[0] == m.mv[2] && m.mv[1] == m.mv[3];
+    if (same)
+        v1 = false;
+    int x0 = m.mv[0], y0 = m.mv[1], x1 = m.mv[2], y1 = m.mv[3];
+    clip_mv(x0, y0, p.cu_x, p.cu_y, pic_w, pic_h);
+    clip_mv(x1, y1, p.cu_x, p.cu_y, pic_w, pic_h);
+    if (v0 && v1)
+    {
+        r.ref0_plane = m.ref_plane[0], r.ref1_plane = m.ref_plane[1];
+        r.qmv0_x = (int16_t)x0, r.qmv0_y = (int16_t)y0, r.qmv1_x = (int16_t)x1, r.qmv1_y = (int16_t)y1;
+        if (p.weighted == 2) // xPredInterBi :347-350
+        {
+            r.weighted_bi = 1;
+            r.wp_w0 = m.wp_w[0], r.wp_o0 = m.wp_o[0], r.wp_w1 = m.wp_w[1], r.wp_o1 = m.wp_o[1];
+            r.log2_denom = m.log2_denom[0];
+        }
+    }
+    else
+    {
+        const int l = v0 ? 0 : 1;
+        r.ref0_plane = m.ref_plane[l];
+        r.qmv0_x = (int16_t)(l ? x1 : x0), r.qmv0_y = (int16_t)(l ? y1 : y0);
+        if (p.weighted) // :265-279 (P) / xPredInterBi :356-368 (B): the intermediate and addWeightUni
+        {
+            r.ref1_plane = X265_HIP_PRED_WEIGHTED;
+            r.qmv1_x = m.wp_w[l], r.qmv1_y = m.wp_o[l];
+            r.log2_denom = m.log2_denom[l];
+        }
+    }
+    return true;
+}
+
 // TEncSearch::xSetSearchRange (reference Lib/TLibEncoder/TEncSearch.cpp:2600-2617): full-pel window around the
 // clipped predictor; MV arithmetic is int16 in the reference (mv.h)
 __host__ __device__ inline void search_window(int mvpx, int mvpy, int merange, int ref_lag, int cu_x, int cu_y, int pic_w, int pic_h,

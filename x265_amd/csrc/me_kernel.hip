@@ -2061,7 +2061,9 @@ __device__ __forceinline__ int req_qy1(const x265_hip_bidir_req &r) { return r.q
 // bidirectional request combines its two predictions the way motion compensation does (14-bit intermediates +
 // luma_addAvg, xPredInterBi) instead of pixelavg_pp: what xMergeEstimation measures on a bi-directional merge
 // candidate (TEncSearch.cpp:2209-2210) and mode decision on a bi-predicted block.
-enum { MODE_COST = 0, MODE_BIDIR = 1, MODE_DIST = 2, MODE_PRED = 4 };
+// MODE_PRED | MODE_PRED_SATD: the predicted strips are not stored but compared (satd) with the block of the
+// "destination" plane, which is the source picture here (x265_hip_mc_satd_batch: xMergeEstimation's measurement).
+enum { MODE_COST = 0, MODE_BIDIR = 1, MODE_DIST = 2, MODE_PRED = 4, MODE_PRED_SATD = 8 };
 enum { INFO_LOWRES = 1 << 24, INFO_MCAVG = 1 << 25, INFO_PRED_BI = 1 << 26, INFO_PRED_W = 1 << 27, INFO_PRED_WBI = 1 << 28 };
 #define DIST_UNITS 16 // 64x64: sixteen 16x16 blocks; 32x24 / 24x32: twelve 8x8 blocks
 
@@ -2069,6 +2071,7 @@ template <int MODE, typename Req>
 __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *reqs, int n, int32_t *out, uint32_t *counters, int parity, int rb)
 {
     constexpr bool BIDIR = (MODE & MODE_BIDIR) != 0, DIST = (MODE & MODE_DIST) != 0, PRED = (MODE & MODE_PRED) != 0;
+    constexpr bool PRED_SATD = (MODE & MODE_PRED_SATD) != 0;
     // A batch of 32 64x64 blocks is 64 passes of the item loop, and a list of such blocks has fewer batches than the
     // chip has waves: the work per batch is bounded instead.  Every wave looks at the same 64 requests spread over
     // the list and halves rb until a batch holds about 512 items (eight passes) by their mean.  The positions are
@@ -2311,6 +2314,15 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
                     }
                     else
                         ref_strip<NT>(r0, rstride, xf, yf, pix);
+                    if (PRED_SATD)
+                    {
+                        int v = 0;
+#pragma unroll
+                        for (int half = 0; half < NT; half++)
+                            v += tile_metric<true>(dst + 4 * half * fstride, fstride, pix + 4 * half, 1);
+                        atomicAdd(&L.cost[k], v);
+                        return;
+                    }
 #pragma unroll
                     for (int y = 0; y < R; y++)
                     {
@@ -2432,7 +2444,7 @@ __device__ __forceinline__ void cost_body(const DeviceTables *tabs, const Req *r
             atomicAdd(&L.cost[k], v);
         }
         wave_sync();
-        if (have && !PRED)
+        if (have && (!PRED || PRED_SATD))
         {
             int c = L.cost[lane];
             if (DIST)
@@ -2461,6 +2473,13 @@ __global__ __launch_bounds__(256) void bidir_cost_kernel(const DeviceTables *tab
 __global__ __launch_bounds__(256) void predict_kernel(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int n, uint32_t *counters, int parity, int rb)
 {
     cost_body<MODE_PRED>(tabs, reqs, n, nullptr, counters, parity, rb);
+}
+
+// satd of the source block against the motion-compensated prediction (x265_hip_mc_satd_batch)
+__global__ __launch_bounds__(256) void mc_satd_kernel(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int n, int32_t *out,
+                                                      uint32_t *counters, int parity, int rb)
+{
+    cost_body<MODE_PRED | MODE_PRED_SATD>(tabs, reqs, n, out, counters, parity, rb);
 }
 
 // cost requests whose metric may be any of sad, satd, sa8d_inter, sse_pp (x265_hip_dist_batch)
@@ -2603,6 +2622,15 @@ void launch_predict(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int
     {
         const int rb = batch_requests(n), blocks = ((n + rb - 1) / rb + 3) / 4;
         hipLaunchKernelGGL(predict_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, counters, parity, rb);
+    }
+}
+
+void launch_mc_satd(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int n, int32_t *out, uint32_t *counters, int parity, hipStream_t st)
+{
+    if (n > 0)
+    {
+        const int rb = batch_requests(n), blocks = ((n + rb - 1) / rb + 3) / 4;
+        hipLaunchKernelGGL(mc_satd_kernel, dim3(blocks < COST_MAX_BLOCKS ? blocks : COST_MAX_BLOCKS), dim3(256), 0, st, tabs, reqs, n, out, counters, parity, rb);
     }
 }
 

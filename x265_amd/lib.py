@@ -38,6 +38,7 @@ EXPORTS = [
     "x265_hip_cost_batch_device_noalloc", "x265_hip_refine_batch", "x265_hip_refine_batch_device",
     "x265_hip_inter_search_batch", "x265_hip_inter_search_batch_device",
     "x265_hip_lookahead_batch", "x265_hip_lookahead_batch_device", "x265_hip_lookahead_status", "x265_hip_ctx_check_records", "x265_hip_ctx_guard_status", "x265_hip_inter_decide_batch", "x265_hip_inter_decide_batch_device",
+    "x265_hip_mc_satd_batch", "x265_hip_mc_satd_batch_device", "x265_hip_merge_estimate_batch", "x265_hip_merge_estimate_batch_device",
     "x265_hip_refine_sections_device",
     "x265_hip_host_alloc", "x265_hip_host_free", "x265_hip_plane_alloc", "x265_hip_plane_upload_async", "x265_hip_download_async",
     "x265_hip_copy_wait_compute", "x265_hip_compute_wait_copy", "x265_hip_copy_sync",
@@ -273,6 +274,28 @@ class Context:
         _check(load().x265_hip_inter_decide_batch_device(self._h, C.c_void_p(d_jobs), C.c_int(njobs), C.c_void_p(d_pus), C.c_int(npu),
                                                          C.c_int(pic_width), C.c_int(pic_height), C.c_void_p(d_job_results),
                                                          C.c_void_p(d_results), C.c_int(1 if any_bidir else 0)))
+
+    def mc_satd_batch(self, reqs):
+        """satd of the block of plane reqs.dst_plane (the source picture) against the prediction of each request"""
+        reqs = np.ascontiguousarray(reqs, PRED_REQ)
+        out = np.zeros(len(reqs), np.int32)
+        _check(load().x265_hip_mc_satd_batch(self._h, _p(reqs), C.c_int(len(reqs)), _p(out)))
+        return out
+
+    def mc_satd_batch_device(self, d_reqs, n, d_costs):
+        _check(load().x265_hip_mc_satd_batch_device(self._h, C.c_void_p(d_reqs), C.c_int(n), C.c_void_p(d_costs)))
+
+    def merge_estimate_batch(self, pus, pic_width, pic_height):
+        """TEncSearch::xMergeEstimation of every prediction unit"""
+        from .abi import MERGE_PU, MERGE_RESULT
+        pus = np.ascontiguousarray(pus, MERGE_PU)
+        out = np.zeros(len(pus), MERGE_RESULT)
+        _check(load().x265_hip_merge_estimate_batch(self._h, _p(pus), C.c_int(len(pus)), C.c_int(pic_width), C.c_int(pic_height), _p(out)))
+        return out
+
+    def merge_estimate_batch_device(self, d_pus, n, pic_width, pic_height, d_results):
+        _check(load().x265_hip_merge_estimate_batch_device(self._h, C.c_void_p(d_pus), C.c_int(n), C.c_int(pic_width), C.c_int(pic_height),
+                                                           C.c_void_p(d_results)))
 
     def refine_sections_device(self, d_reqs, sections, d_costs9):
         """sections: [(count, pu_w, pu_h), ...] (at most abi.MAX_SECTIONS runs of one PU size each, in list order)"""
