@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
-from conftest import random_bidir_reqs, random_cost_reqs, random_inter_units, random_lowres_jobs, random_me_jobs, random_pred_reqs
+from conftest import random_bidir_reqs, random_cost_reqs, random_inter_units, random_lowres_jobs, random_me_jobs, random_pred_reqs  # noqa: E402
 from oracle import pyoracle
 from x265_amd import abi, lib, synth
 
@@ -206,6 +206,15 @@ wres = O.inter_search_batch(pl, tabs, uj, W, H)
 want = O.inter_decide_batch(pl, tabs, uj, wres, up, W, H)
 report("inter_decide_batch (iterations)", res, wres.view(res.dtype), uj)
 report("inter_decide_batch (units)", np.array([g.tobytes() for g in got]), np.array([w_.tobytes() for w_ in want]), up)
+
+# xMergeEstimation per prediction unit and its measurement on single requests (round 3); the source picture is plane 1
+from conftest import random_merge_pus
+mp = random_merge_pus(rng, max(1, N // 2), W, H, abi.MERGE_PU, abi.PARTS, fenc_plane=1, refs=(0, 2, 3, 4))
+got, want = ctx.merge_estimate_batch(mp, W, H), O.merge_estimate_batch(pl, mp, W, H)
+report("merge_estimate_batch", np.array([g.tobytes() for g in got]), np.array([w_.tobytes() for w_ in want]), mp)
+mr = np.concatenate([random_pred_reqs(rng, W, H, abi.PRED_REQ, abi.PARTS, dst_plane=int(rng.choice([1, 4])), refs=(0, 2, 3), weighted_bi=True)
+                     for _ in range(max(4, N // 400))])
+report("mc_satd_batch", ctx.mc_satd_batch(mr), O.mc_satd_batch(pl, mr), mr)
 
 # one long diamond / hexagon list (round 3: lists of 262,144 calls and more search their 32-wide blocks in teams of 8x8
 # cells as well), through the device-array entry point with the record guard on
