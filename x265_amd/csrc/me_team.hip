@@ -59,9 +59,11 @@ enum TeamState { TS_PRE, TS_DIA, TS_HEX1, TS_HEXN, TS_SQ, TS_POST_WAIT, TS_HPEL,
 //            cell = a strip of 4 x 8 (15 filtered rows per 8 rows of output instead of 2 x 11), which needs the registers
 //            of two waves per SIMD and measured slower
 //   TeamT32  blocks up to 32x32: 16 lanes, cell = 8 x 8 (two strips)  ( 4 calls per wave)
+// PREWIN: the window is loaded around the predictor in front of the pre-tests (measured on the lists of a 4K picture x 3
+// references: 8x8 0.347 -> 0.339 ms, 16x16 0.303 -> 0.322 ms, 32x32 the same: on for the smallest class only)
 struct TeamT4
 {
-    enum { L = 4, CW = 1, CH = 1, PITCH = 24, ROWS = 8 + 2 * TEAM_RY, UNIT = 12, CLS = MC_T4 };
+    enum { L = 4, CW = 1, CH = 1, PITCH = 24, ROWS = 8 + 2 * TEAM_RY, UNIT = 12, CLS = MC_T4, PREWIN = 1 };
 };
 #ifndef TEAM_T8_STRIPS
 #define TEAM_T8_STRIPS 0 // measured: strips at two waves per SIMD 0.323 ms for the 16x16 calls of a 4K picture, tiles at three 0.294
@@ -69,17 +71,17 @@ struct TeamT4
 #if TEAM_T8_STRIPS
 struct TeamT8
 {
-    enum { L = 8, CW = 1, CH = 2, PITCH = 32, ROWS = 16 + 2 * TEAM_RY, UNIT = 16, CLS = MC_T8 };
+    enum { L = 8, CW = 1, CH = 2, PITCH = 32, ROWS = 16 + 2 * TEAM_RY, UNIT = 16, CLS = MC_T8, PREWIN = 0 };
 };
 #else
 struct TeamT8 // (16 lanes, a tile each)
 {
-    enum { L = 16, CW = 1, CH = 1, PITCH = 32, ROWS = 16 + 2 * TEAM_RY, UNIT = 16, CLS = MC_T8 };
+    enum { L = 16, CW = 1, CH = 1, PITCH = 32, ROWS = 16 + 2 * TEAM_RY, UNIT = 16, CLS = MC_T8, PREWIN = 0 };
 };
 #endif
 struct TeamT32
 {
-    enum { L = 16, CW = 2, CH = 2, PITCH = 48, ROWS = 32 + 2 * TEAM_RY, UNIT = 16, CLS = MC_T32 };
+    enum { L = 16, CW = 2, CH = 2, PITCH = 48, ROWS = 32 + 2 * TEAM_RY, UNIT = 16, CLS = MC_T32, PREWIN = 0 };
 };
 template <typename T>
 struct __attribute__((aligned(16))) TeamLds
@@ -362,6 +364,15 @@ __device__ __forceinline__ void team_chunk(TeamLds<T> &lds, const int *pat, cons
         need_win = sh ? !fits(ncx, ncy, 2, 0, 0) : !fits(ncx, ncy, 1, 3, 4);
     };
 
+    if (T::PREWIN)
+    {
+        // The window is loaded around the predictor's full-pel rounding before the pre-tests: the predictor, its rounding
+        // and the candidate vectors near them are measured out of it (the others, the zero vector mostly, from the
+        // plane), and the integer stage starts in it when the predictor wins.
+        need_win = has_job;
+        ncx = fpx;
+        ncy = fpy;
+    }
     int guard = 0;
     while (__ballot(st != TS_DONE) != 0 && ++guard < 8192)
     {
@@ -450,11 +461,13 @@ __device__ __forceinline__ void team_chunk(TeamLds<T> &lds, const int *pat, cons
             const bool act = ((vmask >> c) & 1u) != 0;
             if (__ballot(act) == 0)
                 continue;
-            const bool from_plane = __ballot(pre) != 0; // (all teams of a wave are in the pre-tests together)
+            const int pos = act ? lds.cand[team][c] : 0;
+            // (all teams of a wave are in the pre-tests together) one path per pass: with PREWIN the plane's unless every
+            // team's candidate of this slot lies in its window with the filters' margins
+            const bool from_plane = __ballot(pre) != 0 && (!T::PREWIN || __ballot(act && !fits((int)(int16_t)pos >> 2, pos >> 18, 0, 3, 4)) != 0);
             int v = 0, seed = 0;
             if (act)
             {
-                const int pos = lds.cand[team][c];
                 const int qx = (int)(int16_t)pos, qy = pos >> 16;
                 const int rate = mv_rate(qx, qy);
                 if (from_plane)
