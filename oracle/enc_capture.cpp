@@ -1213,6 +1213,8 @@ int main(int argc, char **argv)
     p->frameNumThreads = frame_threads;
     p->poolNumThreads = pool_threads;
     p->logLevel = X265_LOG_WARNING;
+    if (getenv("X265_CAPTURE_SPARSE")) /* whole-sequence captures: a plane's version is told by about 2048 samples per call */
+        g_hip_sparse = true;
     if (getenv("X265_CAPTURE_WEIGHTB")) /* --weightb: weighted prediction in B slices (param.cpp:610) */
         p->bEnableWeightedBiPred = 1;
     if (getenv("X265_CAPTURE_RECT")) /* --rect --amp (param.cpp:562-563): partitions other than 2Nx2N, so xMergeEstimation runs */
