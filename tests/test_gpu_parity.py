@@ -1118,6 +1118,19 @@ def test_record_guard_of_the_request_lists(gpu_ctx, small_seq):
         ok = np.ones(len(bad), bool)
         ok[idx] = False
         assert np.array_equal(got[ok], want[ok]) and (got[~ok] == -1).all()
+        # a good record of another size than its run's (mode 1 refuses it) only costs time: the runs size the batches, the
+        # kernel takes a request's strips from the request
+        odd = recs.copy()
+        big = ring[(ring["pu_w"] == 64) & (ring["pu_h"] == 64)][:2]
+        assert len(big) == 2
+        odd[3], odd[len(runs[0]) + 5] = big[0], big[1]
+        want = gpu_ctx.refine_batch(odd)
+        d2 = DeviceBuffer.from_array(odd)
+        gpu_ctx.refine_sections_device(d2.ptr, [(len(r_), int(r_["pu_w"][0]), int(r_["pu_h"][0])) for r_ in runs], o.ptr)
+        assert gpu_ctx.guard_status() == (0, 0xFFFFFFFF)
+        assert np.array_equal(o.download(np.int32).reshape(len(odd), 9), want)
+        for b_ in (d, d2, o):
+            b_.free()
     finally:
         gpu_ctx.check_records(False)
 
