@@ -565,9 +565,12 @@ enum State
 // LOWRES: the reference is a Lowres (the lookahead's searches): the other sub-pel stage drops out, and vice versa
 // BIG: big_block() sizes, evaluated by q_eval_big (never against a Lowres: the lookahead's blocks are 8x8)
 // WIDE: the block has at least 64 tiles and a width that is a multiple of 16 (q_eval's wide_sad path)
-template <bool SMALL, bool LOWRES, bool BIG = false, bool WIDE = false>
+// MSET (instantiations that are not SMALL): 1 the UMH search only, 2 STAR and FULL only, 3 all of them.  Like SMALL: the
+// states, variables and code of the methods a call cannot use drop out of its instantiation.
+template <bool SMALL, bool LOWRES, bool BIG = false, bool WIDE = false, int MSET = 3>
 __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_job &j, int &rcost, int &rmx, int &rmy, int patv = 0)
 {
+    static_assert(!SMALL || MSET == 3, "MSET selects among the methods SMALL leaves out");
     constexpr bool DIRECT = LOWRES && ME_DIRECT_STATES;
     // integer-stage state, all wave-uniform
     const int lox = j.mvmin_x, loy = j.mvmin_y, hix = j.mvmax_x, hiy = j.mvmax_y; // full-pel, inclusive
@@ -698,7 +701,7 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
 
         // the states of UMH, STAR and the raster scans: a switch of their own, absent from the SMALL instantiation
         bool other = true;
-        if constexpr (!SMALL)
+        if constexpr (!SMALL && (MSET & 1) != 0)
         {
             other = false;
             switch (st)
@@ -934,7 +937,18 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
             st = ST_URING;
             break;
         }
-
+            default:
+                other = true;
+                break;
+            }
+        }
+        if constexpr (!SMALL && (MSET & 2) != 0)
+        {
+            if (other)
+            {
+            other = false;
+            switch (st)
+            {
         // ---- STAR (motion.cpp:887-995; StarPatternSearch :284-524).  The reference's sad_x4 fast path
         // and its guarded scalar path visit the same points in the same order: the guarded form is used.
         case ST_STAR_BEGIN:
@@ -1086,6 +1100,7 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
                 other = true;
                 break;
             }
+            }
         }
         if (other)
         switch (st)
@@ -1146,7 +1161,7 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
                 if (DIRECT)
                     goto hex_begin;
             }
-            else if (method == X265_HIP_UMH)
+            else if ((MSET & 1) != 0 && (MSET == 1 || method == X265_HIP_UMH))
             {
                 // refine predictors: DIA1_ITER(pmv), DIA1_ITER(0) (motion.cpp:707-712)
                 ucost1 = bcost;
@@ -1164,14 +1179,14 @@ __device__ __forceinline__ void motion_estimate_uv(Wave &wv, const x265_hip_me_j
                 flush = FL_BEST;
                 st = ST_U0;
             }
-            else if (method == X265_HIP_STAR)
+            else if ((MSET & 2) != 0 && method == X265_HIP_STAR)
             {
                 point = dist = 0;
                 star_phase = 0;
                 early = 3;
                 st = ST_STAR_BEGIN;
             }
-            else
+            else if ((MSET & 2) != 0)
             {
                 ras_step = 1;
                 ras_quirk = false;
@@ -1473,8 +1488,10 @@ __device__ __forceinline__ void motion_estimate(Wave &wv, const x265_hip_me_job 
         else
             motion_estimate_uv<true, false>(wv, j, bcost, bx, by);
     }
+    else if ((j.method & ~X265_HIP_LOWRES_REF) == X265_HIP_UMH)
+        motion_estimate_uv<false, false, false, false, 1>(wv, j, bcost, bx, by);
     else
-        motion_estimate_uv<false, false>(wv, j, bcost, bx, by);
+        motion_estimate_uv<false, false, false, false, 2>(wv, j, bcost, bx, by);
     if (wv.lane == 0)
     {
         out->cost = bcost;
