@@ -93,8 +93,8 @@ int x265_hip_ctx_sync(x265_hip_ctx *ctx);
  * replaced records to -1 (all nine of a ring); the caller's list is not written.  The refusals are counted on the
  * device: x265_hip_ctx_guard_status waits for the stream and returns (and clears) their number and the lowest index of
  * one in its list; x265_hip_ctx_sync in this mode returns X265_HIP_ERANGE with a message if there were any since the
- * last look.  The remaining *_device entry points (predict, fullsearch, inter search / decide, lookahead, and the one
- * that allocates nothing) have no guard and keep mode 1's copy-back in mode 2; so do the guarded request lists while
+ * last look.  The remaining *_device entry points (predict, mc_satd, fullsearch, inter search / decide, merge estimation,
+ * lookahead, and the one that allocates nothing) have no guard and keep mode 1's copy-back in mode 2; so do the guarded request lists while
  * the context holds no plane that a replaced record could point at (64x64 samples at the origin with the filters'
  * margins). */
 int x265_hip_ctx_check_records(x265_hip_ctx *ctx, int mode);
