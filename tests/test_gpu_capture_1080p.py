@@ -86,6 +86,38 @@ def test_reference_encoder_calls_at_1080p_replay_bit_exactly(tmp_path):
     assert np.array_equal(out["mvp_x"], c["qmvp_x"]) and np.array_equal(out["mvp_y"], c["qmvp_y"])
     for k in ("mvmin_x", "mvmin_y", "mvmax_x", "mvmax_y", "cost", "mvx", "mvy"):
         assert np.array_equal(out[k], c[k]), k
+    # and what predInterSearch left in the CU for every prediction unit whose iterations are all among the recorded calls
+    # (pu.bin): bits, xCheckBestMVP, the bidirectional candidate and the choice through x265_hip_inter_decide_batch
+    from test_oracle_golden import check_pu_decisions
+    PU = np.dtype([("call", "<i4", (8,)), ("call_list", "u1", (8,)), ("call_ref", "u1", (8,)), ("n_calls", "u1"), ("is_p", "u1"),
+                   ("part_size", "u1"), ("part_idx", "u1"), ("num_ref", "u1", (2,)), ("bipred_restriction", "u1"), ("complete", "u1"),
+                   ("list_sel_bits", "u1", (3,)), ("merge_flag", "u1"), ("inter_dir", "u1"), ("pad", "u1", (3,)), ("lambda_sad", "<u4"),
+                   ("mv", "<i2", (4,)), ("ref", "i1", (2,)), ("mvp_idx", "i1", (2,))])
+    assert PU.itemsize == 80  # PuRec of oracle/enc_capture.cpp
+    pus = np.fromfile(tmp_path / "pu.bin", dtype=PU)
+    pus = pus[(pus["complete"] == 1) & (pus["n_calls"] == pus["num_ref"].sum(axis=1))]
+    order = np.concatenate([p["call"][:p["n_calls"]] for p in pus])
+    uj = np.zeros(len(order), abi.INTER_JOB)
+    for k in ("fenc_plane", "ref_plane", "pu_x", "pu_y", "pu_w", "pu_h", "method", "subme", "merange", "num_mvc", "qp", "mvc"):
+        uj[k] = calls[k][order]
+    for k in ("pred_plane", "cu_x", "cu_y", "amvp", "num_amvp"):
+        uj[k] = amvp[k][order]
+    uj["ref_lag"] = H
+    rec = np.zeros(len(pus), abi.INTER_PU)
+    rec["first_job"] = np.concatenate([[0], np.cumsum(pus["n_calls"])[:-1]])
+    rec["num_ref"], rec["list_sel_bits"], rec["lambda_sad"] = pus["num_ref"], pus["list_sel_bits"], pus["lambda_sad"]
+    rec["no_bidir"] = (pus["is_p"] != 0) | (pus["bipred_restriction"] != 0)
+    ctx3 = lib.Context(0)
+    for q in np.unique(calls["qp"]):
+        ctx3.set_qp(int(q))
+    for i, (buf, origin, stride) in enumerate(planes):
+        ctx3.plane_upload(i, buf, stride, origin)
+    res, units = ctx3.inter_decide_batch(uj, rec, W, H)
+    ctx3.close()
+    for k in ("cost", "mvx", "mvy"):
+        assert np.array_equal(res[k], calls[k][order]), k
+    n_dir = check_pu_decisions(units, rec, pus)
+    assert len(pus) > 10000 and n_dir[3] > 300 and n_dir[2] > 300, (len(pus), n_dir)
     sizes = {int(s): int((calls["pu_w"][calls["lowres"] == 0] == s).sum()) for s in (8, 16, 32, 64)}
     print(f"{len(calls)} calls of a 1080p medium-preset encode replayed ({int(calls['lowres'].sum())} lookahead; full-resolution "
           f"block sizes {sizes}; QPs {np.unique(calls['qp']).tolist()}), 0 mismatches")
