@@ -524,6 +524,25 @@ def test_mc_satd_and_merge_estimation(gpu_ctx, oracle, small_seq):
     with pytest.raises(lib.X265HipError):
         gpu_ctx.merge_estimate_batch(q, p0.w, p0.h)
     assert len(gpu_ctx.merge_estimate_batch(pus[:0], p0.w, p0.h)) == 0
+    # record-check mode 1 on the device forms: the records are copied back and refused like the host arrays
+    gpu_ctx.check_records(1)
+    try:
+        q = pus[:4].copy()
+        q["cand"]["ref_plane"][2, 0] = [300, -1]
+        d_pus, d_out = DeviceBuffer.from_array(q), DeviceBuffer(abi.MERGE_RESULT.itemsize * 4)
+        with pytest.raises(lib.X265HipError, match=r"merge_pu\[2\] candidate 0"):
+            gpu_ctx.merge_estimate_batch_device(d_pus.ptr, 4, p0.w, p0.h, d_out.ptr)
+        r = reqs[:4].copy()
+        r["qmv0_y"][1] = 4 * (p0.h + 400)
+        d_r = DeviceBuffer.from_array(r)
+        with pytest.raises(lib.X265HipError, match=r"pred_req\[1\]"):
+            gpu_ctx.mc_satd_batch_device(d_r.ptr, 4, d_out.ptr)
+        d_good = DeviceBuffer.from_array(reqs[:4])
+        gpu_ctx.mc_satd_batch_device(d_good.ptr, 4, d_out.ptr)
+        gpu_ctx.sync()
+        assert np.array_equal(d_out.download(np.int32)[:4], oracle.mc_satd_batch(planes, reqs[:4]))
+    finally:
+        gpu_ctx.check_records(False)
 
 
 def test_primitive_table_mc_entries(oracle):
