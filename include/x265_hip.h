@@ -313,8 +313,9 @@ typedef struct x265_hip_bidir_req
 /* With X265_HIP_MC_AVG in `metric` the two predictions are combined the way TComPrediction::xPredInterBi does
  * (14-bit intermediates + luma_addAvg, TComPrediction.cpp:330-355, 436-473; pixel.cpp:819-839) instead of
  * pixelavg_pp: with X265_HIP_SATD that is what TEncSearch::xMergeEstimation measures on a bi-directional merge
- * candidate (motionCompensation + bufSATD, TEncSearch.cpp:2209-2210), with X265_HIP_SA8D / X265_HIP_SSE what mode
- * decision measures on a bi-predicted block (compress.cpp:215, 265).
+ * candidate of a slice without weighted bi-prediction (motionCompensation + bufSATD, TEncSearch.cpp:2209-2210; every
+ * form of a candidate: x265_hip_merge_estimate_batch), with X265_HIP_SA8D / X265_HIP_SSE what mode decision measures
+ * on a bi-predicted block (compress.cpp:215, 265).
  * With X265_HIP_LOWRES_REF in `metric` the request is the lookahead's bidirectional cost (EstimateRow::
  * estimateCUCost, source/encoder/slicetype.cpp:1585-1603): ref0_plane .. +3 and ref1_plane .. +3 are the
  * lowresPlane[0..3] of two Lowres references, the block is an 8x8 CU of the lowres source picture, the two
@@ -489,9 +490,9 @@ int x265_hip_cost_batch_device_noalloc(x265_hip_ctx *ctx, const void *d_reqs, in
  *   2. the search window around it: TEncSearch::xSetSearchRange (:2600-2617) with the frame-parallel clamp ref_lag
  *      (m_refLagPixels, :110: the search range with frame threads, the picture height without);
  *   3. MotionEstimate::motionEstimate with that predictor, window and the job's candidate vectors (:2340).
- * What stays with the caller is the control plane around it: TComDataCU::fillMvpCand (the candidates come from
- * neighbouring CUs' final vectors), the bit counting of xGetBlkBits / BitCost::bitcost / xCheckBestMVP (:2343-2347,
- * 2565-2598: host floating-point tables over the two candidates, no pixels) and the choice between lists. */
+ * What stays with the caller of this entry point is the control plane around it: TComDataCU::fillMvpCand (the
+ * candidates come from neighbouring CUs' final vectors); the bit counting of xGetBlkBits / BitCost::bitcost /
+ * xCheckBestMVP (:2343-2347, 2565-2598) and the choice between the lists are x265_hip_inter_decide_batch below. */
 typedef struct x265_hip_inter_job
 {
     int32_t fenc_plane;
