@@ -87,14 +87,15 @@ int x265_hip_ctx_sync(x265_hip_ctx *ctx);
  * plane directory in device memory; nothing waits and nothing is copied back, and the call itself returns X265_HIP_OK.
  * x265_hip_me_batch_device checks every job in the kernel that sorts its list: a job that fails is searched by no
  * kernel and gets the result (cost -1, mv 0 0).  x265_hip_cost_batch_device, x265_hip_dist_batch_device,
- * x265_hip_refine_batch_device, x265_hip_refine_sections_device and x265_hip_bidir_cost_batch_device run a kernel that
+ * x265_hip_refine_batch_device, x265_hip_refine_sections_device, x265_hip_bidir_cost_batch_device,
+ * x265_hip_mc_satd_batch_device and x265_hip_fullsearch_device run a kernel that
  * writes a checked copy of the list into a buffer of the context (a record that fails is replaced by a harmless one of
  * its size) in front of the cost kernel, which reads the copy, and one behind it that sets the results of the
- * replaced records to -1 (all nine of a ring); the caller's list is not written.  The refusals are counted on the
+ * replaced records to -1 (all nine of a ring; a CTU's 85 results to cost -1, mv 0 0); the caller's list is not written.  The refusals are counted on the
  * device: x265_hip_ctx_guard_status waits for the stream and returns (and clears) their number and the lowest index of
  * one in its list; x265_hip_ctx_sync in this mode returns X265_HIP_ERANGE with a message if there were any since the
- * last look.  The remaining *_device entry points (predict, mc_satd, fullsearch, inter search / decide, merge estimation,
- * lookahead, and the one that allocates nothing) have no guard and keep mode 1's copy-back in mode 2; so do the guarded request lists while
+ * last look.  The remaining *_device entry points (predict, inter search / decide, merge estimation, lookahead, and
+ * the one that allocates nothing) have no guard and keep mode 1's copy-back in mode 2; so do the guarded request lists while
  * the context holds no plane that a replaced record could point at (64x64 samples at the origin with the filters'
  * margins). */
 int x265_hip_ctx_check_records(x265_hip_ctx *ctx, int mode);

@@ -1124,6 +1124,46 @@ def test_record_guard_of_the_request_lists(gpu_ctx, small_seq):
             assert (got[~ok] == -1).all() and (n_ref, first) == (len(idx), int(idx[0])), (name, n_ref, first, idx)
             got, n_ref, first = run(call, recs, per)  # a good list
             assert np.array_equal(got, want) and n_ref == 0, name
+        # prediction requests measured against the source (x265_hip_mc_satd_batch_device)
+        from conftest import random_pred_reqs
+        pr = np.concatenate([random_pred_reqs(rng, W, H, abi.PRED_REQ, abi.PARTS, dst_plane=1, refs=(0, 2), weighted_bi=True) for _ in range(20)])
+        want = gpu_ctx.mc_satd_batch(pr)
+        bi = np.nonzero(pr["ref1_plane"] >= 0)[0]
+        bad, idx = pr.copy(), np.sort(np.concatenate([rng.choice(bi, 3, replace=False), rng.choice(np.setdiff1d(np.arange(len(pr)), bi), 4, replace=False)]))
+        for i, (k, v) in zip(idx, [("ref0_plane", 300), ("dst_plane", -1), ("pu_w", 20), ("qmv0_y", 4 * (H + 400)), ("ref1_plane", 300), ("pu_y", H + 300),
+                                   ("log2_denom", 9)]):
+            bad[k][i] = v
+            if k == "log2_denom":
+                bad["weighted_bi"][i], bad["ref1_plane"][i] = 1, 0
+        for i in idx:
+            with pytest.raises(lib.X265HipError):
+                gpu_ctx.mc_satd_batch(bad[i:i + 1])
+        got, n_ref, first = run(gpu_ctx.mc_satd_batch_device, bad, 1)
+        ok = np.ones(len(pr), bool)
+        ok[idx] = False
+        assert np.array_equal(got[ok, 0], want[ok]) and (got[~ok] == -1).all() and (n_ref, first) == (len(idx), int(idx[0]))
+        # CTU full searches (x265_hip_fullsearch_device): refused CTUs give 85 x (cost -1, mv 0)
+        cj = np.zeros(12, lib.CTU_JOB)
+        cj["fenc_plane"], cj["ref_plane"], cj["qp"] = 1, rng.choice([0, 2], 12), 30
+        cj["ctu_x"], cj["ctu_y"] = 64 * rng.integers(0, W // 64, 12), 64 * rng.integers(0, H // 64, 12)
+        cj["mvmin_x"], cj["mvmin_y"], cj["mvmax_x"], cj["mvmax_y"] = -8, -6, 7, 9
+        want = gpu_ctx.fullsearch(cj)
+        bad = cj.copy()
+        bad["ref_plane"][2], bad["qp"][5], bad["mvmax_y"][6], bad["mvmax_x"][9], bad["ctu_y"][11] = 300, 81, 400, 200, H + 400
+        idx = np.array([2, 5, 6, 9, 11])
+        for i in idx:
+            with pytest.raises(lib.X265HipError):
+                gpu_ctx.fullsearch(bad[i:i + 1])
+        d, o = DeviceBuffer.from_array(bad), DeviceBuffer(8 * 85 * len(bad))
+        gpu_ctx.fullsearch_device(d.ptr, len(bad), o.ptr)
+        assert gpu_ctx.guard_status() == (5, 2)
+        got = o.download(abi.ME_RESULT).reshape(len(bad), 85)
+        ok = np.ones(len(bad), bool)
+        ok[idx] = False
+        assert np.array_equal(got[ok], want[ok])
+        assert (got["cost"][~ok] == -1).all() and (got["mvx"][~ok] == 0).all() and (got["mvy"][~ok] == 0).all()
+        d.free()
+        o.free()
         # rings in runs of one size (x265_hip_refine_sections_device)
         runs = [ring[ring["pu_w"] == w_] for w_ in (16, 8)]
         runs = [r_[r_["pu_h"] == r_["pu_w"]] for r_ in runs]

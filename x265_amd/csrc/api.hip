@@ -1882,15 +1882,27 @@ int x265_hip_mc_satd_batch_device(x265_hip_ctx *c, const void *d_reqs, int n, vo
         return X265_HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    const int safe = c->check_records == 2 ? guard_safe_plane(c) : -1;
     {
-        int vr = checked_records<x265_hip_pred_req>(c, d_reqs, n, [&](const x265_hip_pred_req *h) { return validate_pred(c, h, n, true); });
+        int vr = checked_records<x265_hip_pred_req>(c, d_reqs, n, [&](const x265_hip_pred_req *h) { return validate_pred(c, h, n, true); }, safe >= 0);
         if (vr)
             return vr;
     }
     int r = push_tabs(c);
     if (r)
         return r;
+    uint8_t *bad = nullptr;
+    if (safe >= 0)
+    {
+        void *sane;
+        if ((r = guard_room(c, n, sizeof(x265_hip_pred_req), &sane, &bad)))
+            return r;
+        LAUNCH(launch_guard_pred(c->dev_tabs, (const x265_hip_pred_req *)d_reqs, n, safe, (x265_hip_pred_req *)sane, bad, c->guard_words, c->stream));
+        d_reqs = sane;
+    }
     LAUNCH(launch_mc_satd(c->dev_tabs, (const x265_hip_pred_req *)d_reqs, n, (int32_t *)d_costs, c->batch_counter, c->batch_parity ^= 1, c->stream));
+    if (bad)
+        LAUNCH(launch_guard_fix(bad, n, 1, (int32_t *)d_costs, c->stream));
     return X265_HIP_OK;
 }
 
@@ -2067,15 +2079,34 @@ int x265_hip_fullsearch_device(x265_hip_ctx *c, const void *d_jobs, int n, void 
         return fail(X265_HIP_EINVAL, "fullsearch_device: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(c->device));
+    if (n == 0)
+        return X265_HIP_OK;
+    int safe = c->check_records == 2 ? guard_safe_plane(c) : -1, safe_qp = -1;
+    for (int q = 0; q < X265_HIP_MAX_QP && safe_qp < 0; q++)
+        if (c->host_tabs.costtab[q])
+            safe_qp = q;
+    if (safe_qp < 0)
+        safe = -1;
     {
-        int vr = checked_records<x265_hip_ctu_job>(c, d_jobs, n, [&](const x265_hip_ctu_job *h) { return validate_ctu(c, h, n); });
+        int vr = checked_records<x265_hip_ctu_job>(c, d_jobs, n, [&](const x265_hip_ctu_job *h) { return validate_ctu(c, h, n); }, safe >= 0);
         if (vr)
             return vr;
     }
     int r = push_tabs(c);
     if (r)
         return r;
+    uint8_t *bad = nullptr;
+    if (safe >= 0)
+    {
+        void *sane;
+        if ((r = guard_room(c, n, sizeof(x265_hip_ctu_job), &sane, &bad)))
+            return r;
+        LAUNCH(launch_guard_ctu(c->dev_tabs, (const x265_hip_ctu_job *)d_jobs, n, safe, safe_qp, (x265_hip_ctu_job *)sane, bad, c->guard_words, c->stream));
+        d_jobs = sane;
+    }
     LAUNCH(launch_fullsearch2(c->dev_tabs, (const x265_hip_ctu_job *)d_jobs, n, (x265_hip_me_result *)d_results, c->stream));
+    if (bad) // 85 results of two words each per CTU: cost -1, vector zero
+        LAUNCH(launch_guard_fix(bad, n, 2 * X265_HIP_PUS_PER_CTU, (int32_t *)d_results, c->stream, true));
     return X265_HIP_OK;
 }
 

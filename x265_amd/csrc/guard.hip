@@ -2,7 +2,7 @@
 //
 // The compute kernels take their records on trust: a record that names a missing plane or reaches outside one makes a
 // wave read outside a buffer.  With the guard on, a thread per record puts it through the checks the host-array entry
-// point makes (validate_cost / validate_dist / validate_refine / validate_bidir in api.hip, against the plane directory
+// point makes (validate_cost / validate_dist / validate_refine / validate_bidir / validate_ctu / validate_pred in api.hip, against the plane directory
 // and the planes' byte spans in device memory) and writes the list the kernel will run: a record that passes as it is, a
 // record that fails replaced by the same-sized block at the origin of a plane the host knows to be large enough, zero
 // vectors.  The hot kernels stay as they are; behind them a second pass sets the results of the replaced records to -1.
@@ -112,13 +112,70 @@ __global__ __launch_bounds__(256) void guard_bidir_kernel(const DeviceTables *ta
     bad[i] = !ok;
 }
 
-// results of the replaced records: `per` 32-bit words each (1 cost, or the 9 costs of a ring), all set to -1
-__global__ __launch_bounds__(256) void guard_fix_kernel(const uint8_t *bad, int n, int per, int32_t *out)
+// x265_hip_fullsearch_device (validate_ctu): a CTU that fails searches the one position of the safe plane's origin
+__global__ __launch_bounds__(256) void guard_ctu_kernel(const DeviceTables *tabs, const x265_hip_ctu_job *jobs, int n, int safe_plane, int safe_qp,
+                                                        x265_hip_ctu_job *sane, uint8_t *bad, uint32_t *words)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    x265_hip_ctu_job j = jobs[i];
+    const bool ok = guard_block(tabs, j.fenc_plane, j.ref_plane, 64, 64) && j.qp < X265_HIP_MAX_QP && tabs->costtab[j.qp] &&
+                    j.mvmin_x <= j.mvmax_x && j.mvmin_y <= j.mvmax_y && j.mvmax_x - j.mvmin_x <= 131 && j.mvmax_y - j.mvmin_y <= 131 &&
+                    guard_inside(tabs, j.fenc_plane, j.ctu_x, j.ctu_y, 64, 64) &&
+                    guard_reach(tabs, j.ref_plane, (long)j.ctu_x + j.mvmin_x, (long)j.ctu_y + j.mvmin_y, (long)j.ctu_x + j.mvmax_x + 64,
+                                (long)j.ctu_y + j.mvmax_y + 64);
+    if (!ok)
+    {
+        guard_refuse(words, i);
+        j.qp = (uint8_t)safe_qp;
+        j.fenc_plane = j.ref_plane = safe_plane;
+        j.ctu_x = j.ctu_y = j.mvmin_x = j.mvmin_y = j.mvmax_x = j.mvmax_y = j.qmvp_x = j.qmvp_y = 0;
+    }
+    sane[i] = j;
+    bad[i] = !ok;
+}
+
+// x265_hip_mc_satd_batch_device (validate_pred as mc_satd uses it: nothing is written, the "destination" is the source)
+__global__ __launch_bounds__(256) void guard_pred_kernel(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int n, int safe_plane,
+                                                         x265_hip_pred_req *sane, uint8_t *bad, uint32_t *words)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    x265_hip_pred_req q = reqs[i];
+    bool ok = guard_block(tabs, q.dst_plane, q.ref0_plane, q.pu_w, q.pu_h) &&
+              (q.ref1_plane < 0 || guard_block(tabs, q.dst_plane, q.ref1_plane, q.pu_w, q.pu_h));
+    if (ok && q.ref1_plane == X265_HIP_PRED_WEIGHTED)
+        ok = q.log2_denom <= 7 && q.qmv1_x >= -128 && q.qmv1_x <= 255 && q.qmv1_y >= -128 && q.qmv1_y <= 127;
+    if (ok && q.weighted_bi)
+        ok = q.ref1_plane >= 0 && q.log2_denom <= 7 && q.wp_w0 >= -128 && q.wp_w0 <= 255 && q.wp_w1 >= -128 && q.wp_w1 <= 255 &&
+             q.wp_o0 >= -128 && q.wp_o0 <= 127 && q.wp_o1 >= -128 && q.wp_o1 <= 127;
+    ok = ok && guard_inside(tabs, q.dst_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h) &&
+         guard_displaced(tabs, q.ref0_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv0_x, q.qmv0_y) &&
+         (q.ref1_plane < 0 || guard_displaced(tabs, q.ref1_plane, q.pu_x, q.pu_y, q.pu_w, q.pu_h, q.qmv1_x, q.qmv1_y));
+    if (!ok)
+    {
+        guard_refuse(words, i);
+        const bool part = guard_partition(q.pu_w, q.pu_h);
+        q = x265_hip_pred_req{};
+        q.pu_w = part ? reqs[i].pu_w : 8;
+        q.pu_h = part ? reqs[i].pu_h : 8;
+        q.dst_plane = q.ref0_plane = safe_plane;
+        q.ref1_plane = -1;
+    }
+    sane[i] = q;
+    bad[i] = !ok;
+}
+
+// results of the replaced records: `per` 32-bit words each (1 cost, the 9 costs of a ring, or with `pairs` the 85
+// (cost, mv) results of a CTU), costs set to -1 and vectors to zero
+__global__ __launch_bounds__(256) void guard_fix_kernel(const uint8_t *bad, int n, int per, int pairs, int32_t *out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n && bad[i])
         for (int k = 0; k < per; k++)
-            out[(size_t)i * per + k] = -1;
+            out[(size_t)i * per + k] = (pairs && (k & 1)) ? 0 : -1;
 }
 
 void launch_guard_cost(const DeviceTables *tabs, const x265_hip_cost_req *reqs, int n, int max_metric, int safe_plane, x265_hip_cost_req *sane, uint8_t *bad,
@@ -139,9 +196,21 @@ void launch_guard_bidir(const DeviceTables *tabs, const x265_hip_bidir_req *reqs
     hipLaunchKernelGGL(guard_bidir_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tabs, reqs, n, safe_plane, sane, bad, words);
 }
 
-void launch_guard_fix(const uint8_t *bad, int n, int per, int32_t *out, hipStream_t st)
+void launch_guard_ctu(const DeviceTables *tabs, const x265_hip_ctu_job *jobs, int n, int safe_plane, int safe_qp, x265_hip_ctu_job *sane, uint8_t *bad,
+                      uint32_t *words, hipStream_t st)
 {
-    hipLaunchKernelGGL(guard_fix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bad, n, per, out);
+    hipLaunchKernelGGL(guard_ctu_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tabs, jobs, n, safe_plane, safe_qp, sane, bad, words);
+}
+
+void launch_guard_pred(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int n, int safe_plane, x265_hip_pred_req *sane, uint8_t *bad,
+                       uint32_t *words, hipStream_t st)
+{
+    hipLaunchKernelGGL(guard_pred_kernel, dim3((n + 255) / 256), dim3(256), 0, st, tabs, reqs, n, safe_plane, sane, bad, words);
+}
+
+void launch_guard_fix(const uint8_t *bad, int n, int per, int32_t *out, hipStream_t st, bool pairs)
+{
+    hipLaunchKernelGGL(guard_fix_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bad, n, per, pairs ? 1 : 0, out);
 }
 
 } // namespace x265hip

@@ -102,7 +102,11 @@ void launch_guard_refine(const DeviceTables *tabs, const x265_hip_refine_req *re
                          uint32_t *words, hipStream_t st);
 void launch_guard_bidir(const DeviceTables *tabs, const x265_hip_bidir_req *reqs, int n, int safe_plane, x265_hip_bidir_req *sane, uint8_t *bad,
                         uint32_t *words, hipStream_t st);
-void launch_guard_fix(const uint8_t *bad, int n, int per, int32_t *out, hipStream_t st);
+void launch_guard_ctu(const DeviceTables *tabs, const x265_hip_ctu_job *jobs, int n, int safe_plane, int safe_qp, x265_hip_ctu_job *sane, uint8_t *bad,
+                      uint32_t *words, hipStream_t st);
+void launch_guard_pred(const DeviceTables *tabs, const x265_hip_pred_req *reqs, int n, int safe_plane, x265_hip_pred_req *sane, uint8_t *bad,
+                       uint32_t *words, hipStream_t st);
+void launch_guard_fix(const uint8_t *bad, int n, int per, int32_t *out, hipStream_t st, bool pairs = false);
 // inter_decide.hip: predInterSearch behind its iterations (`bireq`: 2 npu requests for launch_bidir_cost, whose 2 npu
 // costs are `satd`)
 void launch_inter_decide_lists(const DeviceTables *tabs, const x265_hip_inter_job *jobs, const x265_hip_inter_result *res, const x265_hip_inter_pu *pus, int npu,
