@@ -177,6 +177,29 @@ def test_me_stage_whole_4k_frame_three_refs(uhd, oracle):
     assert len(bad) == 0, (len(bad), jobs[bad[0]], got[bad[0]], want[bad[0]])
 
 
+@pytest.mark.parametrize("lists", [([2, 1, 0], []), ([2, 1], [0])], ids=["P", "B"])
+def test_inter_stage_whole_4k_picture(uhd, oracle, lists):
+    """predInterSearch as a stage at configs[3]'s size (what bench.py's inter_stage leg times): every square PU of a 4K
+    picture as a prediction unit with three (list, reference) iterations -- a P picture, and a B picture with the
+    bidirectional candidate -- through x265_hip_inter_decide_batch; iterations and units equal to the oracle's"""
+    from x265_amd import abi, lib, synth
+    seq, planes, ctx = uhd
+    refs = lists[0] + lists[1]
+    mj = synth.me_jobs(3840, 2160, 3, refs, [seq.global_motion(3, r) for r in refs], method=abi.HEX, subme=2, merange=57, seed=3)
+    ij, pu = synth.inter_units(mj, len(refs), 2160, n_list1=len(lists[1]))
+    assert len(ij) == 3 * 172020 and len(pu) == 172020
+    res, units = ctx.inter_decide_batch(ij, pu, 3840, 2160)
+    tabs = {q: lib.costtab_build(q) for q in range(28, 40)}
+    pl = [p.as_tuple() for p in planes]
+    wres = oracle.inter_search_batch(pl, tabs, ij, 3840, 2160)
+    assert np.array_equal(res, wres.view(res.dtype))
+    want = oracle.inter_decide_batch(pl, tabs, ij, wres, pu, 3840, 2160)
+    bad = np.nonzero(np.array([g.tobytes() != w.tobytes() for g, w in zip(units, want)]))[0]
+    assert len(bad) == 0, (len(bad), units[bad[0]], want[bad[0]])
+    if lists[1]:
+        assert (units["inter_dir"] == 3).sum() > 1000 and units["zero_tried"].sum() > 100
+
+
 def test_satd_candidates_whole_4k_frame_three_refs(uhd, oracle):
     """the list bench.py times (configs[3]: square PUs x 3 references x 16 half-/quarter-pel candidates, 8.26 M
     interpolation + SATD requests), every cost equal to the oracle's"""
